@@ -1,0 +1,598 @@
+"""cfd-proxy_amd -- Python host side of the MI355X-native CFD-Proxy hot path.
+
+The product is the C-ABI library ``lib/libcfdproxy_hip.so`` (C host code + hand-written
+gfx950 HIP kernels; see ``include/*.h``).  This module is a thin ctypes binding of that
+ABI for tests, ``bench.py`` and the multi-process (one rank per GPU, torch.distributed /
+RCCL) driver.  PyTorch is only plumbing here: device buffers handed to RCCL and the
+process group.  Nothing in this module computes on the CPU: without the HIP library and
+a GPU the solver classes raise.
+
+The directory name contains a hyphen, so import it with ``importlib`` (see
+``__graft_entry__.py``) -- it registers itself as ``cfd_proxy_amd``.
+
+Reference interfaces mirrored (file:line into /root/reference/src):
+  Domain            <- solver_data + comm_data              solver_data.h:66-81, comm_data.h:15-55
+  load_domain       <- main()'s open/read sequence           hybrid.f6.c:56-79
+  Plan              <- init_threads()                        threads.c:730-788
+  GpuPartition      <- compute_gradients_gg_* / compute_psd_flux / exchange_dbl_copy_in/out
+                                                             gradients.c:150-336, flux.c:194-200,
+                                                             threads.c:791-869
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+NGRAD = 7
+NFLUX = 3
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+
+FLUX_CONSISTENT = 0
+FLUX_REFERENCE = 1
+TILES_ALL, TILES_BOUNDARY, TILES_INTERIOR = 0, 1, 2
+VAR_ONE, VAR_HASH, VAR_LINEAR = 0, 1, 2
+
+
+# --------------------------------------------------------------------------- build / load
+def build(verbose: bool = False) -> None:
+    """Compile the host library, the HIP library (gfx950) and the driver in-tree."""
+    r = subprocess.run(["make", "-C", _HERE, "all"], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode:
+        raise RuntimeError("building cfd-proxy_amd failed")
+
+
+def _load(name: str) -> C.CDLL:
+    path = os.path.join(_HERE, "lib", name)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `make -C cfd-proxy_amd` (or __graft_entry__.build())")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+_host_lib: Optional[C.CDLL] = None
+_hip_lib: Optional[C.CDLL] = None
+
+
+class SolverData(C.Structure):
+    _fields_ = [
+        ("nfaces", C.c_int), ("nallfaces", C.c_int), ("nownpoints", C.c_int),
+        ("nallpoints", C.c_int), ("ncolors", C.c_int),
+        ("fpoint", C.POINTER(C.c_int)), ("fnormal", C.POINTER(C.c_double)),
+        ("pvolume", C.POINTER(C.c_double)), ("var", C.POINTER(C.c_double)),
+        ("grad", C.POINTER(C.c_double)), ("psd_flux", C.POINTER(C.c_double)),
+        ("fcolor", C.c_void_p), ("niter", C.c_int), ("gpu", C.c_void_p),
+    ]
+
+
+class CommData(C.Structure):
+    _fields_ = [
+        ("nProc", C.c_int), ("iProc", C.c_int), ("ndomains", C.c_int), ("ncommdomains", C.c_int),
+        ("nownpoints", C.c_int), ("naddpoints", C.c_int),
+        ("addpoint_owner", C.POINTER(C.c_int)), ("addpoint_id", C.POINTER(C.c_int)),
+        ("commpartner", C.POINTER(C.c_int)), ("sendcount", C.POINTER(C.c_int)),
+        ("recvcount", C.POINTER(C.c_int)),
+        ("recvindex", C.POINTER(C.POINTER(C.c_int))), ("sendindex", C.POINTER(C.POINTER(C.c_int))),
+        ("nreq", C.c_int), ("req", C.c_void_p), ("stat", C.c_void_p),
+        ("recvbuf", C.c_void_p), ("sendbuf", C.c_void_p),
+        ("remote_recv_offset", C.c_void_p), ("local_recv_offset", C.c_void_p),
+        ("local_send_offset", C.c_void_p), ("notification", C.c_void_p),
+        ("recv_flag", C.c_void_p), ("send_flag", C.c_void_p),
+        ("recv_stage", C.c_int), ("send_stage", C.c_int), ("comm_stage", C.c_int),
+        ("group", C.c_void_p),
+    ]
+
+
+class GenParams(C.Structure):
+    _fields_ = [
+        ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("ndomains", C.c_int),
+        ("connectivity", C.c_int), ("normals", C.c_int), ("volumes", C.c_int),
+        ("ghost_faces", C.c_int), ("cdf_version", C.c_int), ("seed", C.c_uint64),
+    ]
+
+
+class MergeInfo(C.Structure):
+    _fields_ = [
+        ("G", C.c_int), ("r", C.c_int), ("ndomains_total", C.c_int), ("ndom_local", C.c_int),
+        ("domain_ids", C.POINTER(C.c_int)), ("own_offset", C.POINTER(C.c_int)),
+        ("local2merged", C.POINTER(C.POINTER(C.c_int))),
+        ("nghost", C.c_int), ("ghost_domain", C.POINTER(C.c_int)), ("ghost_idx", C.POINTER(C.c_int)),
+        ("npartners", C.c_int), ("partner", C.POINTER(C.c_int)), ("want_off", C.POINTER(C.c_int)),
+        ("nfaces_in", C.c_long), ("nfaces_dropped", C.c_long),
+    ]
+
+
+class TileDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("pstart", "npts", "nhalo", "nfaces", "ninc", "halo_off", "blob_off", "blob_qw")]
+
+
+class PlanOpts(C.Structure):
+    _fields_ = [("tile_points", C.c_int), ("boundary_first", C.c_int)]
+
+
+class PlanStruct(C.Structure):
+    _fields_ = [
+        ("nown", C.c_int), ("nall", C.c_int), ("nfaces_used", C.c_long),
+        ("ntiles", C.c_int), ("nbtiles", C.c_int), ("tile_points", C.c_int),
+        ("new2old", C.POINTER(C.c_int)), ("old2new", C.POINTER(C.c_int)),
+        ("tiles", C.POINTER(TileDesc)),
+        ("halo_idx", C.POINTER(C.c_int)), ("nhalo_total", C.c_long),
+        ("blob", C.POINTER(C.c_ubyte)), ("blob_bytes", C.c_long),
+        ("vol", C.POINTER(C.c_double)), ("degree", C.POINTER(C.c_int)),
+        ("lds_grad", C.c_long), ("lds_flux", C.c_long),
+        ("lds_grad_cls", C.c_long * 2), ("lds_flux_cls", C.c_long * 2),
+        ("nfaces_dup", C.c_long), ("ninc_total", C.c_long),
+        ("npartners", C.c_int), ("partner", C.POINTER(C.c_int)),
+        ("send_off", C.POINTER(C.c_int)), ("send_idx", C.POINTER(C.c_int)),
+        ("recv_off", C.POINTER(C.c_int)),
+    ]
+
+
+def _declare_host(lib: C.CDLL) -> None:
+    P = C.POINTER
+    lib.cfdp_gen_domain.argtypes = [P(GenParams), C.c_int, P(SolverData), P(CommData)]
+    lib.cfdp_gen_write_domain.argtypes = [P(GenParams), C.c_int, C.c_char_p, C.c_int]
+    lib.cfdp_write_domain_file.argtypes = [C.c_char_p, P(SolverData), P(CommData), C.c_int]
+    lib.cfdp_gen_global_ids.argtypes = [P(GenParams), C.c_int, P(C.c_int)]
+    lib.cfdp_free_solver_data.argtypes = [P(SolverData)]
+    lib.cfdp_free_solver_data.restype = None
+    lib.cfdp_free_comm_data.argtypes = [P(CommData)]
+    lib.cfdp_free_comm_data.restype = None
+    lib.cfdp_load_domain.argtypes = [C.c_char_p, C.c_int, C.c_int, P(SolverData), P(CommData)]
+    lib.cfdp_domain_rank.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.cfdp_rank_domains.argtypes = [C.c_int, C.c_int, C.c_int, P(C.c_int), P(C.c_int)]
+    lib.cfdp_rank_domains.restype = None
+    lib.cfdp_merge_domains.argtypes = [C.c_int, P(C.c_int), P(SolverData), P(CommData), C.c_int,
+                                       C.c_int, C.c_int, P(SolverData), P(CommData),
+                                       P(P(MergeInfo))]
+    lib.cfdp_merge_set_send.argtypes = [P(CommData), P(MergeInfo), C.c_int, C.c_int, P(C.c_int),
+                                        P(C.c_int)]
+    lib.cfdp_merge_link_group.argtypes = [C.c_int, P(P(CommData)), P(P(MergeInfo))]
+    lib.cfdp_merge_link_group.restype = None
+    lib.cfdp_merge_scatter.argtypes = [P(MergeInfo), C.c_int, C.c_int, C.c_int, P(C.c_double),
+                                       P(C.c_double)]
+    lib.cfdp_merge_scatter.restype = None
+    lib.cfdp_merge_info_free.argtypes = [P(MergeInfo)]
+    lib.cfdp_merge_info_free.restype = None
+    lib.cfdp_plan_default_opts.argtypes = [P(PlanOpts)]
+    lib.cfdp_plan_default_opts.restype = None
+    lib.cfdp_plan_build.argtypes = [P(SolverData), P(CommData), P(PlanOpts)]
+    lib.cfdp_plan_build.restype = P(PlanStruct)
+    lib.cfdp_plan_free.argtypes = [P(PlanStruct)]
+    lib.cfdp_plan_free.restype = None
+    lib.cfdp_algo_bytes_grad.argtypes = [C.c_long, C.c_long, C.c_long]
+    lib.cfdp_algo_bytes_grad.restype = C.c_double
+    lib.cfdp_algo_bytes_flux.argtypes = [C.c_long, C.c_long, C.c_long]
+    lib.cfdp_algo_bytes_flux.restype = C.c_double
+    lib.cfdp_fill_var.argtypes = [P(C.c_double), P(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int]
+    lib.cfdp_fill_var.restype = None
+    lib.cfdp_nc_open.argtypes = [C.c_char_p]
+    lib.cfdp_nc_close.argtypes = [C.c_int]
+    lib.cfdp_nc_close.restype = None
+    lib.get_nc_val.argtypes = [C.c_int, C.c_char_p]
+    lib.get_nc_int.argtypes = [C.c_int, C.c_char_p, P(C.c_int)]
+    lib.get_nc_int.restype = None
+    lib.get_nc_double.argtypes = [C.c_int, C.c_char_p, P(C.c_double)]
+    lib.get_nc_double.restype = None
+    lib.cfdp_host_version.restype = C.c_char_p
+
+
+def _declare_hip(lib: C.CDLL) -> None:
+    P = C.POINTER
+    vp = C.c_void_p
+    lib.cfdp_gpu_device_count.restype = C.c_int
+    lib.cfdp_gpu_last_error.restype = C.c_char_p
+    lib.cfdp_gpu_create.argtypes = [C.c_int, P(vp)]
+    lib.cfdp_gpu_destroy.argtypes = [vp]
+    lib.cfdp_gpu_destroy.restype = None
+    lib.cfdp_gpu_upload_plan.argtypes = [vp, P(PlanStruct)]
+    lib.cfdp_gpu_bind_grad.argtypes = [vp, vp]
+    lib.cfdp_gpu_bind_sendbuf.argtypes = [vp, vp]
+    for n in ("set_var", "set_grad", "set_flux", "get_grad", "get_flux"):
+        getattr(lib, "cfdp_gpu_" + n).argtypes = [vp, P(C.c_double)]
+    lib.cfdp_gpu_set_variant.argtypes = [vp, C.c_int, C.c_int]
+    lib.cfdp_gpu_gradients.argtypes = [vp, C.c_int, vp]
+    lib.cfdp_gpu_flux.argtypes = [vp, C.c_int, vp]
+    lib.cfdp_gpu_pack.argtypes = [vp, vp]
+    lib.cfdp_gpu_unpack.argtypes = [vp, vp, vp]
+    lib.cfdp_gpu_sync.argtypes = [vp]
+    lib.cfdp_gpu_stream.argtypes = [vp, C.c_int]
+    lib.cfdp_gpu_stream.restype = vp
+    lib.cfdp_gpu_npartners.argtypes = [vp]
+    lib.cfdp_gpu_partner_rank.argtypes = [vp, C.c_int]
+    lib.cfdp_gpu_send_ptr.argtypes = [vp, C.c_int, P(C.c_size_t)]
+    lib.cfdp_gpu_send_ptr.restype = vp
+    lib.cfdp_gpu_recv_ptr.argtypes = [vp, C.c_int, P(C.c_size_t)]
+    lib.cfdp_gpu_recv_ptr.restype = vp
+    lib.cfdp_gpu_grad_ptr.argtypes = [vp]
+    lib.cfdp_gpu_grad_ptr.restype = vp
+    lib.cfdp_gpu_var_ptr.argtypes = [vp]
+    lib.cfdp_gpu_var_ptr.restype = vp
+    lib.cfdp_gpu_iteration_group.argtypes = [P(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.cfdp_gpu_rank_gradients.argtypes = [P(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.cfdp_gpu_rank_flux.argtypes = [P(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.cfdp_gpu_sync_group.argtypes = [P(vp), C.c_int]
+    lib.cfdp_gpu_time_kernels.argtypes = [vp, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]
+    lib.cfdp_gpu_run_iterations.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]
+    lib.cfdp_gpu_counts.argtypes = [vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
+
+
+def host_lib() -> C.CDLL:
+    """C host side only (loader, generator, merger, tiler); usable without a GPU."""
+    global _host_lib
+    if _host_lib is None:
+        _host_lib = _load("libcfdproxy_host.so")
+        _declare_host(_host_lib)
+    return _host_lib
+
+
+def hip_lib() -> C.CDLL:
+    """The C-ABI library with the HIP kernels.  Loading needs ROCm, running needs a GPU."""
+    global _hip_lib
+    if _hip_lib is None:
+        _hip_lib = _load("libcfdproxy_hip.so")
+        _declare_hip(_hip_lib)
+    return _hip_lib
+
+
+def _np_view(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    if n == 0 or not ptr:
+        return np.zeros(shape, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape)
+
+
+# --------------------------------------------------------------------------------- Domain
+class Domain:
+    """One partition: the reference's (solver_data, comm_data) pair with numpy views."""
+
+    def __init__(self, owns: bool = True):
+        self.sd = SolverData()
+        self.cd = CommData()
+        self._owns = owns
+        self.merge_info = None  # set for merged partitions
+
+    # numpy views onto the C arrays (no copies)
+    @property
+    def nown(self): return self.sd.nownpoints
+    @property
+    def nall(self): return self.sd.nallpoints
+    @property
+    def nfaces(self): return self.sd.nfaces
+    @property
+    def fpoint(self): return _np_view(self.sd.fpoint, (self.nfaces, 2), np.int32)
+    @property
+    def fnormal(self): return _np_view(self.sd.fnormal, (self.nfaces, 3), np.float64)
+    @property
+    def pvolume(self): return _np_view(self.sd.pvolume, (self.nall,), np.float64)
+    @property
+    def var(self): return _np_view(self.sd.var, (self.nall, NGRAD), np.float64)
+    @property
+    def grad(self): return _np_view(self.sd.grad, (self.nall, NGRAD, 3), np.float64)
+    @property
+    def psd_flux(self): return _np_view(self.sd.psd_flux, (self.nall, NFLUX), np.float64)
+
+    @property
+    def partners(self) -> List[int]:
+        return [self.cd.commpartner[i] for i in range(self.cd.ncommdomains)] if self.cd.ndomains > 1 else []
+
+    def sendindex(self, k: int) -> np.ndarray:
+        n = self.cd.sendcount[k]
+        if n == 0 or not self.cd.sendindex or not self.cd.sendindex[k]:
+            return np.zeros(0, np.int32)
+        return np.ctypeslib.as_array(self.cd.sendindex[k], shape=(n,)).copy()
+
+    def recvindex(self, k: int) -> np.ndarray:
+        n = self.cd.recvcount[k]
+        if n == 0 or not self.cd.recvindex or not self.cd.recvindex[k]:
+            return np.zeros(0, np.int32)
+        return np.ctypeslib.as_array(self.cd.recvindex[k], shape=(n,)).copy()
+
+    def send_points(self) -> np.ndarray:
+        idx = [self.sendindex(k) for k in self.partners]
+        return np.unique(np.concatenate(idx)) if idx else np.zeros(0, np.int32)
+
+    def addpoint_owner(self): return _np_view(self.cd.addpoint_owner, (self.cd.naddpoints,), np.int32)
+    def addpoint_id(self): return _np_view(self.cd.addpoint_id, (self.cd.naddpoints,), np.int32)
+
+    def write(self, path: str, cdf_version: int = 1) -> None:
+        rc = host_lib().cfdp_write_domain_file(path.encode(), C.byref(self.sd), C.byref(self.cd), cdf_version)
+        if rc:
+            raise IOError(f"writing {path} failed ({rc})")
+
+    def free(self) -> None:
+        if self._owns:
+            lib = host_lib()
+            lib.cfdp_free_solver_data(C.byref(self.sd))
+            lib.cfdp_free_comm_data(C.byref(self.cd))
+            if self.merge_info is not None:
+                lib.cfdp_merge_info_free(self.merge_info)
+                self.merge_info = None
+            self._owns = False
+
+
+def gen_params(nx, ny=None, nz=None, ndomains=1, connectivity=7, normals=1, volumes=1,
+               ghost_faces=0, cdf_version=1, seed=20241) -> GenParams:
+    ny = nx if ny is None else ny
+    nz = nx if nz is None else nz
+    return GenParams(nx, ny, nz, ndomains, connectivity, normals, volumes, ghost_faces, cdf_version, seed)
+
+
+def gen_domain(gp: GenParams, domain: int) -> Domain:
+    d = Domain()
+    rc = host_lib().cfdp_gen_domain(C.byref(gp), domain, C.byref(d.sd), C.byref(d.cd))
+    if rc:
+        raise RuntimeError("generator failed")
+    return d
+
+
+def gen_global_ids(gp: GenParams, domain: int, nall: int) -> np.ndarray:
+    gid = np.zeros(nall, np.int32)
+    n = host_lib().cfdp_gen_global_ids(C.byref(gp), domain, gid.ctypes.data_as(C.POINTER(C.c_int)))
+    assert n == nall, (n, nall)
+    return gid
+
+
+def write_mesh(gp: GenParams, prefix: str, lvl: int, domains: Optional[Sequence[int]] = None) -> None:
+    """Write "<prefix>_domain_<d>_lvl_<lvl>" (reference file naming, hybrid.f6.c:58-62)."""
+    lib = host_lib()
+    for d in (range(gp.ndomains) if domains is None else domains):
+        rc = lib.cfdp_gen_write_domain(C.byref(gp), d, prefix.encode(), lvl)
+        if rc:
+            raise IOError(f"writing domain {d} failed ({rc})")
+
+
+def load_domain(prefix: str, domain: int, lvl: int) -> Domain:
+    d = Domain()
+    host_lib().cfdp_load_domain(prefix.encode(), domain, lvl, C.byref(d.sd), C.byref(d.cd))
+    return d
+
+
+def fill_var(dom: Domain, gid: Optional[np.ndarray], kind: int, nx=1, ny=1, nz=1) -> None:
+    g = None if gid is None else np.ascontiguousarray(gid, np.int32)
+    host_lib().cfdp_fill_var(dom.sd.var, None if g is None else g.ctypes.data_as(C.POINTER(C.c_int)),
+                             dom.nall, kind, nx, ny, nz)
+
+
+def rank_domains(r: int, N: int, G: int):
+    f, c = C.c_int(), C.c_int()
+    host_lib().cfdp_rank_domains(r, N, G, C.byref(f), C.byref(c))
+    return f.value, c.value
+
+
+def merge_domains(doms: Sequence[Domain], domain_ids: Sequence[int], N: int, G: int, r: int) -> Domain:
+    """N/G loaded domains -> the partition of GPU rank r (domain_merge.c)."""
+    lib = host_lib()
+    n = len(doms)
+    sds = (SolverData * n)(*[d.sd for d in doms])
+    cds = (CommData * n)(*[d.cd for d in doms])
+    ids = (C.c_int * n)(*domain_ids)
+    out = Domain()
+    info = C.POINTER(MergeInfo)()
+    rc = lib.cfdp_merge_domains(n, ids, sds, cds, N, G, r, C.byref(out.sd), C.byref(out.cd), C.byref(info))
+    if rc:
+        raise RuntimeError("merge failed")
+    out.merge_info = info
+    return out
+
+
+def merge_requests(part: Domain):
+    """{partner rank: (domains, idx)} -- which points this rank wants, in message order."""
+    mi = part.merge_info.contents
+    out = {}
+    for i in range(mi.npartners):
+        a, b = mi.want_off[i], mi.want_off[i + 1]
+        out[mi.partner[i]] = (np.array(mi.ghost_domain[a:b], np.int32), np.array(mi.ghost_idx[a:b], np.int32))
+    return out
+
+
+def merge_set_send(part: Domain, s: int, domains: np.ndarray, idx: np.ndarray) -> None:
+    d = np.ascontiguousarray(domains, np.int32)
+    i = np.ascontiguousarray(idx, np.int32)
+    ip = C.POINTER(C.c_int)
+    host_lib().cfdp_merge_set_send(C.byref(part.cd), part.merge_info, s, len(d), d.ctypes.data_as(ip),
+                                   i.ctypes.data_as(ip))
+
+
+def merge_link_group(parts: Sequence[Domain]) -> None:
+    """All ranks in this process: wire every rank's send lists (no communication needed)."""
+    for s, ps in enumerate(parts):
+        for r, (dom, idx) in merge_requests(ps).items():
+            merge_set_send(parts[r], s, dom, idx)
+
+
+def merge_scatter(part: Domain, dl: int, npoints_d: int, field: np.ndarray) -> np.ndarray:
+    """merged per-point field -> file numbering of local domain dl (ghost rows included)."""
+    f = np.ascontiguousarray(field, np.float64)
+    rowlen = int(np.prod(f.shape[1:])) if f.ndim > 1 else 1
+    out = np.zeros((npoints_d,) + f.shape[1:], np.float64)
+    dp = C.POINTER(C.c_double)
+    host_lib().cfdp_merge_scatter(part.merge_info, dl, npoints_d, rowlen, f.ctypes.data_as(dp),
+                                  out.ctypes.data_as(dp))
+    return out
+
+
+def algo_bytes_grad(nfaces: int, nown: int, nadd: int) -> float:
+    return host_lib().cfdp_algo_bytes_grad(nfaces, nown, nadd)
+
+
+def algo_bytes_flux(nfaces: int, nown: int, nadd: int) -> float:
+    return host_lib().cfdp_algo_bytes_flux(nfaces, nown, nadd)
+
+
+# ----------------------------------------------------------------------------------- Plan
+class Plan:
+    """The GPU tiling of one partition (host/tiling.c) -- the init_threads() analogue."""
+
+    def __init__(self, dom: Domain, tile_points: int = 0, boundary_first: bool = True):
+        lib = host_lib()
+        o = PlanOpts()
+        lib.cfdp_plan_default_opts(C.byref(o))
+        if tile_points:
+            o.tile_points = tile_points
+        o.boundary_first = 1 if boundary_first else 0
+        self.ptr = lib.cfdp_plan_build(C.byref(dom.sd), C.byref(dom.cd), C.byref(o))
+        if not self.ptr:
+            raise RuntimeError("plan build failed")
+        self.p = self.ptr.contents
+
+    def __getattr__(self, name):
+        return getattr(self.p, name)
+
+    @property
+    def new2old(self): return np.ctypeslib.as_array(self.p.new2old, shape=(self.p.nall,))
+    @property
+    def old2new(self): return np.ctypeslib.as_array(self.p.old2new, shape=(self.p.nall,))
+
+    def tile(self, t: int) -> TileDesc:
+        return self.p.tiles[t]
+
+    def tile_arrays(self, t: int):
+        """(normals[E,3], inc[I], ioff[T+1], halo[H]) of tile t, decoded from the blob."""
+        td = self.p.tiles[t]
+        blob = np.ctypeslib.as_array(self.p.blob, shape=(self.p.blob_bytes,))
+        b0 = td.blob_off * 16
+        fnb = (td.nfaces * 24 + 15) & ~15
+        incb = (td.ninc * 4 + 15) & ~15
+        fn = blob[b0:b0 + td.nfaces * 24].view(np.float64).reshape(-1, 3)
+        inc = blob[b0 + fnb:b0 + fnb + td.ninc * 4].view(np.uint32)
+        ioff = blob[b0 + fnb + incb:b0 + fnb + incb + (td.npts + 1) * 4].view(np.uint32)
+        halo = np.ctypeslib.as_array(self.p.halo_idx, shape=(max(self.p.nhalo_total, 1),))[
+            td.halo_off:td.halo_off + td.nhalo]
+        return fn, inc, ioff, halo
+
+    def free(self):
+        if self.ptr:
+            host_lib().cfdp_plan_free(self.ptr)
+            self.ptr = None
+
+
+# --------------------------------------------------------------------------- GpuPartition
+class GpuError(RuntimeError):
+    pass
+
+
+class GpuPartition:
+    """One partition resident on one MI355X, driven through the C ABI (cfdproxy_hip.h)."""
+
+    def __init__(self, dom: Domain, device: int = 0, tile_points: int = 0, boundary_first: bool = True,
+                 grad_lanes: int = 0, flux_lanes: int = 0):
+        self.lib = hip_lib()
+        if self.lib.cfdp_gpu_device_count() <= 0:
+            raise GpuError("no HIP device: the CFD-Proxy hot path has no CPU fallback")
+        self.dom = dom
+        self.h = C.c_void_p()
+        self._ck(self.lib.cfdp_gpu_create(device, C.byref(self.h)))
+        plan = Plan(dom, tile_points, boundary_first)
+        self.stats = dict(ntiles=plan.ntiles, nbtiles=plan.nbtiles, nfaces_used=plan.nfaces_used,
+                          nfaces_dup=plan.nfaces_dup, ninc=plan.ninc_total, lds_grad=plan.lds_grad,
+                          lds_flux=plan.lds_flux, blob_bytes=plan.blob_bytes, nhalo=plan.nhalo_total,
+                          tile_points=plan.tile_points)
+        try:
+            self._ck(self.lib.cfdp_gpu_upload_plan(self.h, plan.ptr))
+        finally:
+            plan.free()
+        self._ck(self.lib.cfdp_gpu_set_variant(self.h, grad_lanes, flux_lanes))
+        self.push_fields()
+
+    def _ck(self, rc: int) -> None:
+        if rc:
+            raise GpuError(self.lib.cfdp_gpu_last_error().decode())
+
+    @staticmethod
+    def _dp(a: np.ndarray):
+        return a.ctypes.data_as(C.POINTER(C.c_double))
+
+    def push_fields(self) -> None:
+        self._ck(self.lib.cfdp_gpu_set_var(self.h, self.dom.sd.var))
+        self._ck(self.lib.cfdp_gpu_set_grad(self.h, self.dom.sd.grad))
+        self._ck(self.lib.cfdp_gpu_set_flux(self.h, self.dom.sd.psd_flux))
+
+    def pull_fields(self) -> None:
+        self._ck(self.lib.cfdp_gpu_get_grad(self.h, self.dom.sd.grad))
+        self._ck(self.lib.cfdp_gpu_get_flux(self.h, self.dom.sd.psd_flux))
+
+    def set_variant(self, grad_lanes: int, flux_lanes: int = 0) -> None:
+        self._ck(self.lib.cfdp_gpu_set_variant(self.h, grad_lanes, flux_lanes))
+
+    def gradients(self, which: int = TILES_ALL, stream: int = 0) -> None:
+        self._ck(self.lib.cfdp_gpu_gradients(self.h, which, C.c_void_p(stream)))
+
+    def flux(self, mode: int = FLUX_CONSISTENT, stream: int = 0) -> None:
+        self._ck(self.lib.cfdp_gpu_flux(self.h, mode, C.c_void_p(stream)))
+
+    def pack(self, stream: int = 0) -> None:
+        self._ck(self.lib.cfdp_gpu_pack(self.h, C.c_void_p(stream)))
+
+    def unpack(self, dev_ptr: int, stream: int = 0) -> None:
+        self._ck(self.lib.cfdp_gpu_unpack(self.h, C.c_void_p(dev_ptr), C.c_void_p(stream)))
+
+    def sync(self) -> None:
+        self._ck(self.lib.cfdp_gpu_sync(self.h))
+
+    def stream(self, which: int = 0) -> int:
+        return self.lib.cfdp_gpu_stream(self.h, which) or 0
+
+    def counts(self):
+        a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._ck(self.lib.cfdp_gpu_counts(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(nown=a.value, nall=b.value, nsend=c.value, nrecv=d.value)
+
+    def partners(self) -> List[int]:
+        return [self.lib.cfdp_gpu_partner_rank(self.h, s) for s in range(self.lib.cfdp_gpu_npartners(self.h))]
+
+    def send_slice(self, s: int):
+        n = C.c_size_t()
+        p = self.lib.cfdp_gpu_send_ptr(self.h, s, C.byref(n))
+        return p or 0, n.value
+
+    def recv_slice(self, s: int):
+        n = C.c_size_t()
+        p = self.lib.cfdp_gpu_recv_ptr(self.h, s, C.byref(n))
+        return p or 0, n.value
+
+    def bind_grad(self, dev_ptr: int) -> None:
+        self._ck(self.lib.cfdp_gpu_bind_grad(self.h, C.c_void_p(dev_ptr)))
+
+    def bind_sendbuf(self, dev_ptr: int) -> None:
+        self._ck(self.lib.cfdp_gpu_bind_sendbuf(self.h, C.c_void_p(dev_ptr)))
+
+    def time_kernels(self, iters: int, flux_mode: int = FLUX_CONSISTENT):
+        g, f = C.c_float(), C.c_float()
+        self._ck(self.lib.cfdp_gpu_time_kernels(self.h, iters, flux_mode, C.byref(g), C.byref(f)))
+        return g.value, f.value
+
+    def run_iterations(self, iters: int, with_flux: bool = True, flux_mode: int = FLUX_CONSISTENT,
+                       use_graph: bool = True) -> float:
+        ms = C.c_float()
+        self._ck(self.lib.cfdp_gpu_run_iterations(self.h, iters, int(with_flux), flux_mode, int(use_graph),
+                                                  C.byref(ms)))
+        return ms.value
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.cfdp_gpu_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def group_iteration(parts: Sequence[GpuPartition], with_exchange=True, overlap=True, with_flux=True,
+                    flux_mode=FLUX_CONSISTENT) -> None:
+    """One iteration of G in-process ranks (peer copies between their devices)."""
+    lib = hip_lib()
+    arr = (C.c_void_p * len(parts))(*[p.h for p in parts])
+    rc = lib.cfdp_gpu_iteration_group(arr, len(parts), int(with_exchange), int(overlap), int(with_flux), flux_mode)
+    if rc:
+        raise GpuError(lib.cfdp_gpu_last_error().decode())
+
+
+def group_sync(parts: Sequence[GpuPartition]) -> None:
+    for p in parts:
+        p.sync()

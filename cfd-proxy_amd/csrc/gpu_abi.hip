@@ -1,0 +1,474 @@
+// gpu_abi.hip -- implementation of the C ABI declared in include/cfdproxy_hip.h.
+// Device memory, streams, events, hipGraph capture and peer copies; the arithmetic lives in
+// gg_kernels.hip.  No CPU fallback: every entry point needs a HIP device and says so.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "cfdproxy_hip.h"
+#include "gg_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "no error";
+
+int fail(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail("%s failed: %s [%s:%d]", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+}  // namespace
+
+struct cfdp_gpu {
+  int device = 0;
+  hipStream_t s_main = nullptr, s_comm = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_pack = nullptr, ev_senddone = nullptr,
+             ev_fluxdone = nullptr;
+  bool uploaded = false;
+  int nown = 0, nall = 0, ntiles = 0, nbtiles = 0;
+  int tp[2] = {0, 0};         // max owned points per tile: [0] boundary, [1] interior
+  size_t lds_grad[2] = {0, 0}, lds_flux[2] = {0, 0};
+  cfdp_tile_desc *d_tiles = nullptr;
+  uint4 *d_blob = nullptr;
+  int *d_halo = nullptr, *d_sendidx = nullptr;
+  double *d_var = nullptr, *d_vol = nullptr, *d_grad = nullptr, *d_flux = nullptr,
+         *d_sendbuf = nullptr;
+  bool own_grad = true, own_sendbuf = true;
+  std::vector<int> new2old, partner, send_off, recv_off;
+  int grad_lanes = 4, flux_lanes = 4;
+  bool pending_exchange = false;
+  hipGraphExec_t graph = nullptr;
+  int graph_iters = 0, graph_flux = -1, graph_mode = -1, graph_gl = 0, graph_fl = 0;
+
+  gg_args args() const {
+    gg_args a;
+    a.tiles = d_tiles; a.blob = d_blob; a.halo_idx = d_halo; a.var = d_var; a.vol = d_vol;
+    a.grad = d_grad; a.flux = d_flux; a.nown = nown;
+    return a;
+  }
+};
+
+extern "C" {
+
+int cfdp_gpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *cfdp_gpu_last_error(void) { return g_err; }
+
+int cfdp_gpu_create(int device, cfdp_gpu **out) {
+  *out = nullptr;
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (n <= 0) return fail("no HIP device: the CFD-Proxy hot path has no CPU fallback");
+  if (device < 0 || device >= n) return fail("device %d out of range [0,%d)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  cfdp_gpu *g = new cfdp_gpu();
+  g->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&g->s_main, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&g->s_comm, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&g->ev_a));
+  HIP_TRY(hipEventCreate(&g->ev_b));
+  HIP_TRY(hipEventCreateWithFlags(&g->ev_pack, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&g->ev_senddone, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&g->ev_fluxdone, hipEventDisableTiming));
+  *out = g;
+  return 0;
+}
+
+static void free_device(cfdp_gpu *g) {
+  if (g->graph) { hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  hipFree(g->d_tiles); hipFree(g->d_blob); hipFree(g->d_halo); hipFree(g->d_sendidx);
+  hipFree(g->d_var); hipFree(g->d_vol); hipFree(g->d_flux);
+  if (g->own_grad) hipFree(g->d_grad);
+  if (g->own_sendbuf) hipFree(g->d_sendbuf);
+  g->d_tiles = nullptr; g->d_blob = nullptr; g->d_halo = g->d_sendidx = nullptr;
+  g->d_var = g->d_vol = g->d_grad = g->d_flux = g->d_sendbuf = nullptr;
+  g->own_grad = g->own_sendbuf = true;
+  g->uploaded = false;
+}
+
+void cfdp_gpu_destroy(cfdp_gpu *g) {
+  if (!g) return;
+  hipSetDevice(g->device);
+  hipDeviceSynchronize();
+  free_device(g);
+  if (g->s_main) hipStreamDestroy(g->s_main);
+  if (g->s_comm) hipStreamDestroy(g->s_comm);
+  for (hipEvent_t e : {g->ev_a, g->ev_b, g->ev_pack, g->ev_senddone, g->ev_fluxdone})
+    if (e) hipEventDestroy(e);
+  delete g;
+}
+
+int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
+  if (!g || !p) return fail("null argument");
+  HIP_TRY(hipSetDevice(g->device));
+  if (g->uploaded) free_device(g);
+  g->nown = p->nown; g->nall = p->nall; g->ntiles = p->ntiles; g->nbtiles = p->nbtiles;
+  g->tp[0] = g->tp[1] = 0;
+  for (int t = 0; t < p->ntiles; t++) {
+    int c = t < p->nbtiles ? 0 : 1;
+    if (p->tiles[t].npts > g->tp[c]) g->tp[c] = p->tiles[t].npts;
+  }
+  for (int c = 0; c < 2; c++) {
+    g->lds_grad[c] = (size_t)p->lds_grad_cls[c];
+    g->lds_flux[c] = (size_t)p->lds_flux_cls[c];
+  }
+  if (p->lds_grad > 160 * 1024 || p->lds_flux > 160 * 1024)
+    return fail("tile needs %ld / %ld bytes of LDS (> 160 KiB): use a smaller tile_points",
+                p->lds_grad, p->lds_flux);
+  g->new2old.assign(p->new2old, p->new2old + p->nall);
+  g->partner.assign(p->partner, p->partner + p->npartners);
+  g->send_off.assign(1, 0);
+  g->recv_off.assign(1, 0);
+  if (p->npartners) {
+    g->send_off.assign(p->send_off, p->send_off + p->npartners + 1);
+    g->recv_off.assign(p->recv_off, p->recv_off + p->npartners + 1);
+  }
+  const size_t nsend = (size_t)g->send_off.back();
+  HIP_TRY(hipMalloc(&g->d_tiles, sizeof(cfdp_tile_desc) * (size_t)p->ntiles));
+  HIP_TRY(hipMalloc(&g->d_blob, (size_t)p->blob_bytes + 16));
+  HIP_TRY(hipMalloc(&g->d_halo, sizeof(int) * (size_t)(p->nhalo_total + 1)));
+  HIP_TRY(hipMalloc(&g->d_var, sizeof(double) * 8 * (size_t)p->nall));
+  HIP_TRY(hipMalloc(&g->d_vol, sizeof(double) * (size_t)p->nown));
+  HIP_TRY(hipMalloc(&g->d_grad, sizeof(double) * 21 * (size_t)p->nall));
+  HIP_TRY(hipMalloc(&g->d_flux, sizeof(double) * 3 * (size_t)p->nown));
+  HIP_TRY(hipMalloc(&g->d_sendidx, sizeof(int) * (nsend + 1)));
+  HIP_TRY(hipMalloc(&g->d_sendbuf, sizeof(double) * 21 * (nsend + 1)));
+  g->own_grad = g->own_sendbuf = true;
+  HIP_TRY(hipMemcpy(g->d_tiles, p->tiles, sizeof(cfdp_tile_desc) * (size_t)p->ntiles, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(g->d_blob, p->blob, (size_t)p->blob_bytes, hipMemcpyHostToDevice));
+  if (p->nhalo_total)
+    HIP_TRY(hipMemcpy(g->d_halo, p->halo_idx, sizeof(int) * (size_t)p->nhalo_total, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(g->d_vol, p->vol, sizeof(double) * (size_t)p->nown, hipMemcpyHostToDevice));
+  if (nsend)
+    HIP_TRY(hipMemcpy(g->d_sendidx, p->send_idx, sizeof(int) * nsend, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(g->d_var, 0, sizeof(double) * 8 * (size_t)p->nall));
+  HIP_TRY(hipMemset(g->d_grad, 0, sizeof(double) * 21 * (size_t)p->nall));
+  HIP_TRY(hipMemset(g->d_flux, 0, sizeof(double) * 3 * (size_t)p->nown));
+  HIP_TRY(gg_set_max_lds((size_t)p->lds_grad, (size_t)p->lds_flux));
+  g->uploaded = true;
+  return 0;
+}
+
+#define NEED_UPLOAD(g)                                                 \
+  do {                                                                 \
+    if (!(g) || !(g)->uploaded) return fail("no plan uploaded");       \
+    HIP_TRY(hipSetDevice((g)->device));                                \
+  } while (0)
+
+int cfdp_gpu_bind_grad(cfdp_gpu *g, void *dev_grad) {
+  NEED_UPLOAD(g);
+  if (!dev_grad) return fail("null device pointer");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(dev_grad, g->d_grad, sizeof(double) * 21 * (size_t)g->nall, hipMemcpyDeviceToDevice));
+  if (g->own_grad) hipFree(g->d_grad);
+  g->d_grad = static_cast<double *>(dev_grad);
+  g->own_grad = false;
+  if (g->graph) { hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  return 0;
+}
+
+int cfdp_gpu_bind_sendbuf(cfdp_gpu *g, void *dev_sendbuf) {
+  NEED_UPLOAD(g);
+  if (!dev_sendbuf) return fail("null device pointer");
+  HIP_TRY(hipDeviceSynchronize());
+  if (g->own_sendbuf) hipFree(g->d_sendbuf);
+  g->d_sendbuf = static_cast<double *>(dev_sendbuf);
+  g->own_sendbuf = false;
+  return 0;
+}
+
+int cfdp_gpu_set_var(cfdp_gpu *g, const double *var) {
+  NEED_UPLOAD(g);
+  std::vector<double> tmp((size_t)g->nall * 8, 0.0);
+  for (int i = 0; i < g->nall; i++)
+    memcpy(&tmp[(size_t)i * 8], var + (size_t)g->new2old[i] * 7, 7 * sizeof(double));
+  HIP_TRY(hipMemcpy(g->d_var, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int cfdp_gpu_set_grad(cfdp_gpu *g, const double *grad) {
+  NEED_UPLOAD(g);
+  std::vector<double> tmp((size_t)g->nall * 21);
+  for (int i = 0; i < g->nall; i++)
+    memcpy(&tmp[(size_t)i * 21], grad + (size_t)g->new2old[i] * 21, 21 * sizeof(double));
+  HIP_TRY(hipMemcpy(g->d_grad, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int cfdp_gpu_set_flux(cfdp_gpu *g, const double *flux) {
+  NEED_UPLOAD(g);
+  std::vector<double> tmp((size_t)g->nown * 3);
+  for (int i = 0; i < g->nown; i++)
+    memcpy(&tmp[(size_t)i * 3], flux + (size_t)g->new2old[i] * 3, 3 * sizeof(double));
+  HIP_TRY(hipMemcpy(g->d_flux, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int cfdp_gpu_get_grad(cfdp_gpu *g, double *grad) {
+  NEED_UPLOAD(g);
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<double> tmp((size_t)g->nall * 21);
+  HIP_TRY(hipMemcpy(tmp.data(), g->d_grad, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int i = 0; i < g->nall; i++)
+    memcpy(grad + (size_t)g->new2old[i] * 21, &tmp[(size_t)i * 21], 21 * sizeof(double));
+  return 0;
+}
+
+int cfdp_gpu_get_flux(cfdp_gpu *g, double *flux) {
+  NEED_UPLOAD(g);
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<double> tmp((size_t)g->nown * 3);
+  HIP_TRY(hipMemcpy(tmp.data(), g->d_flux, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int i = 0; i < g->nown; i++) /* ghost rows of psd_flux are left untouched */
+    memcpy(flux + (size_t)g->new2old[i] * 3, &tmp[(size_t)i * 3], 3 * sizeof(double));
+  return 0;
+}
+
+int cfdp_gpu_set_variant(cfdp_gpu *g, int grad_lanes, int flux_lanes) {
+  if (!g) return fail("null context");
+  auto ok = [](int l) { return l == 1 || l == 2 || l == 4 || l == 8; };
+  if (grad_lanes == 0) grad_lanes = 4;
+  if (flux_lanes == 0) flux_lanes = 4;
+  if (!ok(grad_lanes) || !ok(flux_lanes)) return fail("lanes per point must be 1, 2, 4 or 8");
+  g->grad_lanes = grad_lanes;
+  g->flux_lanes = flux_lanes;
+  return 0;
+}
+
+static int launch_grad(cfdp_gpu *g, int which, hipStream_t st) {
+  const gg_args a = g->args();
+  if (which == CFDP_TILES_ALL || which == CFDP_TILES_BOUNDARY)
+    HIP_TRY(gg_launch_gradient(a, g->grad_lanes, 0, g->nbtiles, g->tp[0], g->lds_grad[0], st));
+  if (which == CFDP_TILES_ALL || which == CFDP_TILES_INTERIOR)
+    HIP_TRY(gg_launch_gradient(a, g->grad_lanes, g->nbtiles, g->ntiles - g->nbtiles, g->tp[1],
+                               g->lds_grad[1], st));
+  return 0;
+}
+
+static int launch_flux(cfdp_gpu *g, int mode, hipStream_t st) {
+  const gg_args a = g->args();
+  const bool ref = mode == CFDP_FLUX_REFERENCE;
+  HIP_TRY(gg_launch_flux(a, g->flux_lanes, ref, 0, g->nbtiles, g->tp[0], g->lds_flux[0], st));
+  HIP_TRY(gg_launch_flux(a, g->flux_lanes, ref, g->nbtiles, g->ntiles - g->nbtiles, g->tp[1],
+                         g->lds_flux[1], st));
+  return 0;
+}
+
+int cfdp_gpu_gradients(cfdp_gpu *g, int which_tiles, void *stream) {
+  NEED_UPLOAD(g);
+  if (which_tiles < 0 || which_tiles > 2) return fail("bad tile selector %d", which_tiles);
+  return launch_grad(g, which_tiles, stream ? (hipStream_t)stream : g->s_main);
+}
+
+int cfdp_gpu_flux(cfdp_gpu *g, int mode, void *stream) {
+  NEED_UPLOAD(g);
+  if (mode != CFDP_FLUX_CONSISTENT && mode != CFDP_FLUX_REFERENCE) return fail("bad flux mode %d", mode);
+  return launch_flux(g, mode, stream ? (hipStream_t)stream : g->s_main);
+}
+
+int cfdp_gpu_pack(cfdp_gpu *g, void *stream) {
+  NEED_UPLOAD(g);
+  HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), g->d_grad, g->d_sendbuf,
+                         stream ? (hipStream_t)stream : g->s_main));
+  return 0;
+}
+
+int cfdp_gpu_unpack(cfdp_gpu *g, const void *dev_recvbuf, void *stream) {
+  NEED_UPLOAD(g);
+  HIP_TRY(gg_launch_unpack(static_cast<const double *>(dev_recvbuf), g->recv_off.back(), g->nown,
+                           g->d_grad, stream ? (hipStream_t)stream : g->s_main));
+  return 0;
+}
+
+int cfdp_gpu_sync(cfdp_gpu *g) {
+  if (!g) return fail("null context");
+  HIP_TRY(hipSetDevice(g->device));
+  HIP_TRY(hipDeviceSynchronize());
+  return 0;
+}
+
+void *cfdp_gpu_stream(cfdp_gpu *g, int which) { return which ? g->s_comm : g->s_main; }
+int cfdp_gpu_npartners(const cfdp_gpu *g) { return (int)g->partner.size(); }
+int cfdp_gpu_partner_rank(const cfdp_gpu *g, int s) {
+  return (s >= 0 && s < (int)g->partner.size()) ? g->partner[s] : -1;
+}
+void *cfdp_gpu_send_ptr(cfdp_gpu *g, int s, size_t *bytes) {
+  if (s < 0 || s >= (int)g->partner.size()) return nullptr;
+  if (bytes) *bytes = (size_t)(g->send_off[s + 1] - g->send_off[s]) * 21 * sizeof(double);
+  return g->d_sendbuf + (size_t)g->send_off[s] * 21;
+}
+void *cfdp_gpu_recv_ptr(cfdp_gpu *g, int s, size_t *bytes) {
+  if (s < 0 || s >= (int)g->partner.size()) return nullptr;
+  if (bytes) *bytes = (size_t)(g->recv_off[s + 1] - g->recv_off[s]) * 21 * sizeof(double);
+  return g->d_grad + ((size_t)g->nown + g->recv_off[s]) * 21;
+}
+void *cfdp_gpu_grad_ptr(cfdp_gpu *g) { return g->d_grad; }
+void *cfdp_gpu_var_ptr(cfdp_gpu *g) { return g->d_var; }
+
+int cfdp_gpu_counts(const cfdp_gpu *g, int *nown, int *nall, int *nsend, int *nrecv) {
+  if (!g || !g->uploaded) return fail("no plan uploaded");
+  if (nown) *nown = g->nown;
+  if (nall) *nall = g->nall;
+  if (nsend) *nsend = g->send_off.back();
+  if (nrecv) *nrecv = g->recv_off.back();
+  return 0;
+}
+
+// ----------------------------------------------------------------- in-process rank group
+// Phase 1 of rank a's iteration: gradients (+ pack + peer copies into the partners' ghost rows).
+int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, int overlap) {
+  if (!ranks || G < 1 || a < 0 || a >= G) return fail("bad rank group");
+  cfdp_gpu *ga = ranks[a];
+  NEED_UPLOAD(ga);
+  const bool comm = with_exchange && !ga->partner.empty();
+  ga->pending_exchange = comm;
+  if (!comm) return launch_grad(ga, CFDP_TILES_ALL, ga->s_main);
+  // the send arena is free again once last iteration's peer copies have drained
+  HIP_TRY(hipStreamWaitEvent(ga->s_main, ga->ev_senddone, 0));
+  if (launch_grad(ga, overlap ? CFDP_TILES_BOUNDARY : CFDP_TILES_ALL, ga->s_main)) return 1;
+  HIP_TRY(gg_launch_pack(ga->d_sendidx, ga->send_off.back(), ga->d_grad, ga->d_sendbuf, ga->s_main));
+  HIP_TRY(hipEventRecord(ga->ev_pack, ga->s_main));
+  if (overlap && launch_grad(ga, CFDP_TILES_INTERIOR, ga->s_main)) return 1;
+  HIP_TRY(hipStreamWaitEvent(ga->s_comm, ga->ev_pack, 0));
+  for (size_t s = 0; s < ga->partner.size(); s++) {
+    const int b = ga->partner[s];
+    if (b < 0 || b >= G) return fail("partner rank %d outside the in-process group", b);
+    cfdp_gpu *gb = ranks[b];
+    int slot = -1;
+    for (size_t i = 0; i < gb->partner.size(); i++)
+      if (gb->partner[i] == a) slot = (int)i;
+    if (slot < 0) return fail("rank %d sends to %d which does not list it as partner", a, b);
+    size_t sbytes = 0, rbytes = 0;
+    void *src = cfdp_gpu_send_ptr(ga, (int)s, &sbytes);
+    void *dst = cfdp_gpu_recv_ptr(gb, slot, &rbytes);
+    if (sbytes != rbytes) return fail("halo size mismatch %d->%d: %zu vs %zu bytes", a, b, sbytes, rbytes);
+    if (!sbytes) continue;
+    // b's ghost rows may still be read by b's previous flux (write-after-read)
+    HIP_TRY(hipStreamWaitEvent(ga->s_comm, gb->ev_fluxdone, 0));
+    HIP_TRY(hipMemcpyPeerAsync(dst, gb->device, src, ga->device, sbytes, ga->s_comm));
+  }
+  HIP_TRY(hipEventRecord(ga->ev_senddone, ga->s_comm));
+  return 0;
+}
+
+// Phase 2 of rank b's iteration: wait for the partners' copies, then the pseudo-flux loop.
+int cfdp_gpu_rank_flux(cfdp_gpu **ranks, int G, int b, int with_flux, int flux_mode) {
+  if (!ranks || G < 1 || b < 0 || b >= G) return fail("bad rank group");
+  cfdp_gpu *gb = ranks[b];
+  NEED_UPLOAD(gb);
+  if (gb->pending_exchange)
+    for (int a : gb->partner) HIP_TRY(hipStreamWaitEvent(gb->s_main, ranks[a]->ev_senddone, 0));
+  gb->pending_exchange = false;
+  if (with_flux && launch_flux(gb, flux_mode, gb->s_main)) return 1;
+  HIP_TRY(hipEventRecord(gb->ev_fluxdone, gb->s_main));
+  return 0;
+}
+
+int cfdp_gpu_iteration_group(cfdp_gpu **ranks, int G, int with_exchange, int overlap, int with_flux,
+                             int flux_mode) {
+  for (int a = 0; a < G; a++)
+    if (cfdp_gpu_rank_gradients(ranks, G, a, with_exchange, overlap)) return 1;
+  for (int b = 0; b < G; b++)
+    if (cfdp_gpu_rank_flux(ranks, G, b, with_flux, flux_mode)) return 1;
+  return 0;
+}
+
+int cfdp_gpu_sync_group(cfdp_gpu **ranks, int G) {
+  for (int a = 0; a < G; a++)
+    if (cfdp_gpu_sync(ranks[a])) return 1;
+  return 0;
+}
+
+// --------------------------------------------------------------------------- measurement
+int cfdp_gpu_time_kernels(cfdp_gpu *g, int iters, int flux_mode, float *ms_grad, float *ms_flux) {
+  NEED_UPLOAD(g);
+  if (iters < 1) return fail("iters must be >= 1");
+  hipStream_t st = g->s_main;
+  for (int w = 0; w < 2; w++) {
+    if (launch_grad(g, CFDP_TILES_ALL, st)) return 1;
+    if (launch_flux(g, flux_mode, st)) return 1;
+  }
+  HIP_TRY(hipEventRecord(g->ev_a, st));
+  for (int i = 0; i < iters; i++)
+    if (launch_grad(g, CFDP_TILES_ALL, st)) return 1;
+  HIP_TRY(hipEventRecord(g->ev_b, st));
+  HIP_TRY(hipEventSynchronize(g->ev_b));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, g->ev_a, g->ev_b));
+  if (ms_grad) *ms_grad = ms / (float)iters;
+  HIP_TRY(hipEventRecord(g->ev_a, st));
+  for (int i = 0; i < iters; i++)
+    if (launch_flux(g, flux_mode, st)) return 1;
+  HIP_TRY(hipEventRecord(g->ev_b, st));
+  HIP_TRY(hipEventSynchronize(g->ev_b));
+  HIP_TRY(hipEventElapsedTime(&ms, g->ev_a, g->ev_b));
+  if (ms_flux) *ms_flux = ms / (float)iters;
+  return 0;
+}
+
+int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode, int use_graph,
+                            float *ms_total) {
+  NEED_UPLOAD(g);
+  if (iters < 1) return fail("iters must be >= 1");
+  hipStream_t st = g->s_main;
+  const int chunk = 25;  // NITER of the reference harness (src/hybrid.f6.c:72)
+  if (use_graph) {
+    const bool stale = !g->graph || g->graph_flux != with_flux || g->graph_mode != flux_mode ||
+                       g->graph_gl != g->grad_lanes || g->graph_fl != g->flux_lanes;
+    if (stale) {
+      if (g->graph) { hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+      hipGraph_t gr = nullptr;
+      HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      int rc = 0;
+      for (int i = 0; i < chunk && !rc; i++) {
+        rc = launch_grad(g, CFDP_TILES_ALL, st);
+        if (!rc && with_flux) rc = launch_flux(g, flux_mode, st);
+      }
+      hipError_t ec = hipStreamEndCapture(st, &gr);
+      if (rc) { if (gr) hipGraphDestroy(gr); return 1; }
+      HIP_TRY(ec);
+      HIP_TRY(hipGraphInstantiate(&g->graph, gr, nullptr, nullptr, 0));
+      HIP_TRY(hipGraphDestroy(gr));
+      g->graph_iters = chunk; g->graph_flux = with_flux; g->graph_mode = flux_mode;
+      g->graph_gl = g->grad_lanes; g->graph_fl = g->flux_lanes;
+    }
+  }
+  HIP_TRY(hipEventRecord(g->ev_a, st));
+  int done = 0;
+  while (done < iters) {
+    if (use_graph && iters - done >= chunk) {
+      HIP_TRY(hipGraphLaunch(g->graph, st));
+      done += chunk;
+    } else {
+      if (launch_grad(g, CFDP_TILES_ALL, st)) return 1;
+      if (with_flux && launch_flux(g, flux_mode, st)) return 1;
+      done++;
+    }
+  }
+  HIP_TRY(hipEventRecord(g->ev_b, st));
+  HIP_TRY(hipEventSynchronize(g->ev_b));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, g->ev_a, g->ev_b));
+  if (ms_total) *ms_total = ms;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,285 @@
+/*
+ * dropin.c -- the reference's entry points on top of the GPU path (cfdproxy_dropin.h).
+ *
+ *   init_communication / compute_communication_tables / free_communication_ressources
+ *                                        <- reference src/comm_data.c:257-307,446-521
+ *   init_threads                         <- reference src/threads.c:730-788
+ *   compute_gradients_gg_<variant>       <- reference src/gradients.c:150-336
+ *   compute_psd_flux                     <- reference src/flux.c:194-200
+ *   test_solver                          <- reference src/solver.c:35-314
+ *
+ * Process model: the reference is one MPI rank per domain.  Here one process drives G
+ * in-process ranks (one per GPU, or several per GPU when fewer devices than ranks exist);
+ * the G comm_data share a cfdp_group, and "sending" is a device-to-device peer copy into
+ * the partner's ghost rows (the gaspi_write_notify pattern of
+ * src/exchange_data_gaspi.c:105-151 mapped to xGMI), ordered by HIP events instead of
+ * notifications.  The multi-process model (one process per GPU under torch.distributed /
+ * RCCL) lives in the Python host (cfd-proxy_amd/__init__.py) and shares the same C ABI.
+ */
+#include "cfdproxy_hip.h"
+#include "host_util.h"
+
+#include <string.h>
+
+typedef struct cfdp_group {
+  int G;
+  cfdp_gpu **gpus;       /* [G], index = rank */
+  solver_data **sds;     /* [G] */
+  comm_data **cds;       /* [G] */
+  int flux_mode;
+} cfdp_group;
+
+typedef struct cfdp_solver { /* what solver_data.gpu points to */
+  cfdp_gpu *gpu;
+  cfdp_group *group;
+  int rank;
+} cfdp_solver;
+
+#define GPU_OK(call)                                                                       \
+  do {                                                                                     \
+    if ((call) != 0) {                                                                     \
+      fprintf(stderr, "Error: %s [%s:%i]\n", cfdp_gpu_last_error(), __FILE__, __LINE__);   \
+      exit(EXIT_FAILURE);                                                                  \
+    }                                                                                      \
+  } while (0)
+
+/* ------------------------------------------------------------------ communication setup */
+void init_communication(int argc, char *argv[], comm_data *cd) {
+  /* reference: MPI_Init_thread + field reset (src/comm_data.c:257-307).  No MPI here:
+   * a comm_data starts as rank 0 of 1; cfdp_group_create() assigns ranks.               */
+  (void)argc; (void)argv;
+  CFDP_ASSERT(cd != NULL);
+  memset(cd, 0, sizeof(*cd));
+  cd->nProc = 1;
+  cd->iProc = 0;
+}
+
+void compute_communication_tables(comm_data *cd) {
+  /* reference: create_recvsend_index (MPI exchange of ghost ids) + offset tables + buffer
+   * allocation (src/comm_data.c:446-502).  Merged partitions arrive with recvindex built
+   * (domain_merge.c) and sendindex linked (cfdp_group_link()); a raw single file gets its
+   * recvindex here exactly like src/comm_data.c:161-174.  Buffers live on the device.   */
+  CFDP_ASSERT(cd != NULL);
+  if (cd->ndomains == 1) return;
+  CFDP_ASSERT(cd->naddpoints != 0 && cd->addpoint_owner != NULL && cd->addpoint_id != NULL);
+  CFDP_ASSERT(cd->commpartner != NULL && cd->sendcount != NULL && cd->recvcount != NULL);
+  if (!cd->recvindex) {
+    cd->recvindex = cfdp_calloc((size_t)cd->ndomains, sizeof(int *));
+    for (int i = 0; i < cd->ncommdomains; i++) {
+      int k = cd->commpartner[i], count = 0;
+      if (cd->recvcount[k] <= 0) continue;
+      cd->recvindex[k] = cfdp_malloc((size_t)cd->recvcount[k] * sizeof(int));
+      for (int j = 0; j < cd->naddpoints; j++)
+        if (cd->addpoint_owner[j] == k) cd->recvindex[k][count++] = cd->nownpoints + j;
+      CFDP_ASSERT(count == cd->recvcount[k]);
+    }
+  }
+  if (!cd->sendindex) cd->sendindex = cfdp_calloc((size_t)cd->ndomains, sizeof(int *));
+}
+
+void free_communication_ressources(comm_data *cd) {
+  CFDP_ASSERT(cd != NULL);
+  (void)cd; /* nothing process-global to tear down (reference: MPI_Win_free, MPI_Finalize) */
+}
+
+/* link the send side of G in-process partitions: what rank s receives from r (ghost
+ * (owner-local id) lists) becomes r's sendindex[s] -- the MPI_Send/Recv of
+ * src/comm_data.c:203-249 done by reading the partner's tables directly               */
+void cfdp_group_link_raw(int G, comm_data **cds) {
+  for (int r = 0; r < G; r++)
+    for (int s = 0; s < G; s++) {
+      if (s == r || !cds[s]->recvcount || cds[s]->recvcount[r] <= 0) continue;
+      comm_data *me = cds[r], *other = cds[s];
+      int n = other->recvcount[r];
+      CFDP_ASSERT(me->sendcount[s] == n);
+      free(me->sendindex[s]);
+      me->sendindex[s] = cfdp_malloc((size_t)n * sizeof(int));
+      for (int j = 0; j < n; j++) {
+        int ghost = other->recvindex[r][j] - other->nownpoints;
+        me->sendindex[s][j] = other->addpoint_id[ghost];
+      }
+    }
+}
+
+cfdp_group *cfdp_group_create(int G, solver_data **sds, comm_data **cds) {
+  cfdp_group *grp = cfdp_calloc(1, sizeof(*grp));
+  grp->G = G;
+  grp->gpus = cfdp_calloc((size_t)G, sizeof(cfdp_gpu *));
+  grp->sds = cfdp_malloc((size_t)G * sizeof(solver_data *));
+  grp->cds = cfdp_malloc((size_t)G * sizeof(comm_data *));
+  grp->flux_mode = CFDP_FLUX_CONSISTENT;
+  for (int r = 0; r < G; r++) {
+    grp->sds[r] = sds[r];
+    grp->cds[r] = cds[r];
+    cds[r]->group = grp;
+    cds[r]->nProc = G;
+    cds[r]->iProc = r;
+  }
+  return grp;
+}
+
+void cfdp_group_set_flux_mode(cfdp_group *grp, int mode) { grp->flux_mode = mode; }
+
+void cfdp_group_destroy(cfdp_group *grp) {
+  if (!grp) return;
+  for (int r = 0; r < grp->G; r++) {
+    if (grp->gpus[r]) cfdp_gpu_destroy(grp->gpus[r]);
+    if (grp->sds[r]) { free(grp->sds[r]->gpu); grp->sds[r]->gpu = NULL; }
+    if (grp->cds[r]) grp->cds[r]->group = NULL;
+  }
+  free(grp->gpus); free(grp->sds); free(grp->cds);
+  free(grp);
+}
+
+/* ------------------------------------------------------------------------ init_threads */
+void init_threads(comm_data *cd, solver_data *sd, int NTHREADS) {
+  /* NTHREADS (OpenMP threads of the reference) selects nothing here: the decomposition is
+   * into GPU tiles.  A non-positive value keeps the default tile size, a value in
+   * [8,1024] is taken as owned points per tile (a tuning hook for experiments).          */
+  CFDP_ASSERT(cd != NULL && sd != NULL);
+  cfdp_plan_opts o;
+  cfdp_plan_default_opts(&o);
+  const char *env = getenv("CFDP_TILE_POINTS");
+  if (env && atoi(env) >= 8 && atoi(env) <= 1024) o.tile_points = atoi(env);
+  (void)NTHREADS;
+  cfdp_group *grp = (cfdp_group *)cd->group;
+  int rank = cd->iProc;
+  if (!grp) { /* stand-alone partition: a private group of one */
+    solver_data *sds[1] = {sd};
+    comm_data *cds[1] = {cd};
+    int np = cd->nProc, ip = cd->iProc;
+    grp = cfdp_group_create(1, sds, cds);
+    cd->nProc = np; cd->iProc = ip;
+    rank = 0;
+  }
+  CFDP_ASSERT(rank >= 0 && rank < grp->G);
+  cfdp_plan *plan = cfdp_plan_build(sd, cd, &o);
+  int ndev = cfdp_gpu_device_count();
+  if (ndev <= 0) {
+    fprintf(stderr, "Error: no HIP device (the GPU path has no CPU fallback) [%s:%i]\n", __FILE__, __LINE__);
+    exit(EXIT_FAILURE);
+  }
+  cfdp_gpu *gpu = NULL;
+  GPU_OK(cfdp_gpu_create(rank % ndev, &gpu));
+  GPU_OK(cfdp_gpu_upload_plan(gpu, plan));
+  cfdp_plan_free(plan);
+  grp->gpus[rank] = gpu;
+  cfdp_solver *sv = cfdp_calloc(1, sizeof(*sv));
+  sv->gpu = gpu; sv->group = grp; sv->rank = rank;
+  sd->gpu = sv;
+  cfdp_sync_fields_to_device(sd);
+}
+
+static cfdp_solver *solver_of(solver_data *sd) {
+  if (!sd || !sd->gpu) {
+    fprintf(stderr, "Error: init_threads() has not been called for this solver_data\n");
+    exit(EXIT_FAILURE);
+  }
+  return (cfdp_solver *)sd->gpu;
+}
+
+void cfdp_sync_fields_to_device(solver_data *sd) {
+  cfdp_solver *sv = solver_of(sd);
+  GPU_OK(cfdp_gpu_set_var(sv->gpu, &sd->var[0][0]));
+  GPU_OK(cfdp_gpu_set_grad(sv->gpu, &sd->grad[0][0][0]));
+  GPU_OK(cfdp_gpu_set_flux(sv->gpu, &sd->psd_flux[0][0]));
+}
+
+void cfdp_sync_fields_to_host(solver_data *sd) {
+  cfdp_solver *sv = solver_of(sd);
+  GPU_OK(cfdp_gpu_get_grad(sv->gpu, &sd->grad[0][0][0]));
+  GPU_OK(cfdp_gpu_get_flux(sv->gpu, &sd->psd_flux[0][0]));
+}
+
+/* --------------------------------------------------------------- gradients (10 variants) */
+static void gradients(solver_data *sd, int with_exchange, int overlap) {
+  cfdp_solver *sv = solver_of(sd);
+  GPU_OK(cfdp_gpu_rank_gradients(sv->group->gpus, sv->group->G, sv->rank, with_exchange, overlap));
+}
+
+void compute_gradients_gg_comm_free(comm_data *cd, solver_data *sd, int final) {
+  (void)cd; (void)final;
+  gradients(sd, 0, 0);
+}
+/* bulk-synchronous family: full gradient, then pack, then exchange (src/gradients.c:167,
+ * 226,264,301; src/exchange_data_mpi.c:199-284)                                          */
+#define BULK(name)                                                              \
+  void name(comm_data *cd, solver_data *sd, int final) {                        \
+    (void)cd; (void)final;                                                      \
+    gradients(sd, 1, 0);                                                        \
+  }
+/* asynchronous family: sent points first, exchange overlapped with the interior
+ * (src/gradients.c:188,208,246,284,321; src/exchange_data_gaspi.c:307-502)               */
+#define ASYNC(name)                                                             \
+  void name(comm_data *cd, solver_data *sd, int final) {                        \
+    (void)cd; (void)final;                                                      \
+    gradients(sd, 1, 1);                                                        \
+  }
+BULK(compute_gradients_gg_mpi_bulk_sync)
+BULK(compute_gradients_gg_gaspi_bulk_sync)
+BULK(compute_gradients_gg_mpifence_bulk_sync)
+BULK(compute_gradients_gg_mpipscw_bulk_sync)
+ASYNC(compute_gradients_gg_mpi_early_recv)
+ASYNC(compute_gradients_gg_mpi_async)
+ASYNC(compute_gradients_gg_gaspi_async)
+ASYNC(compute_gradients_gg_mpifence_async)
+ASYNC(compute_gradients_gg_mpipscw_async)
+
+void compute_psd_flux(solver_data *sd) {
+  cfdp_solver *sv = solver_of(sd);
+  GPU_OK(cfdp_gpu_rank_flux(sv->group->gpus, sv->group->G, sv->rank, 1, sv->group->flux_mode));
+}
+
+/* -------------------------------------------------------------------------- test_solver */
+#define N_MEDIAN 25
+#define N_SOLVER 3
+
+static int cmp_double(const void *a, const void *b) {
+  double x = *(const double *)a, y = *(const double *)b;
+  return (x > y) - (x < y);
+}
+
+typedef void (*grad_fn)(comm_data *, solver_data *, int);
+
+/* Times every in-process rank of the group `cd` belongs to (the reference times one MPI
+ * rank between barriers, src/solver.c:42-58; here the barrier is a device sync of the
+ * whole group).  Prints the reference's TIMINGS block: median seconds per NITER
+ * iterations.                                                                            */
+void test_solver(comm_data *cd, solver_data *sd, int NTHREADS) {
+  cfdp_solver *sv = solver_of(sd);
+  cfdp_group *grp = sv->group;
+  const int G = grp->G;
+  static const char *names[N_SOLVER] = {"comm_free", "exchange_dbl_xgmi_bulk_sync",
+                                        "exchange_dbl_xgmi_async"};
+  grad_fn fns[N_SOLVER] = {compute_gradients_gg_comm_free, compute_gradients_gg_mpi_bulk_sync,
+                           compute_gradients_gg_gaspi_async};
+  double median[N_SOLVER][N_MEDIAN];
+  int nvar = (cd->ndomains == 1 || G == 1) ? 1 : N_SOLVER;
+  for (int k = 0; k < N_MEDIAN; k++) {
+    for (int v = 0; v < nvar; v++) {
+      GPU_OK(cfdp_gpu_sync_group(grp->gpus, G));
+      double t = -cfdp_now();
+      for (int i = 0; i < sd->niter; i++) {
+        int final = (i == sd->niter - 1);
+        for (int r = 0; r < G; r++) fns[v](grp->cds[r], grp->sds[r], final);
+        for (int r = 0; r < G; r++) compute_psd_flux(grp->sds[r]);
+      }
+      GPU_OK(cfdp_gpu_sync_group(grp->gpus, G));
+      t += cfdp_now();
+      median[v][k] = t;
+    }
+    printf(".");
+    fflush(stdout);
+  }
+  printf("\n\n*** SETUP\n");
+  printf("                                 nProc: %d\n", G);
+  printf("                              NTHREADS: %d\n", NTHREADS);
+  printf("                                 NITER: %d\n", sd->niter);
+  printf("                              N_MEDIAN: %d\n", N_MEDIAN);
+  printf("\n*** TIMINGS\n");
+  for (int v = 0; v < nvar; v++) {
+    qsort(median[v], N_MEDIAN, sizeof(double), cmp_double);
+    printf("%38s: %10.6f\n", names[v], median[v][N_MEDIAN / 2]);
+  }
+  fflush(stdout);
+}

@@ -1,0 +1,353 @@
+/*
+ * tiling.c -- the GPU analogue of init_threads() (reference src/threads.c:730-788).
+ *
+ * What the reference builds for OpenMP threads, and what replaces it here:
+ *
+ *   reference                                        |  this file
+ *   -------------------------------------------------+---------------------------------------
+ *   init_thread_id: contiguous point ranges per      |  point TILES grown breadth-first over
+ *     thread (src/rangelist.c:320-398)               |    the face graph (compact, ~128 points),
+ *                                                    |    one workgroup each
+ *   init_thread_rangelist: every thread copies each  |  every tile gets a private copy of each
+ *     face touching one of its points; face class    |    face touching one of its points
+ *     says which end it may write; cross faces are   |    ("owner computes", cross-tile faces
+ *     processed once per side (:513-523,567-608)     |    duplicated) -> no atomics, no colouring
+ *   colours of <=96 faces + first/last point lists   |  per point incidence lists (CSR): a
+ *     for strip-mined zero-init and finalise         |    lane accumulates a point in registers,
+ *     (:654-703, src/points_of_color.c)              |    starts from 0 and scales by 1/volume once
+ *   faces touching sent points sorted first          |  send points are tiled FIRST (tiles
+ *     (ttype 0-2 before 3-5, :572-607)               |    [0,nbtiles)): their kernel + pack run
+ *                                                    |    ahead of / beside the interior tiles
+ *   gather_sendcount/recvcount per colour            |  one pack list per partner; ghost rows
+ *     (src/thread_comm.c:27-432)                     |    renumbered so a message IS a row block
+ *
+ * Points are renumbered tile-major (new2old/old2new); results are returned in file order.
+ */
+#include "cfdproxy_host.h"
+#include "host_util.h"
+
+#include <string.h>
+
+void cfdp_plan_default_opts(cfdp_plan_opts *o) {
+  o->tile_points = 128;
+  o->boundary_first = 1;
+}
+
+typedef struct {
+  int nown;
+  const int *xadj;       /* [nown+1] */
+  const int *adj_other;  /* other end point (old id) */
+  int *tile_of;          /* [nown] */
+  int *stamp;            /* [nown] */
+  unsigned char *seeded; /* [nown] */
+  int *seedq; int sq_head, sq_tail;
+  int *lq;               /* local queue scratch [nown] */
+  int *order; int norder;
+  int *tile_first; int ntiles, cap_tiles;
+  int cursor;
+} tiler;
+
+static void tiler_open_tile(tiler *T) {
+  if (T->ntiles + 1 >= T->cap_tiles) {
+    T->cap_tiles = T->cap_tiles ? 2 * T->cap_tiles : 1024;
+    T->tile_first = realloc(T->tile_first, (size_t)(T->cap_tiles + 1) * sizeof(int));
+  }
+  T->tile_first[T->ntiles] = T->norder;
+}
+
+/* tile all points with mask[p]==want (mask==NULL: all) into tiles of <= TP points */
+static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
+  const int nown = T->nown;
+  int remaining = 0;
+  for (int p = 0; p < nown; p++)
+    if (T->tile_of[p] < 0 && (!mask || mask[p] == want)) remaining++;
+  T->cursor = 0;
+  while (remaining > 0) {
+    const int t = T->ntiles;
+    tiler_open_tile(T);
+    int cnt = 0, head = 0, tail = 0;
+    while (cnt < TP) {
+      if (head == tail) { /* need a seed */
+        int seed = -1;
+        while (T->sq_head < T->sq_tail) {
+          int q = T->seedq[T->sq_head++];
+          if (T->tile_of[q] < 0 && (!mask || mask[q] == want) && T->stamp[q] != t + 1) {
+            seed = q;
+            break;
+          }
+        }
+        while (seed < 0 && T->cursor < nown) {
+          int q = T->cursor++;
+          if (T->tile_of[q] < 0 && (!mask || mask[q] == want) && T->stamp[q] != t + 1) seed = q;
+        }
+        if (seed < 0) break;
+        T->stamp[seed] = t + 1;
+        T->lq[tail++] = seed;
+      }
+      int p = T->lq[head++];
+      T->tile_of[p] = t;
+      T->order[T->norder++] = p;
+      cnt++;
+      remaining--;
+      for (int e = T->xadj[p]; e < T->xadj[p + 1]; e++) {
+        int q = T->adj_other[e];
+        if (q >= nown || T->tile_of[q] >= 0 || T->stamp[q] == t + 1) continue;
+        if (mask && mask[q] != want) continue;
+        T->stamp[q] = t + 1;
+        T->lq[tail++] = q;
+      }
+    }
+    /* frontier of the closed tile seeds the following tiles (keeps tiles adjacent) */
+    for (int i = head; i < tail; i++) {
+      int q = T->lq[i];
+      if (!T->seeded[q]) { T->seeded[q] = 1; T->seedq[T->sq_tail++] = q; }
+    }
+    T->ntiles++;
+    CFDP_ASSERT(cnt > 0);
+  }
+}
+
+typedef struct { unsigned char *p; size_t len, cap; } bytebuf;
+static void *bb_reserve(bytebuf *b, size_t n) {
+  if (b->len + n > b->cap) {
+    size_t nc = b->cap ? b->cap : (1u << 20);
+    while (nc < b->len + n) nc *= 2;
+    b->p = realloc(b->p, nc);
+    CFDP_ASSERT(b->p != NULL);
+    b->cap = nc;
+  }
+  void *r = b->p + b->len;
+  memset(r, 0, n);
+  b->len += n;
+  return r;
+}
+
+cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *opts) {
+  cfdp_plan_opts o;
+  if (opts) o = *opts; else cfdp_plan_default_opts(&o);
+  CFDP_ASSERT(o.tile_points >= 8 && o.tile_points <= 1024);
+  const int nown = sd->nownpoints, nall = sd->nallpoints, nf = sd->nfaces;
+  CFDP_ASSERT(nown > 0 && nall >= nown);
+  const int has_comm = cd && cd->ndomains > 1 && cd->ncommdomains > 0;
+
+  cfdp_plan *P = cfdp_calloc(1, sizeof(*P));
+  P->nown = nown; P->nall = nall; P->tile_points = o.tile_points;
+
+  /* ---- 1. point -> incident faces (CSR over owned points, file face order) ---- */
+  int *xadj = cfdp_calloc((size_t)nown + 2, sizeof(int));
+  long used = 0;
+  for (int f = 0; f < nf; f++) {
+    int a = sd->fpoint[f][0], b = sd->fpoint[f][1];
+    if (a < nown) xadj[a + 1]++;
+    if (b < nown) xadj[b + 1]++;
+    if (a < nown || b < nown) used++;
+  }
+  P->nfaces_used = used;
+  for (int p = 0; p < nown; p++) xadj[p + 1] += xadj[p];
+  const int nadj = xadj[nown];
+  int *adj_face = cfdp_malloc((size_t)(nadj ? nadj : 1) * sizeof(int)); /* bit31: owned end is p1 */
+  int *adj_other = cfdp_malloc((size_t)(nadj ? nadj : 1) * sizeof(int));
+  int *fill = cfdp_malloc((size_t)nown * sizeof(int));
+  memcpy(fill, xadj, (size_t)nown * sizeof(int));
+  for (int f = 0; f < nf; f++) {
+    int a = sd->fpoint[f][0], b = sd->fpoint[f][1];
+    if (a < nown) { adj_face[fill[a]] = f; adj_other[fill[a]++] = b; }
+    if (b < nown) { adj_face[fill[b]] = (int)((unsigned)f | 0x80000000u); adj_other[fill[b]++] = a; }
+  }
+  free(fill);
+
+  /* ---- 2. which owned points are sent (reference htype 2, src/rangelist.c:129-141) ---- */
+  unsigned char *is_send = cfdp_calloc((size_t)nown, 1);
+  int any_send = 0;
+  if (has_comm && cd->sendindex)
+    for (int i = 0; i < cd->ncommdomains; i++) {
+      int k = cd->commpartner[i];
+      for (int j = 0; j < cd->sendcount[k]; j++) {
+        int pnt = cd->sendindex[k][j];
+        CFDP_ASSERT(pnt >= 0 && pnt < nown);
+        is_send[pnt] = 1;
+        any_send = 1;
+      }
+    }
+
+  /* ---- 3. grow tiles ---- */
+  tiler T;
+  memset(&T, 0, sizeof T);
+  T.nown = nown; T.xadj = xadj; T.adj_other = adj_other;
+  T.tile_of = cfdp_malloc((size_t)nown * sizeof(int));
+  for (int p = 0; p < nown; p++) T.tile_of[p] = -1;
+  T.stamp = cfdp_calloc((size_t)nown, sizeof(int));
+  T.seeded = cfdp_calloc((size_t)nown, 1);
+  T.seedq = cfdp_malloc((size_t)nown * sizeof(int));
+  T.lq = cfdp_malloc((size_t)nown * sizeof(int));
+  T.order = cfdp_malloc((size_t)nown * sizeof(int));
+  if (any_send && o.boundary_first) {
+    int btp = o.tile_points / 2 < 8 ? 8 : o.tile_points / 2; /* sheets have big halos */
+    tiler_pass(&T, is_send, 1, btp);
+    P->nbtiles = T.ntiles;
+    /* seed the interior from the inner side of the boundary sheet */
+    memset(T.seeded, 0, (size_t)nown);
+    T.sq_head = T.sq_tail = 0;
+    for (int i = 0; i < T.norder; i++) {
+      int p = T.order[i];
+      for (int e = xadj[p]; e < xadj[p + 1]; e++) {
+        int q = adj_other[e];
+        if (q < nown && T.tile_of[q] < 0 && !T.seeded[q]) { T.seeded[q] = 1; T.seedq[T.sq_tail++] = q; }
+      }
+    }
+    tiler_pass(&T, is_send, 0, o.tile_points);
+  } else {
+    tiler_pass(&T, NULL, 0, o.tile_points);
+    P->nbtiles = 0;
+  }
+  CFDP_ASSERT(T.norder == nown);
+  T.tile_first[T.ntiles] = nown;
+  P->ntiles = T.ntiles;
+
+  /* ---- 4. renumber: owned points tile-major; ghosts grouped by partner, message order ---- */
+  P->new2old = cfdp_malloc((size_t)nall * sizeof(int));
+  P->old2new = cfdp_malloc((size_t)nall * sizeof(int));
+  for (int i = 0; i < nall; i++) P->old2new[i] = -1;
+  for (int i = 0; i < nown; i++) { P->new2old[i] = T.order[i]; P->old2new[T.order[i]] = i; }
+  int ng = nown;
+  if (has_comm) {
+    int np = 0;
+    for (int i = 0; i < cd->ncommdomains; i++) {
+      int k = cd->commpartner[i];
+      if (cd->sendcount[k] > 0 || cd->recvcount[k] > 0) np++;
+    }
+    P->npartners = np;
+    P->partner = cfdp_malloc((size_t)(np ? np : 1) * sizeof(int));
+    P->send_off = cfdp_calloc((size_t)np + 1, sizeof(int));
+    P->recv_off = cfdp_calloc((size_t)np + 1, sizeof(int));
+    np = 0;
+    for (int i = 0; i < cd->ncommdomains; i++) {
+      int k = cd->commpartner[i];
+      if (!(cd->sendcount[k] > 0 || cd->recvcount[k] > 0)) continue;
+      P->partner[np] = k;
+      P->send_off[np + 1] = P->send_off[np] + cd->sendcount[k];
+      P->recv_off[np + 1] = P->recv_off[np] + cd->recvcount[k];
+      for (int j = 0; j < cd->recvcount[k]; j++) {
+        int old = cd->recvindex[k][j];
+        CFDP_ASSERT(old >= nown && old < nall && P->old2new[old] < 0);
+        P->old2new[old] = ng;
+        P->new2old[ng++] = old;
+      }
+      np++;
+    }
+    P->send_idx = cfdp_malloc((size_t)(P->send_off[np] ? P->send_off[np] : 1) * sizeof(int));
+    for (int s = 0; s < np; s++) {
+      int k = P->partner[s];
+      for (int j = 0; j < cd->sendcount[k]; j++)
+        P->send_idx[P->send_off[s] + j] = P->old2new[cd->sendindex[k][j]];
+    }
+  }
+  for (int i = nown; i < nall; i++) /* ghosts nobody sends us (or no comm tables at all) */
+    if (P->old2new[i] < 0) { P->old2new[i] = ng; P->new2old[ng++] = i; }
+  CFDP_ASSERT(ng == nall);
+
+  P->vol = cfdp_malloc((size_t)nown * sizeof(double));
+  P->degree = cfdp_malloc((size_t)nown * sizeof(int));
+  for (int i = 0; i < nown; i++) {
+    int old = P->new2old[i];
+    P->vol[i] = sd->pvolume[old];
+    P->degree[i] = xadj[old + 1] - xadj[old];
+  }
+
+  /* ---- 5. per-tile face copies, halo lists, incidence lists ---- */
+  P->tiles = cfdp_calloc((size_t)P->ntiles, sizeof(cfdp_tile_desc));
+  int *fstamp = cfdp_calloc((size_t)(nf ? nf : 1), sizeof(int));
+  int *fval = cfdp_malloc((size_t)(nf ? nf : 1) * sizeof(int));
+  int *hstamp = cfdp_calloc((size_t)nall, sizeof(int));
+  int *hval = cfdp_malloc((size_t)nall * sizeof(int));
+  bytebuf blob = {0, 0, 0}, halo = {0, 0, 0};
+  long lds_g[2] = {0, 0}, lds_f[2] = {0, 0};
+  for (int t = 0; t < P->ntiles; t++) {
+    const int ts = T.tile_first[t], te = T.tile_first[t + 1], np = te - ts;
+    cfdp_tile_desc *td = &P->tiles[t];
+    td->pstart = ts;
+    td->npts = np;
+    /* count */
+    int E = 0, H = 0, I = 0;
+    for (int li = 0; li < np; li++) {
+      int p = T.order[ts + li];
+      for (int e = xadj[p]; e < xadj[p + 1]; e++) {
+        int q = adj_other[e];
+        int f = adj_face[e] & 0x7FFFFFFF, sgn = (unsigned)adj_face[e] >> 31;
+        int in_tile = q < nown && T.tile_of[q] == t;
+        I++;
+        if (!in_tile || sgn == 0) {
+          if (fstamp[f] != t + 1) { fstamp[f] = t + 1; fval[f] = E++; }
+        }
+        if (!in_tile && hstamp[q] != t + 1) { hstamp[q] = t + 1; hval[q] = H++; }
+      }
+    }
+    CFDP_ASSERT(np + H <= 65535);
+    CFDP_ASSERT(E <= 32767);
+    td->nhalo = H; td->nfaces = E; td->ninc = I;
+    const long b_fn = cfdp_blob_fn_bytes(E), b_inc = cfdp_blob_inc_bytes(I),
+               b_off = cfdp_blob_off_bytes(np);
+    CFDP_ASSERT(blob.len % 16 == 0 && blob.len / 16 < 0x7FFFFFFF);
+    td->blob_off = (int)(blob.len / 16);
+    td->blob_qw = (int)((b_fn + b_inc + b_off) / 16);
+    td->halo_off = (int)(halo.len / 4);
+    unsigned char *bp = bb_reserve(&blob, (size_t)(b_fn + b_inc + b_off));
+    int *hp = bb_reserve(&halo, (size_t)H * 4);
+    double *fn = (double *)bp;
+    uint32_t *inc = (uint32_t *)(bp + b_fn);
+    uint32_t *ioff = (uint32_t *)(bp + b_fn + b_inc);
+    /* fill: faces were numbered in first-touch order above; re-walk identically */
+    int Ic = 0;
+    for (int li = 0; li < np; li++) {
+      int p = T.order[ts + li];
+      ioff[li] = (uint32_t)Ic;
+      for (int e = xadj[p]; e < xadj[p + 1]; e++) {
+        int q = adj_other[e];
+        int f = adj_face[e] & 0x7FFFFFFF;
+        unsigned sgn = (unsigned)adj_face[e] >> 31;
+        int in_tile = q < nown && T.tile_of[q] == t;
+        int lf = fval[f];
+        /* an internal face is listed by both ends; the normal is stored once */
+        fn[3 * lf + 0] = sd->fnormal[f][0];
+        fn[3 * lf + 1] = sd->fnormal[f][1];
+        fn[3 * lf + 2] = sd->fnormal[f][2];
+        unsigned nbr;
+        if (in_tile) nbr = (unsigned)(P->old2new[q] - ts);
+        else { nbr = (unsigned)(np + hval[q]); hp[hval[q]] = P->old2new[q]; }
+        inc[Ic++] = nbr | ((unsigned)lf << 16) | (sgn << 31);
+      }
+    }
+    ioff[np] = (uint32_t)Ic;
+    CFDP_ASSERT(Ic == I);
+    P->nfaces_dup += E;
+    P->ninc_total += I;
+    const int cls = t < P->nbtiles ? 0 : 1;
+    long lg = (long)td->blob_qw * 16 + (long)(np + H) * 64;
+    long lf = (long)td->blob_qw * 16 + (long)(np + H) * 80;
+    if (lg > lds_g[cls]) lds_g[cls] = lg;
+    if (lf > lds_f[cls]) lds_f[cls] = lf;
+  }
+  /* (an internal face is numbered at its p0 end's visit in the count loop, which has
+   * finished for the whole tile before the fill loop reads fval[])                       */
+  for (int c = 0; c < 2; c++) { P->lds_grad_cls[c] = lds_g[c]; P->lds_flux_cls[c] = lds_f[c]; }
+  P->lds_grad = lds_g[0] > lds_g[1] ? lds_g[0] : lds_g[1];
+  P->lds_flux = lds_f[0] > lds_f[1] ? lds_f[0] : lds_f[1];
+  P->blob = blob.p; P->blob_bytes = (long)blob.len;
+  P->halo_idx = (int *)halo.p; P->nhalo_total = (long)(halo.len / 4);
+  if (!P->blob) P->blob = cfdp_calloc(16, 1);
+  if (!P->halo_idx) P->halo_idx = cfdp_calloc(4, 1);
+
+  free(fstamp); free(fval); free(hstamp); free(hval);
+  free(T.tile_of); free(T.stamp); free(T.seeded); free(T.seedq); free(T.lq);
+  free(T.order); free(T.tile_first);
+  free(xadj); free(adj_face); free(adj_other); free(is_send);
+  return P;
+}
+
+void cfdp_plan_free(cfdp_plan *p) {
+  if (!p) return;
+  free(p->new2old); free(p->old2new); free(p->tiles); free(p->halo_idx); free(p->blob);
+  free(p->vol); free(p->degree); free(p->partner); free(p->send_off); free(p->send_idx);
+  free(p->recv_off);
+  free(p);
+}

@@ -1,0 +1,192 @@
+/*
+ * cfdproxy_dropin.h -- the drop-in boundary of the MI355X-native CFD-Proxy hot path.
+ *
+ * CFD-Proxy has no plugin/FFI layer: the "boundary" is the set of plain C structs and
+ * functions that its driver (src/hybrid.f6.c:54-88) and harness (src/solver.c:35-314)
+ * call.  This header declares exactly those, with the reference's names, argument
+ * meaning and error behaviour (message + exit()), so that a host program written
+ * against the reference headers recompiles against this one unchanged.  Each
+ * declaration cites the reference interface it replaces.
+ *
+ * What is behind it is new: a NetCDF-classic reader of our own (no libnetcdf), a
+ * domain merger (N dualgrid domains -> G GPUs), a graph tiler, and hand-written
+ * gfx950 HIP kernels reached through the thin C ABI of cfdproxy_hip.h.
+ *
+ * Struct fields that exist in the reference keep their name, type and order; new
+ * fields are only ever appended (marked "ext").
+ */
+#ifndef CFDPROXY_DROPIN_H
+#define CFDPROXY_DROPIN_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants (reference src/solver_data.h:9-10, src/flux.h:7-9) ------------------- */
+#define NGRAD 7 /* equations whose gradient is reconstructed         */
+#define NFLUX 3 /* pseudo-flux components                            */
+#define IVX 0
+#define IVY 1
+#define IVZ 2
+
+/* ---- MPI / GASPI opaque types --------------------------------------------------------
+ * reference src/comm_data.h:4-11 pulls in <mpi.h> (and typedefs the GASPI types when
+ * GASPI is absent).  The GPU path needs neither; when CFDP_WITH_MPI is not defined the
+ * MPI handle types are opaque placeholders so that the struct keeps its field list.   */
+#ifdef CFDP_WITH_MPI
+#include <mpi.h>
+#else
+typedef int MPI_Request;
+typedef struct { int cfdp_opaque[5]; } MPI_Status;
+#endif
+typedef unsigned long gaspi_offset_t;
+typedef unsigned short gaspi_notification_id_t;
+
+/* 64-byte aligned counter (reference src/solver_data.h:12-15) */
+typedef struct { int global __attribute__((aligned(64))); } counter_t;
+
+/* per-thread private face copies (reference src/solver_data.h:22-26) */
+typedef struct {
+  int (*fpoint)[2];
+  double (*fnormal)[3];
+} solver_data_local;
+
+/* colour descriptor (reference src/solver_data.h:28-63).  The GPU path replaces colours
+ * by point tiles (cfdp_plan) but keeps the type so `solver_data.fcolor` still compiles. */
+typedef struct RangeList_t {
+  struct RangeList_t *succ;
+  int start, stop, ftype;
+  int nall_points_of_color;   int *all_points_of_color;
+  int nfirst_points_of_color; int *first_points_of_color;
+  int nlast_points_of_color;  int *last_points_of_color;
+  int nsendcount; int *sendpartner; int *sendcount; int **sendindex; int **sendoffset;
+  int nrecvcount; int *recvpartner; int *recvcount; int **recvindex; int **recvoffset;
+  int tid;
+} RangeList;
+
+/* mesh + fields of one partition (reference src/solver_data.h:66-81) */
+typedef struct {
+  int nfaces;
+  int nallfaces;
+  int nownpoints;              /* points [0,nownpoints) are owned                       */
+  int nallpoints;              /* points [nownpoints,nallpoints) are ghosts (addpoints) */
+  int ncolors;
+  int (*fpoint)[2];            /* face -> (p0,p1)                                       */
+  double (*fnormal)[3];        /* face normal (area-weighted)                           */
+  double *pvolume;             /* dual-cell volume per point                            */
+  double (*var)[NGRAD];        /* primitive variables                                   */
+  double (*grad)[NGRAD][3];    /* Green-Gauss gradients (the parity quantity)           */
+  double (*psd_flux)[NFLUX];   /* pseudo viscous flux                                   */
+  RangeList *fcolor;
+  int niter;
+  /* ext: */
+  void *gpu;                   /* cfdp_solver* attached by init_threads(); NULL before  */
+} solver_data;
+
+/* halo topology of one partition (reference src/comm_data.h:15-55) */
+typedef struct {
+  int nProc;
+  int iProc;
+  int ndomains;
+  int ncommdomains;
+  int nownpoints;
+  int naddpoints;
+  int *addpoint_owner;         /* [naddpoints] owner rank of ghost j                    */
+  int *addpoint_id;            /* [naddpoints] owner-local id of ghost j                */
+  int *commpartner;            /* [ncommdomains]                                        */
+  int *sendcount;              /* [ndomains], indexed by rank                           */
+  int *recvcount;              /* [ndomains], indexed by rank                           */
+  int **recvindex;             /* [ndomains][recvcount[k]] local ghost ids              */
+  int **sendindex;             /* [ndomains][sendcount[k]] local own ids                */
+  int nreq;
+  MPI_Request *req;
+  MPI_Status *stat;
+  double **recvbuf;
+  double **sendbuf;
+  gaspi_offset_t *remote_recv_offset;
+  gaspi_offset_t *local_recv_offset;
+  gaspi_offset_t *local_send_offset;
+  gaspi_notification_id_t *notification;
+  volatile counter_t *recv_flag;
+  volatile counter_t *send_flag;
+  volatile int recv_stage;
+  volatile int send_stage;
+  volatile int comm_stage;
+  /* ext: in-process rank group (one process drives G GPUs; rank g <-> peers[g])        */
+  void *group;                 /* cfdp_group* shared by the G comm_data of a process    */
+} comm_data;
+
+/* ---- loader: reference src/read_netcdf.h:4-6 (libnetcdf replaced by our own reader).
+ * `ncid` is a handle from cfdp_nc_open().  Failure: message + exit(2), like ERR()
+ * in reference src/error_handling.h:4-10.                                              */
+int  cfdp_nc_open(const char *path);              /* replaces nc_open  (hybrid.f6.c:65) */
+void cfdp_nc_close(int ncid);                     /* replaces nc_close (hybrid.f6.c:91) */
+void get_nc_double(int ncid, const char *name, double *array);
+void get_nc_int(int ncid, const char *name, int *array);
+int  get_nc_val(int ncid, const char *name);      /* value = a DIMENSION length         */
+
+/* ---- reference src/solver_data.h:84-85 ---------------------------------------------- */
+void read_solver_data(int ncid, solver_data *sd);
+void init_solver_data(solver_data *sd, int NITER);
+
+/* ---- reference src/comm_data.h:58-61 ------------------------------------------------- */
+void init_communication(int argc, char *argv[], comm_data *cd);
+void read_communication_data(int ncid, comm_data *cd);
+void compute_communication_tables(comm_data *cd);
+void free_communication_ressources(comm_data *cd);
+
+/* ---- reference src/rangelist.h:17-20: preprocessing entry point.  Here: builds the GPU
+ * tiling (cfdp_plan) for this partition and uploads it to the device.                  */
+void init_threads(comm_data *cd, solver_data *sd, int NTHREADS);
+
+/* ---- reference src/threads.h:13-24: callback types of the colour iterator.  Kept for
+ * source compatibility; the GPU path orders pack/exchange by stream events instead.    */
+typedef void (*send_fn)(RangeList *color, comm_data *cd, double *data, int dim2);
+typedef void (*exch_fn)(comm_data *cd, double *data, int dim2, int final);
+
+/* ---- reference src/gradients.h:7-25.  All variants enqueue the HIP gradient kernel on
+ * the partition's device.  comm_free does no exchange; *_bulk_sync run gradient -> pack
+ * -> xGMI exchange -> unpack in order; the async/early_recv variants run boundary tiles
+ * first and overlap pack+exchange with the interior tiles on a second stream.          */
+void compute_gradients_gg_comm_free(comm_data *cd, solver_data *sd, int final);
+void compute_gradients_gg_mpi_bulk_sync(comm_data *cd, solver_data *sd, int final);
+void compute_gradients_gg_mpi_early_recv(comm_data *cd, solver_data *sd, int final);
+void compute_gradients_gg_mpi_async(comm_data *cd, solver_data *sd, int final);
+void compute_gradients_gg_gaspi_bulk_sync(comm_data *cd, solver_data *sd, int final);
+void compute_gradients_gg_gaspi_async(comm_data *cd, solver_data *sd, int final);
+void compute_gradients_gg_mpifence_bulk_sync(comm_data *cd, solver_data *sd, int final);
+void compute_gradients_gg_mpifence_async(comm_data *cd, solver_data *sd, int final);
+void compute_gradients_gg_mpipscw_bulk_sync(comm_data *cd, solver_data *sd, int final);
+void compute_gradients_gg_mpipscw_async(comm_data *cd, solver_data *sd, int final);
+
+/* ---- reference src/flux.h:12 -------------------------------------------------------- */
+void compute_psd_flux(solver_data *sd);
+
+/* ---- reference src/solver.h:7: the timing harness (25 samples x NITER iterations,
+ * median in seconds per NITER iterations, reference src/solver.c:32-33,302-311).       */
+void test_solver(comm_data *cd, solver_data *sd, int NTHREADS);
+
+/* ---- ext: moving results across the boundary (the reference never reads a value back;
+ * parity needs it).  Copies device grad / psd_flux into sd->grad / sd->psd_flux in FILE
+ * numbering.  Ghost rows hold what the halo exchange delivered.                        */
+void cfdp_sync_fields_to_host(solver_data *sd);
+/* ext: push host sd->var (and sd->grad/psd_flux initial values) to the device.         */
+void cfdp_sync_fields_to_device(solver_data *sd);
+
+/* ---- ext: in-process rank group.  The reference is one MPI rank per partition; here one
+ * process may drive G partitions (one per GPU).  The G comm_data share a group; a "send"
+ * is a peer copy into the partner's ghost rows.                                         */
+typedef struct cfdp_group cfdp_group;
+cfdp_group *cfdp_group_create(int G, solver_data **sds, comm_data **cds);
+/* build sendindex of raw (un-merged) partitions from the partners' ghost tables: the
+ * MPI_Send/Recv of reference src/comm_data.c:203-249 without MPI                        */
+void cfdp_group_link_raw(int G, comm_data **cds);
+void cfdp_group_set_flux_mode(cfdp_group *grp, int mode);
+void cfdp_group_destroy(cfdp_group *grp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFDPROXY_DROPIN_H */

@@ -1,0 +1,112 @@
+/*
+ * cfdproxy_hip.h -- the thin C ABI between the C host side and the gfx950 HIP kernels.
+ *
+ * Plain pointers, sizes and opaque handles only.  `stream` arguments are hipStream_t
+ * values passed as void* (NULL = the context's own stream), so a caller that owns its
+ * streams (a C driver, or PyTorch used as plumbing) can order work itself.
+ *
+ * Every function returns 0 on success and a non-zero code on failure;
+ * cfdp_gpu_last_error() describes the last failure of the calling thread.  The drop-in
+ * layer (cfdproxy_dropin.h) turns a failure into message + exit(), the reference's
+ * convention (src/error_handling.h:25-30).
+ *
+ * Reference interfaces each entry point replaces:
+ *   cfdp_gpu_upload_plan      <- init_threads()                       src/threads.c:730-788
+ *   cfdp_gpu_gradients        <- private_compute_gradients_gg() over all colours of all
+ *                                threads                               src/gradients.c:25-147
+ *   cfdp_gpu_flux             <- private_compute_psd_flux()            src/flux.c:111-190
+ *   cfdp_gpu_pack             <- exchange_dbl_copy_in[_local]()        src/threads.c:791-813,842-854
+ *   cfdp_gpu_unpack           <- exchange_dbl_copy_out[_local]()       src/threads.c:816-839,857-869
+ *   cfdp_gpu_send_ptr/recv_ptr<- cd->sendbuf[i] / cd->recvbuf[i]       src/exchange_data_mpi.c:27-76
+ *   cfdp_gpu_exchange_peer    <- exchange_dbl_mpi_bulk_sync / _async, exchange_dbl_gaspi_*
+ *                                (in-process ranks, peer copies over xGMI)
+ *                                                                      src/exchange_data_mpi.c:199-543
+ */
+#ifndef CFDPROXY_HIP_H
+#define CFDPROXY_HIP_H
+
+#include "cfdproxy_host.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cfdp_gpu cfdp_gpu; /* one partition resident on one device */
+
+/* which tiles a gradient launch covers */
+enum { CFDP_TILES_ALL = 0, CFDP_TILES_BOUNDARY = 1, CFDP_TILES_INTERIOR = 2 };
+/* pseudo-flux semantics */
+enum {
+  CFDP_FLUX_CONSISTENT = 0, /* every owned point accumulates +/- flux of all its faces     */
+  CFDP_FLUX_REFERENCE = 1   /* the reference's 1-thread result on owned points: flux.c uses
+                               the README class numbering (src/flux.c:177-188 vs
+                               src/rangelist.c:719-736), so the "+" side of a face whose two
+                               ends are both owned is never added                          */
+};
+/* kernel variants (lanes per point); 0 = library default */
+enum { CFDP_GRAD_DEFAULT = 0, CFDP_GRAD_L1 = 1, CFDP_GRAD_L2 = 2, CFDP_GRAD_L4 = 4, CFDP_GRAD_L8 = 8 };
+
+int  cfdp_gpu_device_count(void);
+const char *cfdp_gpu_last_error(void);
+
+int  cfdp_gpu_create(int device, cfdp_gpu **out);
+void cfdp_gpu_destroy(cfdp_gpu *g);
+
+/* copy the tiled mesh to the device and allocate the fields (var, grad, psd_flux, send
+ * arena).  The plan may be freed afterwards.                                             */
+int  cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *plan);
+/* optional: use caller-owned device memory for grad [nall*21 doubles] / the send arena
+ * [nsend*21 doubles] (e.g. buffers registered with a communication library)              */
+int  cfdp_gpu_bind_grad(cfdp_gpu *g, void *dev_grad);
+int  cfdp_gpu_bind_sendbuf(cfdp_gpu *g, void *dev_sendbuf);
+
+/* host <-> device fields, FILE numbering on the host side: var [nall][7], grad
+ * [nall][7][3], psd_flux [nall][3] (ghost rows of psd_flux are not computed)             */
+int  cfdp_gpu_set_var(cfdp_gpu *g, const double *var);
+int  cfdp_gpu_set_grad(cfdp_gpu *g, const double *grad);
+int  cfdp_gpu_set_flux(cfdp_gpu *g, const double *psd_flux);
+int  cfdp_gpu_get_grad(cfdp_gpu *g, double *grad);
+int  cfdp_gpu_get_flux(cfdp_gpu *g, double *psd_flux);
+
+/* launches (asynchronous) */
+int  cfdp_gpu_set_variant(cfdp_gpu *g, int grad_lanes, int flux_lanes);
+int  cfdp_gpu_gradients(cfdp_gpu *g, int which_tiles, void *stream);
+int  cfdp_gpu_flux(cfdp_gpu *g, int mode, void *stream);
+int  cfdp_gpu_pack(cfdp_gpu *g, void *stream);   /* grad rows of send points -> send arena */
+int  cfdp_gpu_unpack(cfdp_gpu *g, const void *dev_recvbuf, void *stream); /* staging path  */
+int  cfdp_gpu_sync(cfdp_gpu *g);
+void *cfdp_gpu_stream(cfdp_gpu *g, int which /*0 main, 1 comm*/);
+
+/* exchange geometry: partner slot s in [0, npartners) */
+int  cfdp_gpu_npartners(const cfdp_gpu *g);
+int  cfdp_gpu_partner_rank(const cfdp_gpu *g, int s);
+void *cfdp_gpu_send_ptr(cfdp_gpu *g, int s, size_t *bytes);  /* slice of the send arena    */
+void *cfdp_gpu_recv_ptr(cfdp_gpu *g, int s, size_t *bytes);  /* ghost rows of grad         */
+void *cfdp_gpu_grad_ptr(cfdp_gpu *g);
+void *cfdp_gpu_var_ptr(cfdp_gpu *g);
+
+/* in-process ranks: one halo exchange among the G partitions of this process; sends of
+ * rank a to rank b are device-to-device (peer) copies into b's ghost rows.  `bulk` != 0:
+ * after the full gradient; else boundary tiles -> pack -> copies overlap interior tiles. */
+int  cfdp_gpu_iteration_group(cfdp_gpu **ranks, int G, int with_exchange, int overlap,
+                              int with_flux, int flux_mode);
+/* the two phases of one rank's iteration (what the drop-in compute_gradients_gg_* and
+ * compute_psd_flux enqueue): gradients [+ pack + peer copies], then wait-for-halo + flux */
+int  cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, int overlap);
+int  cfdp_gpu_rank_flux(cfdp_gpu **ranks, int G, int b, int with_flux, int flux_mode);
+int  cfdp_gpu_sync_group(cfdp_gpu **ranks, int G);
+
+/* measurement: `iters` back-to-back launches bracketed by HIP events on the context's
+ * main stream; average milliseconds per launch (gradient over all tiles; flux)           */
+int  cfdp_gpu_time_kernels(cfdp_gpu *g, int iters, int flux_mode, float *ms_grad, float *ms_flux);
+/* K full iterations (gradients [+flux]) captured in one hipGraph and replayed            */
+int  cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode,
+                             int use_graph, float *ms_total);
+
+/* sizes for callers that allocate */
+int  cfdp_gpu_counts(const cfdp_gpu *g, int *nown, int *nall, int *nsend, int *nrecv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,158 @@
+/*
+ * cfdproxy_host.h -- host-side (plain C, no HIP) services around the drop-in boundary:
+ *
+ *   1. dualgrid generator  -- deterministic F6-like stand-in meshes written in the exact
+ *      NetCDF schema the reference loader reads (the real f6/dualgrid.N.tgz files are
+ *      stripped from the reference checkout: /root/reference/.MISSING_LARGE_BLOBS:1-6).
+ *   2. domain merger       -- N dualgrid domains -> one partition per GPU
+ *      (replaces the MPI index exchange of reference src/comm_data.c:116-255).
+ *   3. tiler ("plan")      -- the GPU analogue of init_threads()
+ *      (reference src/threads.c:730-788, src/rangelist.c:320-764, src/points_of_color.c):
+ *      owner-computes point tiles with duplicated cross faces instead of thread domains
+ *      + colours, and pack lists instead of per-colour send lists (src/thread_comm.c).
+ */
+#ifndef CFDPROXY_HOST_H
+#define CFDPROXY_HOST_H
+
+#include "cfdproxy_dropin.h"
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================================================================= generator === */
+typedef struct {
+  int nx, ny, nz;          /* lattice points per axis                                     */
+  int ndomains;            /* recursive-coordinate-bisection partitions                    */
+  int connectivity;        /* 7: Freudenthal/Kuhn edges (F6-like, ~6.8 faces/point);       */
+                           /* 3: Cartesian edges (known-answer mesh)                       */
+  int normals;             /* 0: lattice normals h^2*e_d ; 1: N(0,1)^3 * h^2 (hash-seeded) */
+  int volumes;             /* 0: h^3 ; 1: U(0.5,2)*h^3 (hash-seeded)                       */
+  int ghost_faces;         /* 1: also store faces between two ghost points                 */
+  int cdf_version;         /* 1 or 2                                                       */
+  uint64_t seed;
+} cfdp_gen_params;
+
+/* fill `sd` (mesh arrays, fields = 1.0) and `cd` (halo topology) for one domain, in memory */
+int  cfdp_gen_domain(const cfdp_gen_params *gp, int domain, solver_data *sd, comm_data *cd);
+/* write one domain as "<prefix>_domain_<domain>_lvl_<lvl>" (reference src/hybrid.f6.c:58-62) */
+int  cfdp_gen_write_domain(const cfdp_gen_params *gp, int domain, const char *prefix, int lvl);
+/* write any (sd,cd) pair in the dualgrid schema */
+int  cfdp_write_domain_file(const char *path, const solver_data *sd, const comm_data *cd,
+                            int cdf_version);
+/* global lattice id of every point of a generated domain (tests / var-field helpers) */
+int  cfdp_gen_global_ids(const cfdp_gen_params *gp, int domain, int *gid /*[nallpoints]*/);
+
+void cfdp_free_solver_data(solver_data *sd);
+void cfdp_free_comm_data(comm_data *cd);
+
+/* load "<prefix>_domain_<domain>_lvl_<lvl>" through the drop-in loader
+ * (read_solver_data + init_solver_data + read_communication_data)                        */
+int  cfdp_load_domain(const char *prefix, int domain, int lvl, solver_data *sd, comm_data *cd);
+
+/* ========================================================================== merger === */
+typedef struct {
+  int G, r;                /* GPU ranks, my rank                                           */
+  int ndomains_total;
+  int ndom_local;
+  int *domain_ids;         /* [ndom_local] ascending                                       */
+  int *own_offset;         /* [ndom_local+1] merged id of each local domain's first point  */
+  int **local2merged;      /* [ndom_local][nallpoints_d] file numbering -> merged id       */
+  int nghost;              /* merged ghosts                                                */
+  int *ghost_domain;       /* [nghost] owner domain of merged ghost j                      */
+  int *ghost_idx;          /* [nghost] owner-domain-local id                               */
+  int npartners;
+  int *partner;            /* [npartners] partner ranks, ascending                         */
+  int *want_off;           /* [npartners+1] into ghost_* (ghosts are grouped by partner)   */
+  long nfaces_in, nfaces_dropped;
+} cfdp_merge_info;
+
+/* rank that owns `domain` under the block distribution used everywhere */
+int  cfdp_domain_rank(int domain, int ndomains_total, int G);
+void cfdp_rank_domains(int r, int ndomains_total, int G, int *first, int *count);
+
+/* merge `ndom_local` loaded domains into one partition.  out_cd gets nProc=G, iProc=r,
+ * ndomains=G, commpartner/recvcount/recvindex filled; sendcount/sendindex are filled by
+ * cfdp_merge_set_send() once the partners' request lists are known.                      */
+int  cfdp_merge_domains(int ndom_local, const int *domain_ids, const solver_data *sds,
+                        const comm_data *cds, int ndomains_total, int G, int r,
+                        solver_data *out_sd, comm_data *out_cd, cfdp_merge_info **info);
+/* partner `s` wants `count` of my points, given as (domain, idx) pairs in message order */
+int  cfdp_merge_set_send(comm_data *out_cd, const cfdp_merge_info *info, int s, int count,
+                         const int *want_domain, const int *want_idx);
+/* all G ranks in one process: wire every rank's send lists from its partners' requests   */
+void cfdp_merge_link_group(int G, comm_data **cds, cfdp_merge_info **infos);
+/* scatter a merged per-point field (rowlen doubles) back to domain `dl` file numbering   */
+void cfdp_merge_scatter(const cfdp_merge_info *info, int dl, int npoints_d, int rowlen,
+                        const double *merged, double *out);
+void cfdp_merge_info_free(cfdp_merge_info *info);
+
+/* ============================================================================ tiler === */
+typedef struct {
+  int pstart;              /* first point (new numbering) owned by the tile               */
+  int npts;                /* owned points                                                 */
+  int nhalo;               /* points read but not owned                                    */
+  int nfaces;              /* faces touching an owned point (cross-tile faces duplicated)  */
+  int ninc;                /* (point,face) incidences                                      */
+  int halo_off;            /* into cfdp_plan.halo_idx                                      */
+  int blob_off;            /* into cfdp_plan.blob, in 16-byte units                        */
+  int blob_qw;             /* blob length in 16-byte units                                 */
+} cfdp_tile_desc;
+
+/* incidence word: [15:0] local index of the OTHER end point (>= npts: halo slot),
+ * [30:16] tile-local face, [31] 1 if the owned point is p1 of the face (contribution is
+ * subtracted, reference src/gradients.c:87-107,126-131)                                  */
+#define CFDP_INC_NBR(w)  ((w) & 0xFFFFu)
+#define CFDP_INC_FACE(w) (((w) >> 16) & 0x7FFFu)
+#define CFDP_INC_SIGN(w) ((w) >> 31)
+
+typedef struct {
+  int tile_points;         /* owned points per tile (<= 1024)                              */
+  int boundary_first;      /* tile send points first (comm/compute overlap)                */
+} cfdp_plan_opts;
+
+typedef struct cfdp_plan {
+  int nown, nall;
+  long nfaces_used;        /* faces with >=1 owned end                                     */
+  int ntiles, nbtiles;     /* tiles [0,nbtiles) hold every send point                      */
+  int tile_points;
+  int *new2old, *old2new;  /* [nall] device numbering <-> file numbering                   */
+  cfdp_tile_desc *tiles;
+  int *halo_idx;  long nhalo_total;
+  unsigned char *blob; long blob_bytes;
+  double *vol;             /* [nown] pvolume, new numbering                                */
+  int *degree;             /* [nown] incidences per point, new numbering                   */
+  long lds_grad, lds_flux; /* dynamic LDS bytes the kernels need (max over all tiles)      */
+  long lds_grad_cls[2], lds_flux_cls[2]; /* same, [0] boundary tiles, [1] interior tiles    */
+  long nfaces_dup, ninc_total;
+  /* exchange (empty when the partition has no partners) */
+  int npartners;
+  int *partner;            /* [npartners] ranks                                            */
+  int *send_off;           /* [npartners+1]                                                */
+  int *send_idx;           /* [send_off[npartners]] NEW ids, message order                 */
+  int *recv_off;           /* [npartners+1]; partner s fills rows nown+recv_off[s]...      */
+} cfdp_plan;
+
+void cfdp_plan_default_opts(cfdp_plan_opts *o);
+cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *o);
+void cfdp_plan_free(cfdp_plan *p);
+/* layout of a tile blob: byte offsets of its three sections */
+static inline long cfdp_blob_fn_bytes(int nfaces) { return ((long)nfaces * 24 + 15) & ~15L; }
+static inline long cfdp_blob_inc_bytes(int ninc) { return ((long)ninc * 4 + 15) & ~15L; }
+static inline long cfdp_blob_off_bytes(int npts) { return ((long)(npts + 1) * 4 + 15) & ~15L; }
+/* algorithmic bytes of one gradient / flux pass */
+double cfdp_algo_bytes_grad(long nfaces, long nown, long nadd);
+double cfdp_algo_bytes_flux(long nfaces, long nown, long nadd);
+
+/* var fields used by tests, bench and the driver */
+enum { CFDP_VAR_ONE = 0, CFDP_VAR_HASH = 1, CFDP_VAR_LINEAR = 2 };
+void cfdp_fill_var(double (*var)[NGRAD], const int *gid, int npoints, int kind,
+                   int nx, int ny, int nz);
+
+const char *cfdp_host_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
