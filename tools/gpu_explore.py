@@ -1,0 +1,45 @@
+"""GPU exploration (not part of the product): parity on a small mesh, then kernel timings
+over tile size x lanes-per-point on the level-2 and level-1 stand-in meshes."""
+import sys, time, json, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package, load_oracle, smoke
+m = load_package(); orc = load_oracle()
+out = open(os.environ.get("EXPLORE_OUT", "gpurun_out/explore.log"), "a")
+def log(*a):
+    s = " ".join(str(x) for x in a); print(s, flush=True); out.write(s + "\n"); out.flush()
+smoke()
+sizes = [int(x) for x in os.environ.get("SIZES", "64,128").split(",")]
+tps = [int(x) for x in os.environ.get("TPS", "64,128,256").split(",")]
+lanes = [int(x) for x in os.environ.get("LANES", "1,2,4,8").split(",")]
+for n in sizes:
+    gp = m.gen_params(n, ndomains=1); dom = m.gen_domain(gp, 0)
+    m.fill_var(dom, None, m.VAR_HASH)
+    var = dom.var.copy()
+    bg = m.algo_bytes_grad(dom.nfaces, dom.nown, 0); bf = m.algo_bytes_flux(dom.nfaces, dom.nown, 0)
+    ref = None
+    if n <= 64:
+        r = orc.CpuRef(dom.fpoint, dom.fnormal, dom.pvolume, dom.nown, nthreads=8)
+        g_ref = r.gradients(var); f_ref = r.flux(g_ref, 0); r.close()
+    for tp in tps:
+        for L in lanes:
+            if tp * L > 1024: continue
+            t0 = time.time()
+            try:
+                part = m.GpuPartition(dom, tile_points=tp, grad_lanes=L, flux_lanes=min(L, 8))
+            except Exception as e:
+                log("n", n, "tp", tp, "L", L, "FAILED", e); continue
+            t_up = time.time() - t0
+            iters = 50 if n <= 64 else 20
+            mg, mf = part.time_kernels(iters)
+            mg, mf = part.time_kernels(iters)
+            err = ""
+            if n <= 64:
+                part.gradients(); part.flux(); part.pull_fields()
+                e1 = np.abs(dom.grad - g_ref).max() / np.abs(g_ref).max()
+                e2 = np.abs(dom.psd_flux - f_ref).max() / np.abs(f_ref).max()
+                err = "relerr grad %.2e flux %.2e" % (e1, e2)
+            log("n", n, "tp", tp, "L", L, "grad %.1f us %.0f GB/s (%.1f%% of 8TB/s)" % (mg * 1e3, bg / mg / 1e6, bg / mg / 1e6 / 80),
+                "flux %.1f us %.0f GB/s" % (mf * 1e3, bf / mf / 1e6), "lds", part.stats["lds_grad"], "setup %.1fs" % t_up, err)
+            part.close()
+    dom.free()
