@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- Green-Gauss gradient iterations/s on the F6-like dualgrid stand-ins.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One "step" = one iteration of the hot path as the reference harness times it
+(reference src/solver.c:48-54): Green-Gauss gradients over all faces (+ halo exchange of the
+168-byte gradient rows when N>1) + the pseudo-flux face loop.  Inputs are resident in HBM
+before the timed region starts.
+
+Workload (BASELINE.json configs; the real f6/dualgrid.N files are stripped from the reference
+checkout, so deterministic stand-ins with the same schema are generated):
+  N=1: dualgrid.12 level-2 stand-in: 64^3 lattice, 12 domain files -> loader -> merged on one GPU
+  N=8: dualgrid.384 finest-level stand-in: 128^3 lattice, 384 domains, 48 per GPU
+  N=2,4: the same 262,144 owned points per GPU (128x64x64 / 128x128x64, 12 domains per GPU)
+so per-GPU work is fixed ("scaling": "weak") and `value` counts 262,144-point partition
+iterations per second summed over GPUs (= iterations/s of the whole mesh x N).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--tile-points", type=int, default=0)
+    ap.add_argument("--grad-lanes", type=int, default=0)
+    ap.add_argument("--flux-lanes", type=int, default=0)
+    ap.add_argument("--no-files", action="store_true", help="generate domains in memory (skip the loader)")
+    ap.add_argument("--no-finest", action="store_true", help="skip the finest-level single-GPU roofline run")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--cpu-samples", type=int, default=7)
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "staged"])
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    from cfd_proxy_amd import multigpu as mg
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        backend = "nccl" if args.transport == "rccl" else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                device_id=torch.device("cuda", device) if backend == "nccl" else None)
+
+    dims, ndom = mg.bench_mesh(world)
+    gp = pkg.gen_params(*dims, ndomains=ndom)
+    t0 = time.time()
+    part, st = mg.build_rank_partition(gp, ndom, world, rank, via_files=not args.no_files)
+    mg.exchange_requests(part, rank, world, dist)
+    nfaces_part, nown, nadd = part.nfaces, part.nown, part.nall - part.nown
+    solver = mg.RankSolver(part, rank, world, device, dist, transport=args.transport,
+                           tile_points=args.tile_points, grad_lanes=args.grad_lanes, flux_lanes=args.flux_lanes)
+    t_setup = time.time() - t0
+
+    def barrier():
+        solver.synchronize()
+        if dist is not None:
+            dist.barrier()
+        solver.synchronize()
+
+    def timed(steps: int, **kw) -> float:
+        """seconds for exactly `steps` steps, max over ranks"""
+        barrier()
+        t = time.perf_counter()
+        if world == 1:
+            solver.gpu.run_iterations(steps, with_flux=True, use_graph=True)  # hipGraph replay of 25-step chunks
+        else:
+            for _ in range(steps):
+                solver.step(**kw)
+        solver.synchronize()
+        barrier()
+        dt = time.perf_counter() - t
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=solver.device if args.transport == "rccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # warmup (untimed), then EXACTLY K timed steps
+    if world == 1:
+        solver.gpu.run_iterations(max(args.warmup, 1), with_flux=True, use_graph=True)
+    else:
+        for _ in range(args.warmup):
+            solver.step(with_exchange=True, overlap=True)
+    dt = timed(args.steps, with_exchange=True, overlap=True)
+    ms_per_step = dt / args.steps * 1e3
+    its = args.steps / dt  # iterations/s of the whole mesh
+
+    out = {
+        "metric": "green_gauss_gradient_iterations_per_sec",
+        "value": its * world,
+        "unit": "iterations/s of one 262144-point (dualgrid.12 lvl-2 sized) partition, summed over GPUs",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic (F6-like dualgrid stand-in; the f6/dualgrid.N files are not distributed)",
+        "config": {
+            "workload": {1: "dualgrid.12 lvl 2 stand-in (64^3, 12 domains merged on 1 GPU, no halo exchange)",
+                         8: "dualgrid.384 finest-level stand-in (128^3, 384 domains, 48 per GPU, RCCL halo exchange)"}.get(
+                world, f"{dims[0]}x{dims[1]}x{dims[2]} lattice, {ndom} domains, {ndom // world} per GPU, RCCL halo exchange"),
+            "mesh_points": dims[0] * dims[1] * dims[2], "points_per_gpu": nown, "faces_per_gpu": nfaces_part,
+            "ghost_points_per_gpu": nadd, "iteration": "gradients + halo exchange + pseudo flux",
+            "mesh_iterations_per_s": its, "via_dualgrid_files": not args.no_files,
+            "tiles": solver.gpu.stats["ntiles"], "tile_points": solver.gpu.stats["tile_points"],
+            "setup_s": round(t_setup, 2),
+        },
+    }
+
+    # ---- overlap efficiency (reference's own normalisation: comm_free / with exchange) ----
+    if world > 1:
+        dt_free = timed(args.steps, with_exchange=False)
+        dt_bulk = timed(args.steps, with_exchange=True, overlap=False)
+        out["overlap"] = {"t_comm_free_ms": dt_free / args.steps * 1e3, "t_async_ms": ms_per_step,
+                          "t_bulk_sync_ms": dt_bulk / args.steps * 1e3,
+                          "efficiency_async": dt_free / dt, "efficiency_bulk_sync": dt_free / dt_bulk}
+
+    # ---- roofline of the dominant kernel (gradient face loop), HIP events on its own stream ----
+    bg = pkg.algo_bytes_grad(nfaces_part, nown, nadd)
+    bf = pkg.algo_bytes_flux(nfaces_part, nown, nadd)
+    ms_g, ms_f = solver.gpu.time_kernels(200)
+    out["roofline"] = {"bound": "hbm", "kernel": "gg_gradient_kernel", "achieved": bg / (ms_g * 1e-3) / 1e9,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bg / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "traffic": None, "algorithmic_bytes_per_launch": bg, "us_per_launch": ms_g * 1e3,
+                       "flux_kernel": {"achieved": bf / (ms_f * 1e-3) / 1e9, "us_per_launch": ms_f * 1e3,
+                                       "algorithmic_bytes_per_launch": bf}}
+
+    if rank == 0 and world == 1:
+        # ---- the truly HBM-bound single-GPU case: finest level (2.1 M points, 0.95 GB per pass) ----
+        if not args.no_finest:
+            gp1 = pkg.gen_params(128, ndomains=1)
+            d1 = pkg.gen_domain(gp1, 0)
+            pkg.fill_var(d1, None, pkg.VAR_HASH)
+            p1 = pkg.GpuPartition(d1, device=device, tile_points=args.tile_points, grad_lanes=args.grad_lanes,
+                                  flux_lanes=args.flux_lanes)
+            g1, f1 = p1.time_kernels(50)
+            b1 = pkg.algo_bytes_grad(d1.nfaces, d1.nown, 0)
+            b1f = pkg.algo_bytes_flux(d1.nfaces, d1.nown, 0)
+            out["finest_level"] = {"workload": "dualgrid.384 finest-level stand-in merged on 1 GPU (128^3)",
+                                   "points": d1.nown, "faces": d1.nfaces, "algorithmic_bytes_per_launch": b1,
+                                   "us_per_launch": g1 * 1e3, "achieved": b1 / (g1 * 1e-3) / 1e9,
+                                   "frac": b1 / (g1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "iterations_per_s": 1e3 / (g1 + f1), "flux_us_per_launch": f1 * 1e3,
+                                   "flux_achieved": b1f / (f1 * 1e-3) / 1e9}
+            p1.close()
+            d1.free()
+        # ---- CPU baseline: the oracle (a port of the reference's algorithm class) on the host cores ----
+        if not args.no_cpu:
+            from __graft_entry__ import load_oracle
+            orc = load_oracle()
+            cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+            ref = orc.CpuRef(part.fpoint, part.fnormal, part.pvolume, part.nown, nthreads=cores)
+            samples = sorted(ref.timed(part.var, niter=25, with_flux=True) for _ in range(args.cpu_samples))
+            gsamples = sorted(ref.timed(part.var, niter=25, with_flux=False) for _ in range(3))
+            ref.close()
+            med = samples[len(samples) // 2]
+            out["cpu_baseline"] = {"value": 25.0 / med, "unit": "iterations/s", "cores": cores, "kind": "port",
+                                   "sample": f"same 64^3 merged mesh, {args.cpu_samples} samples x 25 iterations "
+                                             f"(gradients+flux), median; oracle/cpu_ref.c OpenMP",
+                                   "gradient_only_iterations_per_s": 25.0 / gsamples[len(gsamples) // 2]}
+    if rank == 0:
+        print(json.dumps(out))
+    solver.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -182,6 +182,10 @@ def _declare_host(lib: C.CDLL) -> None:
     lib.get_nc_int.restype = None
     lib.get_nc_double.argtypes = [C.c_int, C.c_char_p, P(C.c_double)]
     lib.get_nc_double.restype = None
+    lib.compute_communication_tables.argtypes = [P(CommData)]
+    lib.compute_communication_tables.restype = None
+    lib.cfdp_group_link_raw.argtypes = [C.c_int, P(P(CommData))]
+    lib.cfdp_group_link_raw.restype = None
     lib.cfdp_host_version.restype = C.c_char_p
 
 
@@ -319,6 +323,46 @@ class Domain:
             self._owns = False
 
 
+_libc = C.CDLL(None)
+_libc.malloc.restype = C.c_void_p
+_libc.malloc.argtypes = [C.c_size_t]
+
+
+def _c_copy(arr: np.ndarray, dtype, ctype):
+    """copy a numpy array into malloc()ed memory (owned by the C struct, freed with free())"""
+    a = np.ascontiguousarray(arr, dtype)
+    p = _libc.malloc(max(a.nbytes, 1))
+    C.memmove(p, a.ctypes.data, a.nbytes)
+    return C.cast(p, C.POINTER(ctype))
+
+
+def domain_from_arrays(fpoint, fnormal, pvolume, nown, var=None, ndomains=1, iproc=0,
+                       addpoint_owner=None, addpoint_idx=None, commpartner=None, sendcount=None,
+                       recvcount=None) -> Domain:
+    """Build a (solver_data, comm_data) pair from arrays -- what read_solver_data() /
+    read_communication_data() produce from a file (fields initialised to 1.0)."""
+    d = Domain()
+    nall, nf = len(pvolume), len(fpoint)
+    d.sd.nfaces = d.sd.nallfaces = nf
+    d.sd.nownpoints, d.sd.nallpoints, d.sd.ncolors, d.sd.niter = int(nown), nall, 1, 25
+    d.sd.fpoint = _c_copy(fpoint, np.int32, C.c_int)
+    d.sd.fnormal = _c_copy(fnormal, np.float64, C.c_double)
+    d.sd.pvolume = _c_copy(pvolume, np.float64, C.c_double)
+    d.sd.var = _c_copy(np.ones((nall, NGRAD)) if var is None else var, np.float64, C.c_double)
+    d.sd.grad = _c_copy(np.ones((nall, NGRAD, 3)), np.float64, C.c_double)
+    d.sd.psd_flux = _c_copy(np.ones((nall, NFLUX)), np.float64, C.c_double)
+    d.cd.nProc, d.cd.iProc, d.cd.ndomains, d.cd.nownpoints = ndomains, iproc, ndomains, int(nown)
+    if ndomains > 1:
+        d.cd.naddpoints = nall - int(nown)
+        d.cd.ncommdomains = len(commpartner)
+        d.cd.addpoint_owner = _c_copy(addpoint_owner, np.int32, C.c_int)
+        d.cd.addpoint_id = _c_copy(addpoint_idx, np.int32, C.c_int)
+        d.cd.commpartner = _c_copy(commpartner, np.int32, C.c_int)
+        d.cd.sendcount = _c_copy(sendcount, np.int32, C.c_int)
+        d.cd.recvcount = _c_copy(recvcount, np.int32, C.c_int)
+    return d
+
+
 def gen_params(nx, ny=None, nz=None, ndomains=1, connectivity=7, normals=1, volumes=1,
                ghost_faces=0, cdf_version=1, seed=20241) -> GenParams:
     ny = nx if ny is None else ny
@@ -407,6 +451,17 @@ def merge_link_group(parts: Sequence[Domain]) -> None:
     for s, ps in enumerate(parts):
         for r, (dom, idx) in merge_requests(ps).items():
             merge_set_send(parts[r], s, dom, idx)
+
+
+def link_raw_group(doms: Sequence[Domain]) -> None:
+    """Un-merged partitions, one per rank, all in this process: build recvindex
+    (compute_communication_tables, comm_data.c:161-174) and sendindex (the MPI index exchange
+    of comm_data.c:203-249, read directly from the partners' tables)."""
+    lib = host_lib()
+    for d in doms:
+        lib.compute_communication_tables(C.byref(d.cd))
+    arr = (C.POINTER(CommData) * len(doms))(*[C.pointer(d.cd) for d in doms])
+    lib.cfdp_group_link_raw(len(doms), arr)
 
 
 def merge_scatter(part: Domain, dl: int, npoints_d: int, field: np.ndarray) -> np.ndarray:

@@ -1,0 +1,201 @@
+"""One process per GPU: the multi-rank host of the hot path (torch.distributed = plumbing).
+
+The reference runs one MPI rank per dualgrid domain and exchanges ghost gradients with
+MPI/GASPI point-to-point messages (reference src/exchange_data_mpi.c:96-166,199-543,
+src/exchange_data_gaspi.c:105-151).  Here each GPU rank owns N/G whole domains
+(host/domain_merge.c) and exchanges 168-byte gradient rows with its neighbour ranks:
+
+  * transport "rccl": grouped ncclSend/ncclRecv (torch.distributed batch_isend_irecv on the
+    "nccl" backend = RCCL over xGMI).  The send side is the packed send arena, the receive
+    side is the ghost-row block of `grad` itself (ghost rows are numbered in message order),
+    so there is no unpack pass and no staging copy.
+  * transport "staged": device -> host -> gloo -> host -> device.  Only for tests on
+    machines without one GPU per rank (several ranks may share cuda:0).
+
+Overlap (reference: "trigger the communication as early as possible", README.txt:118-130):
+tiles holding sent points run first; pack + exchange go to a second stream while the
+interior tiles run on the main stream; the pseudo-flux kernel waits for both.
+
+Setup traffic mirrors create_recvsend_index (reference src/comm_data.c:203-249): every rank
+tells each partner which of the partner's points it needs, as (domain, idx) pairs.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import tempfile
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import (FLUX_CONSISTENT, TILES_ALL, TILES_BOUNDARY, TILES_INTERIOR, VAR_HASH, Domain,
+               GpuPartition, fill_var, gen_domain, gen_global_ids, load_domain, merge_domains,
+               merge_requests, merge_set_send, rank_domains)
+
+ROWLEN = 21  # NGRAD * 3 doubles per halo point (reference dim2, src/gradients.c:176-177)
+
+
+def bench_mesh(n_ranks: int) -> Tuple[Tuple[int, int, int], int]:
+    """Stand-in meshes for the BASELINE.json configs, 262,144 owned points per GPU:
+    1 GPU = dualgrid.12 level 2 (64^3), 8 GPUs = dualgrid.384 finest level (128^3)."""
+    table = {1: ((64, 64, 64), 12), 2: ((128, 64, 64), 24), 4: ((128, 128, 64), 48),
+             8: ((128, 128, 128), 384)}
+    if n_ranks in table:
+        return table[n_ranks]
+    return (64 * n_ranks, 64, 64), 12 * n_ranks
+
+
+def exchange_requests(part: Domain, rank: int, world: int, dist=None, all_requests=None) -> None:
+    """Fill part's send lists from what the partners request (comm_data.c:203-249 analogue).
+    `dist`: an initialised torch.distributed module, or None with `all_requests` given
+    (list over ranks of merge_requests() dicts) for in-process use."""
+    mine = {int(k): (v[0], v[1]) for k, v in merge_requests(part).items()}
+    if dist is not None and world > 1:
+        gathered: List[Optional[dict]] = [None] * world
+        dist.all_gather_object(gathered, mine)
+    else:
+        gathered = all_requests if all_requests is not None else [mine]
+    for s, req in enumerate(gathered):
+        if s == rank or not req:
+            continue
+        if rank in req:
+            dom, idx = req[rank]
+            merge_set_send(part, s, dom, idx)
+
+
+def build_rank_partition(gp, n_domains: int, world: int, rank: int, via_files: bool = True,
+                         var_kind: int = VAR_HASH, workdir: Optional[str] = None) -> Tuple[Domain, dict]:
+    """Generate (optionally through dualgrid files + the drop-in loader) and merge the domains
+    of `rank`.  Returns the merged partition (send lists not yet linked) and setup stats."""
+    first, count = rank_domains(rank, n_domains, world)
+    ids = list(range(first, first + count))
+    tmp = None
+    doms = []
+    if via_files:
+        tmp = tempfile.mkdtemp(prefix=f"cfdp_r{rank}_", dir=workdir)
+        prefix = os.path.join(tmp, "dualgrid")
+        from . import write_mesh
+        write_mesh(gp, prefix, 2, ids)
+        doms = [load_domain(prefix, d, 2) for d in ids]
+        shutil.rmtree(tmp, ignore_errors=True)
+    else:
+        doms = [gen_domain(gp, d) for d in ids]
+    for d, dom in zip(ids, doms):
+        fill_var(dom, gen_global_ids(gp, d, dom.nall), var_kind, gp.nx, gp.ny, gp.nz)
+    part = merge_domains(doms, ids, n_domains, world, rank)
+    mi = part.merge_info.contents
+    for dl, dom in enumerate(doms):
+        l2m = np.ctypeslib.as_array(mi.local2merged[dl], shape=(dom.nall,))
+        part.var[l2m] = dom.var
+    stats = dict(domains=count, nown=part.nown, nghost=part.nall - part.nown, nfaces=part.nfaces,
+                 faces_dropped=int(mi.nfaces_dropped))
+    for dom in doms:
+        dom.free()
+    return part, stats
+
+
+class RankSolver:
+    """The per-rank iteration: gradients (+ halo exchange) + pseudo flux on one GPU."""
+
+    def __init__(self, part: Domain, rank: int, world: int, device: int, dist=None,
+                 transport: str = "rccl", tile_points: int = 0, grad_lanes: int = 0, flux_lanes: int = 0):
+        import torch
+
+        self.torch = torch
+        self.dist = dist
+        self.rank, self.world = rank, world
+        self.transport = transport
+        torch.cuda.set_device(device)
+        self.device = torch.device("cuda", device)
+        self.gpu = GpuPartition(part, device=device, tile_points=tile_points, grad_lanes=grad_lanes,
+                                flux_lanes=flux_lanes)
+        c = self.gpu.counts()
+        self.nown, self.nall, self.nsend, self.nrecv = c["nown"], c["nall"], c["nsend"], c["nrecv"]
+        self.partners = self.gpu.partners()
+        # torch owns the buffers RCCL touches: grad (ghost rows = receive side) and the send arena
+        self.grad_t = torch.empty(self.nall * ROWLEN, dtype=torch.float64, device=self.device)
+        self.send_t = torch.empty(max(self.nsend, 1) * ROWLEN, dtype=torch.float64, device=self.device)
+        self.gpu.bind_grad(self.grad_t.data_ptr())
+        self.gpu.bind_sendbuf(self.send_t.data_ptr())
+        self.s_main = torch.cuda.Stream(device=self.device)
+        self.s_comm = torch.cuda.Stream(device=self.device)
+        self.ev_pack = torch.cuda.Event()
+        self.ev_flux = torch.cuda.Event()
+        self.send_views, self.recv_views = [], []
+        so = ro = 0
+        for s in range(len(self.partners)):
+            _, sb = self.gpu.send_slice(s)
+            _, rb = self.gpu.recv_slice(s)
+            ns, nr = sb // 8, rb // 8
+            self.send_views.append(self.send_t[so:so + ns])
+            self.recv_views.append(self.grad_t[self.nown * ROWLEN + ro: self.nown * ROWLEN + ro + nr])
+            so += ns
+            ro += nr
+        if transport == "staged":
+            self.h_send = [torch.empty(v.numel(), dtype=torch.float64).pin_memory() for v in self.send_views]
+            self.h_recv = [torch.empty(v.numel(), dtype=torch.float64).pin_memory() for v in self.recv_views]
+
+    # ------------------------------------------------------------------------------ pieces
+    def _exchange(self) -> None:
+        """halo exchange on the comm stream; the caller has recorded ev_pack on s_main"""
+        torch, dist = self.torch, self.dist
+        if not self.partners or self.world == 1:
+            return
+        with torch.cuda.stream(self.s_comm):
+            self.s_comm.wait_event(self.ev_pack)
+            # ghost rows are still read by the previous flux kernel (write-after-read)
+            self.s_comm.wait_event(self.ev_flux)
+            if self.transport == "rccl":
+                ops = []
+                for s, peer in enumerate(self.partners):
+                    if self.send_views[s].numel():
+                        ops.append(dist.P2POp(dist.isend, self.send_views[s], peer))
+                    if self.recv_views[s].numel():
+                        ops.append(dist.P2POp(dist.irecv, self.recv_views[s], peer))
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()  # orders s_comm after the RCCL stream; does not block the host
+            else:  # staged through the host (tests only)
+                for s in range(len(self.partners)):
+                    self.h_send[s].copy_(self.send_views[s], non_blocking=True)
+                self.s_comm.synchronize()
+                reqs = []
+                for s, peer in enumerate(self.partners):
+                    if self.h_send[s].numel():
+                        reqs.append(dist.isend(self.h_send[s], peer))
+                    if self.h_recv[s].numel():
+                        reqs.append(dist.irecv(self.h_recv[s], peer))
+                for r in reqs:
+                    r.wait()
+                for s in range(len(self.partners)):
+                    self.recv_views[s].copy_(self.h_recv[s], non_blocking=True)
+
+    def step(self, with_exchange: bool = True, overlap: bool = True, with_flux: bool = True,
+             flux_mode: int = FLUX_CONSISTENT) -> None:
+        """one iteration = what test_solver times (reference src/solver.c:48-54)"""
+        sm = self.s_main.cuda_stream
+        comm = with_exchange and self.world > 1 and bool(self.partners)
+        if not comm:
+            self.gpu.gradients(TILES_ALL, sm)
+        else:
+            self.gpu.gradients(TILES_BOUNDARY if overlap else TILES_ALL, sm)
+            self.gpu.pack(sm)
+            self.ev_pack.record(self.s_main)
+            if overlap:
+                self.gpu.gradients(TILES_INTERIOR, sm)
+            self._exchange()
+            self.s_main.wait_stream(self.s_comm)
+        if with_flux:
+            self.gpu.flux(flux_mode, sm)
+        self.ev_flux.record(self.s_main)
+
+    def synchronize(self) -> None:
+        self.torch.cuda.synchronize(self.device)
+
+    def grad_host(self) -> np.ndarray:
+        """grad in FILE (merged-partition) numbering, ghost rows included"""
+        self.synchronize()
+        self.gpu.pull_fields()
+        return self.gpu.dom.grad
+
+    def close(self) -> None:
+        self.gpu.close()

@@ -1,0 +1,91 @@
+"""One rank of a multi-process halo-exchange test (launched by test_multirank.py).
+
+CPU mode (gloo, no GPU): host logic only -- domain merge, request exchange over the process
+group (the create_recvsend_index analogue), message order -- with the ORACLE standing in for the
+device kernels (tests may use the oracle; the product never does).
+GPU mode (--gpu): the real RankSolver with the "staged" transport, all ranks on cuda:0.
+Each rank checks its owned AND ghost gradient rows against the un-partitioned mesh."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_oracle, load_package  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("--dims", default="16,12,10")
+    ap.add_argument("--ndomains", type=int, default=12)
+    ap.add_argument("--files", action="store_true")
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg, orc = load_package(), load_oracle()
+    from cfd_proxy_amd import multigpu as mg
+
+    dims = tuple(int(x) for x in args.dims.split(","))
+    gp = pkg.gen_params(*dims, ndomains=args.ndomains)
+    part, st = mg.build_rank_partition(gp, args.ndomains, world, rank, via_files=args.files)
+    mg.exchange_requests(part, rank, world, dist)
+
+    # global truth from the un-partitioned mesh
+    g1 = pkg.gen_params(*dims, ndomains=1)
+    whole = pkg.gen_domain(g1, 0)
+    pkg.fill_var(whole, None, pkg.VAR_HASH, *dims)
+    truth = orc.np_gradients(whole.fpoint, whole.fnormal, whole.pvolume, whole.var, whole.nown)
+    # lattice id of every merged point: var = 1 + 0.01*((7*gid + 13*eq) % 101) is not injective, so
+    # rebuild gid from the generator instead
+    first, count = pkg.rank_domains(rank, args.ndomains, world)
+    gid = np.full(part.nall, -1, np.int64)
+    mi = part.merge_info.contents
+    for dl in range(count):
+        dom = pkg.gen_domain(gp, first + dl)
+        l2m = np.ctypeslib.as_array(mi.local2merged[dl], shape=(dom.nall,))
+        gid[l2m] = pkg.gen_global_ids(gp, first + dl, dom.nall)
+        dom.free()
+    assert (gid >= 0).all()
+    assert np.array_equal(part.var, whole.var[gid])
+
+    if args.gpu:
+        solver = mg.RankSolver(part, rank, world, 0, dist, transport="staged", tile_points=32)
+        for overlap in (True, False):
+            part.grad[:] = 1.0
+            solver.gpu.push_fields()
+            solver.step(with_exchange=True, overlap=overlap, with_flux=True)
+            solver.step(with_exchange=True, overlap=overlap, with_flux=True)  # twice: buffer reuse hazards
+            g = solver.grad_host().copy()
+            err = np.abs(g - truth[gid]).max() / np.abs(truth).max()
+            assert err <= 1e-12, (rank, overlap, err)
+        solver.close()
+    else:
+        ref = orc.CpuRef(part.fpoint, part.fnormal, part.pvolume, part.nown, nthreads=2, sendpoints=part.send_points())
+        g = ref.gradients(part.var)
+        ref.close()
+        assert np.all(g[part.nown:] == 1.0)
+        reqs, bufs = [], {}
+        for s in part.partners:
+            msg = torch.from_numpy(orc.pack(part.sendindex(s), g).ravel().copy())
+            bufs[s] = torch.empty(len(part.recvindex(s)) * 21, dtype=torch.float64)
+            reqs.append(dist.isend(msg, s))
+            reqs.append(dist.irecv(bufs[s], s))
+        for r in reqs:
+            r.wait()
+        for s in part.partners:
+            orc.unpack(part.recvindex(s), g, bufs[s].numpy().reshape(-1, 21))
+        err = np.abs(g - truth[gid]).max() / np.abs(truth).max()
+        assert err <= 1e-12, (rank, err)
+    dist.barrier()
+    print(f"RANK_OK {rank} own={part.nown} ghost={part.nall - part.nown} partners={part.partners}")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,85 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol include/*.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"^\s*#.*?$", "", src, flags=re.M)
+    src = re.sub(r"\{[^{}]*\}", "{}", src)  # bodies of structs/enums/inline functions
+    src = re.sub(r"\{[^{}]*\}", "{}", src)
+    names = []
+    for stmt in src.split(";"):
+        stmt = " ".join(stmt.split())
+        if not stmt or stmt.startswith("typedef") or "static inline" in stmt or stmt.startswith("extern \"C\""):
+            stmt = stmt.replace('extern "C" {}', "").replace('extern "C" {', "").strip()
+            if not stmt or stmt.startswith("typedef") or "static inline" in stmt:
+                continue
+        m = re.match(r"^(?:[\w]+[\s\*]+)+(\w+)\s*\(", stmt)
+        if m:
+            names.append(m.group(1))
+    return names
+
+
+@pytest.mark.parametrize("header,lib", [("cfdproxy_hip.h", "libcfdproxy_hip.so"), ("cfdproxy_host.h", "libcfdproxy_hip.so"),
+                                        ("cfdproxy_dropin.h", "libcfdproxy_hip.so"), ("cfdproxy_host.h", "libcfdproxy_host.so")])
+def test_every_declared_symbol_is_exported(pkg, header, lib):
+    names = declared_functions(header)
+    assert len(names) >= 10, names
+    handle = ctypes.CDLL(os.path.join(ROOT, "cfd-proxy_amd", "lib", lib))
+    missing = [n for n in names if not hasattr(handle, n)]
+    assert not missing, f"{lib} does not export {missing}"
+
+
+def test_expected_entry_points_are_declared():
+    hip = declared_functions("cfdproxy_hip.h")
+    for n in ("cfdp_gpu_create", "cfdp_gpu_upload_plan", "cfdp_gpu_gradients", "cfdp_gpu_flux", "cfdp_gpu_pack",
+              "cfdp_gpu_unpack", "cfdp_gpu_rank_gradients", "cfdp_gpu_rank_flux", "cfdp_gpu_time_kernels"):
+        assert n in hip
+    drop = declared_functions("cfdproxy_dropin.h")
+    for n in ("init_communication", "read_communication_data", "compute_communication_tables",
+              "free_communication_ressources", "read_solver_data", "init_solver_data", "init_threads", "test_solver",
+              "compute_psd_flux", "get_nc_int", "get_nc_double", "get_nc_val") + tuple(
+            "compute_gradients_gg_" + v for v in ("comm_free", "mpi_bulk_sync", "mpi_early_recv", "mpi_async",
+                                                  "gaspi_bulk_sync", "gaspi_async", "mpifence_bulk_sync",
+                                                  "mpifence_async", "mpipscw_bulk_sync", "mpipscw_async")):
+        assert n in drop, n
+
+
+def test_product_never_touches_the_oracle():
+    """the product path must not import, link or execute anything under oracle/"""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "cfd-proxy_amd")):
+        if "/build" in base or base.endswith("/lib") or base.endswith("/bin") or "__pycache__" in base:
+            continue
+        for f in files:
+            if f.endswith((".c", ".h", ".hip", ".py", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"cpu_ref|libcpu_ref|load_oracle|oracle/", txt) and "never" not in txt.split("oracle/")[0][-200:]:
+                    for line in txt.splitlines():
+                        if re.search(r"cpu_ref|libcpu_ref|load_oracle", line) or (
+                                "oracle/" in line and not line.lstrip().startswith(("*", "//", "#", '"""'))):
+                            bad.append((f, line.strip()))
+    assert not bad, bad
+
+
+def test_gpu_entry_points_fail_loudly_without_a_device(pkg):
+    """no CPU fallback: without a GPU the ABI reports an error instead of computing"""
+    hip = pkg.hip_lib()
+    if hip.cfdp_gpu_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = ctypes.c_void_p()
+    assert hip.cfdp_gpu_create(0, ctypes.byref(h)) != 0
+    assert b"HIP" in hip.cfdp_gpu_last_error() or b"hip" in hip.cfdp_gpu_last_error()
+    gp = pkg.gen_params(4, 4, 4)
+    dom = pkg.gen_domain(gp, 0)
+    with pytest.raises(pkg.GpuError):
+        pkg.GpuPartition(dom)
+    dom.free()

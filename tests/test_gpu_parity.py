@@ -1,0 +1,346 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the golden vectors of the
+compiled reference and against the oracle, on an MI355X.  Tolerance: 1e-10 relative
+(BASELINE.json north_star), measured as in SURVEY.md section 8c (conftest.rel_err)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, TOL, golden_domain, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+LANES = [1, 2, 4, 8]
+
+
+def run_partition(pkg, dom, tile_points, lanes, flux_mode=0, flux_lanes=None):
+    part = pkg.GpuPartition(dom, tile_points=tile_points, grad_lanes=lanes,
+                            flux_lanes=lanes if flux_lanes is None else flux_lanes)
+    part.gradients()
+    part.flux(flux_mode)
+    part.pull_fields()
+    part.close()
+    return dom.grad.copy(), dom.psd_flux.copy()
+
+
+@pytest.mark.parametrize("name", ["g1_7x6x5", "g1_cart_6x6x6", "g1_one_9x9x9"])
+@pytest.mark.parametrize("lanes", LANES)
+@pytest.mark.parametrize("tile_points", [16, 64, 128])
+def test_gradients_match_compiled_reference(gpu, orc, name, lanes, tile_points):
+    pkg = gpu
+    fx = load_golden(name)
+    dom = golden_domain(pkg, fx, 0)
+    fp, fn, vol, var, nown = dom.fpoint.copy(), dom.fnormal.copy(), dom.pvolume.copy(), dom.var.copy(), dom.nown
+    g, f = run_partition(pkg, dom, tile_points, lanes, flux_mode=pkg.FLUX_REFERENCE)
+    for key in [k for k in fx.files if k.startswith("grad_comm_free")]:
+        assert rel_err(orc, g, fx[key], fp, fn, vol, var, nown) <= TOL, key
+    gold_f = fx["flux_comm_free_t1_d0"]
+    assert np.abs(f - gold_f)[:nown].max() <= TOL * np.abs(gold_f[:nown]).max()
+    dom.free()
+
+
+@pytest.mark.parametrize("lanes", LANES)
+def test_flux_consistent_mode_matches_oracle(gpu, orc, lanes):
+    pkg = gpu
+    fx = load_golden("g1_7x6x5")
+    dom = golden_domain(pkg, fx, 0)
+    g, f = run_partition(pkg, dom, 32, lanes, flux_mode=pkg.FLUX_CONSISTENT)
+    f_np = orc.np_flux(dom.fpoint, dom.fnormal, g, dom.nown, mode=0)
+    assert np.abs(f - f_np)[: dom.nown].max() <= TOL * np.abs(f_np[: dom.nown]).max()
+    dom.free()
+
+
+def test_comm_free_leaves_ghost_rows_and_faceless_points_alone(gpu, orc):
+    """the reference never writes a ghost row (points_of_color.c:140-147,254); a single domain of a
+    partitioned mesh run alone keeps the initial 1.0 there (fixture from the compiled reference)"""
+    pkg = gpu
+    fx = load_golden("g4_dom0_alone")
+    nown = int(fx["d0_nown"])
+    dom = pkg.domain_from_arrays(fx["d0_fpoint"], fx["d0_fnormal"], fx["d0_pvolume"], nown, var=fx["d0_var"])
+    g, f = run_partition(pkg, dom, 32, 4, flux_mode=pkg.FLUX_REFERENCE)
+    gold = fx["grad_alone_0_t1_d0"]
+    assert np.all(g[nown:] == 1.0) and np.all(gold[nown:] == 1.0)
+    assert rel_err(orc, g, gold, dom.fpoint, dom.fnormal, dom.pvolume, dom.var, nown) <= TOL
+    gold_f = fx["flux_alone_0_t1_d0"]
+    assert np.abs(f - gold_f)[:nown].max() <= TOL * np.abs(gold_f[:nown]).max()
+    dom.free()
+    # isolated point / ghost-ghost face
+    fp = np.array([[0, 1], [1, 2], [2, 4], [4, 5], [5, 4]], np.int32)
+    fn = np.arange(15, dtype=float).reshape(5, 3) + 1
+    dom = pkg.domain_from_arrays(fp, fn, np.arange(6, dtype=float) + 1, 4, var=np.arange(42, dtype=float).reshape(6, 7) * 0.5 + 1)
+    g, f = run_partition(pkg, dom, 8, 2)
+    ref = orc.np_gradients(fp, fn, dom.pvolume, dom.var, 4)
+    assert np.all(g[3] == 1.0) and np.all(g[4:] == 1.0) and np.all(f[3] == 1.0)
+    assert np.allclose(g[:3], ref[:3], rtol=1e-13)
+    dom.free()
+
+
+@pytest.mark.parametrize("name,nd", [("g2_10x8x6", 2), ("g4_12x10x9", 4)])
+@pytest.mark.parametrize("overlap", [False, True])
+def test_halo_exchange_between_in_process_ranks(gpu, orc, name, nd, overlap):
+    """one un-merged domain per rank, all ranks on this GPU, peer copies into the ghost rows:
+    reproduces the reference's mpi_bulk_sync result including the ghost rows"""
+    pkg = gpu
+    fx = load_golden(name)
+    doms = [golden_domain(pkg, fx, d) for d in range(nd)]
+    pkg.link_raw_group(doms)
+    parts = [pkg.GpuPartition(dom, tile_points=16, grad_lanes=4) for dom in doms]
+    for _ in range(3):  # repeated iterations exercise the send-arena / ghost-row reuse ordering
+        pkg.group_iteration(parts, with_exchange=True, overlap=overlap, with_flux=True)
+    pkg.group_sync(parts)
+    for d, (dom, part) in enumerate(zip(doms, parts)):
+        part.pull_fields()
+        gold = fx[f"grad_mpi_bulk_sync_t1_d{d}"]
+        assert rel_err(orc, dom.grad, gold, dom.fpoint, dom.fnormal, dom.pvolume, dom.var, dom.nown) <= TOL
+        assert np.abs(dom.grad[dom.nown:] - gold[dom.nown:]).max() <= TOL * np.abs(gold).max()
+    for d, dom in enumerate(doms):  # ghost rows are bit copies of the owner's rows
+        owner, idx = fx[f"d{d}_addpoint_owner"], fx[f"d{d}_addpoint_idx"]
+        for j in range(dom.nall - dom.nown):
+            assert np.array_equal(dom.grad[dom.nown + j], doms[owner[j]].grad[idx[j]])
+    for p in parts:
+        p.close()
+    for dom in doms:
+        dom.free()
+
+
+def test_pack_and_unpack_kernels_match_copy_in_out(gpu, orc):
+    """gg_pack_kernel / gg_unpack_kernel vs exchange_dbl_copy_in/out (threads.c:791-839)"""
+    import torch
+    pkg = gpu
+    fx = load_golden("g4_12x10x9")
+    doms = [golden_domain(pkg, fx, d) for d in range(4)]
+    pkg.link_raw_group(doms)
+    dom = doms[0]
+    rng = np.random.default_rng(5)
+    dom.grad[:] = rng.standard_normal(dom.grad.shape)
+    g0 = dom.grad.copy()
+    part = pkg.GpuPartition(dom, tile_points=16)
+    c = part.counts()
+    send = torch.zeros(c["nsend"] * 21, dtype=torch.float64, device="cuda")
+    part.bind_sendbuf(send.data_ptr())
+    part.pack()
+    part.sync()
+    expect = np.concatenate([orc.pack(dom.sendindex(k), g0) for k in part.partners()])
+    assert np.array_equal(send.cpu().numpy().reshape(-1, 21), expect)
+    msg = rng.standard_normal((c["nrecv"], 21))
+    recv = torch.from_numpy(msg).cuda()
+    part.unpack(recv.data_ptr())
+    part.pull_fields()
+    ref = g0.copy()
+    off = 0
+    for k in part.partners():
+        ri = dom.recvindex(k)
+        orc.unpack(ri, ref, msg[off: off + len(ri)])
+        off += len(ri)
+    assert np.array_equal(dom.grad, ref)
+    part.close()
+    for d in doms:
+        d.free()
+
+
+@pytest.mark.parametrize("G", [1, 3])
+def test_merged_partitions_match_unpartitioned_mesh(gpu, orc, G):
+    """12 domain files -> loader -> G merged partitions (+ exchange) == the un-partitioned mesh"""
+    pkg = gpu
+    dims, nd = (24, 20, 18), 12
+    gp = pkg.gen_params(*dims, ndomains=nd)
+    g1 = pkg.gen_params(*dims, ndomains=1)
+    whole = pkg.gen_domain(g1, 0)
+    pkg.fill_var(whole, None, pkg.VAR_HASH, *dims)
+    ref = orc.CpuRef(whole.fpoint, whole.fnormal, whole.pvolume, whole.nown, nthreads=4)
+    truth = ref.gradients(whole.var)
+    ftruth = ref.flux(truth, mode=0)
+    ref.close()
+    from cfd_proxy_amd import multigpu as mg
+    parts = [mg.build_rank_partition(gp, nd, G, r, via_files=True)[0] for r in range(G)]
+    pkg.merge_link_group(parts)
+    gparts = [pkg.GpuPartition(p, tile_points=64) for p in parts]
+    pkg.group_iteration(gparts, with_exchange=True, overlap=True, with_flux=True)
+    pkg.group_sync(gparts)
+    for r, (p, gp_) in enumerate(zip(parts, gparts)):
+        gp_.pull_fields()
+        first, count = pkg.rank_domains(r, nd, G)
+        for dl in range(count):
+            dom = pkg.gen_domain(gp, first + dl)
+            gid = pkg.gen_global_ids(gp, first + dl, dom.nall)
+            back = pkg.merge_scatter(p, dl, dom.nall, p.grad)
+            assert np.abs(back - truth[gid]).max() <= TOL * np.abs(truth).max()   # ghost rows included
+            fb = pkg.merge_scatter(p, dl, dom.nall, p.psd_flux)
+            assert np.abs(fb[: dom.nown] - ftruth[gid[: dom.nown]]).max() <= TOL * np.abs(ftruth).max()
+            dom.free()
+        gp_.close()
+    whole.free()
+
+
+@pytest.mark.parametrize("var_kind", ["one", "hash", "linear"])
+@pytest.mark.parametrize("lanes", LANES)
+def test_oracle_parity_seeded_mesh(gpu, orc, var_kind, lanes):
+    pkg = gpu
+    dims = (40, 36, 30)
+    gp = pkg.gen_params(*dims, ndomains=1)
+    dom = pkg.gen_domain(gp, 0)
+    pkg.fill_var(dom, None, {"one": pkg.VAR_ONE, "hash": pkg.VAR_HASH, "linear": pkg.VAR_LINEAR}[var_kind], *dims)
+    var = dom.var.copy()
+    ref = orc.CpuRef(dom.fpoint, dom.fnormal, dom.pvolume, dom.nown, nthreads=8)
+    g_ref = ref.gradients(var)
+    f_ref = ref.flux(g_ref, mode=0)
+    ref.close()
+    g, f = run_partition(pkg, dom, 128 if lanes < 8 else 64, lanes)
+    assert rel_err(orc, g, g_ref, dom.fpoint, dom.fnormal, dom.pvolume, var, dom.nown) <= TOL
+    assert np.abs(g - g_ref).max() <= TOL * np.abs(g_ref).max()
+    assert np.abs(f - f_ref).max() <= TOL * max(np.abs(f_ref).max(), 1e-300)
+    dom.free()
+
+
+def test_known_answer_cartesian_linear_field(gpu):
+    pkg = gpu
+    n = 20
+    gp = pkg.gen_params(n, n, n, ndomains=1, connectivity=3, normals=0, volumes=0)
+    dom = pkg.gen_domain(gp, 0)
+    pkg.fill_var(dom, None, pkg.VAR_LINEAR, n, n, n)
+    g, _ = run_partition(pkg, dom, 128, 4)
+    gid = np.arange(dom.nall)
+    x, y, z = gid % n, (gid // n) % n, gid // (n * n)
+    interior = (x > 0) & (x < n - 1) & (y > 0) & (y < n - 1) & (z > 0) & (z < n - 1)
+    for eq in range(7):
+        slope = np.array([eq + 1.0, 2.0 * eq - 3.0, 0.5 * eq + 1.0])
+        assert np.abs(g[interior, eq, :] - slope).max() <= 1e-10
+    # constant field on a closed stencil: exactly zero gradient in the interior
+    pkg.fill_var(dom, None, pkg.VAR_ONE)
+    g, _ = run_partition(pkg, dom, 128, 4)
+    assert np.abs(g[interior]).max() <= 1e-12
+    dom.free()
+
+
+def sampled_reference(orc, dom, sample):
+    """numpy statement restricted to a set of points (cheap at full size)"""
+    fp = dom.fpoint
+    mark = np.zeros(dom.nall, bool)
+    mark[sample] = True
+    sel = mark[fp[:, 0]] | mark[fp[:, 1]]
+    g = orc.np_gradients(fp[sel], dom.fnormal[sel], dom.pvolume, dom.var, dom.nown)
+    return g[sample]
+
+
+@pytest.mark.parametrize("n", [64, 128])
+def test_full_size_properties(gpu, orc, n):
+    """BASELINE.json sizes (64^3 level-2, 128^3 finest stand-in): determinism, linearity,
+    independence of the tiling, and sampled rows against the numpy statement"""
+    pkg = gpu
+    gp = pkg.gen_params(n, ndomains=1)
+    dom = pkg.gen_domain(gp, 0)
+    rng = np.random.default_rng(n)
+    v1 = 1.0 + rng.random((dom.nall, 7))
+    v2 = rng.standard_normal((dom.nall, 7))
+    part = pkg.GpuPartition(dom, tile_points=128, grad_lanes=4)
+
+    def grad_of(v, p=part):
+        dom.var[:] = v
+        p.push_fields()
+        p.gradients()
+        p.pull_fields()
+        return dom.grad.copy()
+
+    g1 = grad_of(v1)
+    assert np.array_equal(g1, grad_of(v1))                          # deterministic: no atomics
+    g2 = grad_of(v2)
+    a, b = 0.75, -2.0                                               # exact scalings: linearity to round-off
+    g12 = grad_of(a * v1 + b * v2)
+    scale = np.abs(g1).max() + np.abs(g2).max()
+    assert np.abs(g12 - (a * g1 + b * g2)).max() <= 1e-12 * scale
+    sample = rng.choice(dom.nown, 4000, replace=False)
+    dom.var[:] = v1
+    ref = sampled_reference(orc, dom, sample)
+    assert np.abs(g1[sample] - ref).max() <= TOL * np.abs(ref).max()
+    part.close()
+    part2 = pkg.GpuPartition(dom, tile_points=64, grad_lanes=8)    # another tiling, another kernel variant
+    g1b = grad_of(v1, part2)
+    assert np.abs(g1b - g1).max() <= 1e-12 * np.abs(g1).max()
+    part2.flux(pkg.FLUX_CONSISTENT)
+    part2.pull_fields()
+    f = dom.psd_flux.copy()
+    part2.flux(pkg.FLUX_CONSISTENT)
+    part2.pull_fields()
+    assert np.array_equal(f, dom.psd_flux)                          # flux idempotent + deterministic
+    part2.close()
+    dom.free()
+
+
+def test_abi_error_paths(gpu):
+    pkg = gpu
+    hip = pkg.hip_lib()
+    h = C.c_void_p()
+    assert hip.cfdp_gpu_create(99, C.byref(h)) != 0 and b"out of range" in hip.cfdp_gpu_last_error()
+    assert hip.cfdp_gpu_create(0, C.byref(h)) == 0
+    assert hip.cfdp_gpu_gradients(h, 0, None) != 0 and b"no plan" in hip.cfdp_gpu_last_error()
+    assert hip.cfdp_gpu_set_variant(h, 3, 4) != 0
+    hip.cfdp_gpu_destroy(h)
+    gp = pkg.gen_params(6, 6, 6)
+    dom = pkg.gen_domain(gp, 0)
+    part = pkg.GpuPartition(dom, tile_points=16)
+    with pytest.raises(pkg.GpuError):
+        part.gradients(which=7)
+    with pytest.raises(pkg.GpuError):
+        part.flux(mode=5)
+    part.close()
+    dom.free()
+
+
+def test_dropin_entry_points_in_reference_call_order(gpu, orc, tmp_path):
+    """the reference main()'s sequence (hybrid.f6.c:54-88) against the drop-in library"""
+    pkg = gpu
+    lib = pkg.hip_lib()
+    gp = pkg.gen_params(14, 12, 10, ndomains=1)
+    prefix = str(tmp_path / "dualgrid")
+    pkg.write_mesh(gp, prefix, 2)
+    sd, cd = pkg.SolverData(), pkg.CommData()
+    P = C.POINTER
+    lib.init_communication.argtypes = [C.c_int, C.c_void_p, P(pkg.CommData)]
+    lib.cfdp_nc_open.argtypes = [C.c_char_p]
+    for fn, at in (("read_solver_data", [C.c_int, P(pkg.SolverData)]), ("init_solver_data", [P(pkg.SolverData), C.c_int]),
+                   ("read_communication_data", [C.c_int, P(pkg.CommData)]), ("compute_communication_tables", [P(pkg.CommData)]),
+                   ("init_threads", [P(pkg.CommData), P(pkg.SolverData), C.c_int]),
+                   ("compute_gradients_gg_comm_free", [P(pkg.CommData), P(pkg.SolverData), C.c_int]),
+                   ("compute_psd_flux", [P(pkg.SolverData)]), ("cfdp_sync_fields_to_host", [P(pkg.SolverData)]),
+                   ("cfdp_sync_fields_to_device", [P(pkg.SolverData)]), ("free_communication_ressources", [P(pkg.CommData)])):
+        getattr(lib, fn).argtypes = at
+        getattr(lib, fn).restype = None
+    lib.init_communication(0, None, C.byref(cd))
+    ncid = lib.cfdp_nc_open(f"{prefix}_domain_0_lvl_2".encode())
+    lib.read_solver_data(ncid, C.byref(sd))
+    lib.init_solver_data(C.byref(sd), 25)
+    lib.read_communication_data(ncid, C.byref(cd))
+    lib.compute_communication_tables(C.byref(cd))
+    nall, nf = sd.nallpoints, sd.nfaces
+    var = np.ctypeslib.as_array(sd.var, shape=(nall * 7,)).reshape(nall, 7)
+    var[:] = 1.0 + 0.01 * ((7 * np.arange(nall)[:, None] + 13 * np.arange(7)[None, :]) % 101)
+    lib.init_threads(C.byref(cd), C.byref(sd), 4)
+    for i in range(2):
+        lib.compute_gradients_gg_comm_free(C.byref(cd), C.byref(sd), i == 1)
+        lib.compute_psd_flux(C.byref(sd))
+    lib.cfdp_sync_fields_to_host(C.byref(sd))
+    grad = np.ctypeslib.as_array(sd.grad, shape=(nall * 21,)).reshape(nall, 7, 3)
+    fp = np.ctypeslib.as_array(sd.fpoint, shape=(nf * 2,)).reshape(nf, 2)
+    fn_ = np.ctypeslib.as_array(sd.fnormal, shape=(nf * 3,)).reshape(nf, 3)
+    vol = np.ctypeslib.as_array(sd.pvolume, shape=(nall,))
+    ref = orc.CpuRef(fp, fn_, vol, sd.nownpoints, nthreads=2)
+    g_ref = ref.gradients(var)
+    ref.close()
+    assert rel_err(orc, grad, g_ref, fp, fn_, vol, var, sd.nownpoints) <= TOL
+    lib.free_communication_ressources(C.byref(cd))
+    lib.cfdp_nc_close(ncid)
+
+
+def test_driver_binary_with_reference_cli(gpu, tmp_path):
+    """bin/hybrid.f6.hip -lvl L PREFIX: 4 domain files, 2 in-process ranks on this GPU"""
+    pkg = gpu
+    gp = pkg.gen_params(16, 14, 12, ndomains=4)
+    prefix = str(tmp_path / "dualgrid")
+    pkg.write_mesh(gp, prefix, 2)
+    exe = os.path.join(ROOT, "cfd-proxy_amd", "bin", "hybrid.f6.hip")
+    r = subprocess.run([exe, "-lvl", "2", prefix, "--gpus", "2", "--var", "hash"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "*** SUCCESS" in r.stdout and "comm_free:" in r.stdout and "exchange_dbl_xgmi_async:" in r.stdout
+    r = subprocess.run([exe, "-bad"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "Usage" in r.stdout

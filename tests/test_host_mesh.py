@@ -1,0 +1,216 @@
+"""Generator, domain merger and tiler (host C side, CPU only).  The tiler tests restate the
+run-time invariants of the reference's eval.c / thread_comm.c asserts for GPU tiles
+(reference src/eval.c:88-235, src/thread_comm.c:159-205,329-428)."""
+import numpy as np
+import pytest
+
+from conftest import golden_domain, load_golden
+
+
+def global_truth(pkg, orc, gp, var_kind):
+    """gradient of every lattice point from the un-partitioned mesh (numpy statement)"""
+    g1 = pkg.gen_params(gp.nx, gp.ny, gp.nz, ndomains=1, connectivity=gp.connectivity, normals=gp.normals,
+                        volumes=gp.volumes, seed=gp.seed)
+    d = pkg.gen_domain(g1, 0)
+    pkg.fill_var(d, None, var_kind, gp.nx, gp.ny, gp.nz)
+    g = orc.np_gradients(d.fpoint, d.fnormal, d.pvolume, d.var, d.nown)
+    out = (g, d.var.copy(), d.nfaces)
+    d.free()
+    return out
+
+
+@pytest.mark.parametrize("dims,nd,gf", [((9, 8, 7), 2, 0), ((12, 10, 9), 4, 1), ((13, 7, 5), 5, 0), ((16, 12, 10), 12, 0)])
+def test_generator_domains_are_consistent(pkg, orc, dims, nd, gf):
+    gp = pkg.gen_params(*dims, ndomains=nd, ghost_faces=gf)
+    truth, _, nf_global = global_truth(pkg, orc, gp, pkg.VAR_HASH)
+    doms = [pkg.gen_domain(gp, d) for d in range(nd)]
+    gids = [pkg.gen_global_ids(gp, d, doms[d].nall) for d in range(nd)]
+    assert sum(d.nown for d in doms) == dims[0] * dims[1] * dims[2]
+    own_gid = np.concatenate([gids[d][: doms[d].nown] for d in range(nd)])
+    assert len(np.unique(own_gid)) == len(own_gid)  # every lattice point owned exactly once
+    for d, dom in enumerate(doms):
+        fp = dom.fpoint
+        has_own = (fp[:, 0] < dom.nown) | (fp[:, 1] < dom.nown)
+        assert gf or has_own.all()
+        if gf:
+            assert (~has_own).any()  # ghost-ghost faces present when asked for
+        owner, idx = dom.addpoint_owner(), dom.addpoint_id()
+        for j in range(dom.nall - dom.nown):  # ghost j really is point idx of its owner
+            assert gids[owner[j]][idx[j]] == gids[d][dom.nown + j] and idx[j] < doms[owner[j]].nown
+        for k in range(nd):
+            assert dom.cd.sendcount[k] == doms[k].cd.recvcount[d]  # symmetric halo
+            assert dom.cd.recvcount[k] == np.count_nonzero(owner == k)
+        assert d not in dom.partners and sorted(dom.partners) == dom.partners
+        # the domain alone reproduces the global gradient on its owned points
+        pkg.fill_var(dom, gids[d], pkg.VAR_HASH, *dims)
+        g = orc.np_gradients(dom.fpoint, dom.fnormal, dom.pvolume, dom.var, dom.nown)
+        assert np.abs(g[: dom.nown] - truth[gids[d][: dom.nown]]).max() <= 1e-12 * np.abs(truth).max()
+    for dom in doms:
+        dom.free()
+
+
+@pytest.mark.parametrize("dims,nd,G", [((12, 10, 9), 4, 1), ((12, 10, 9), 4, 2), ((16, 12, 10), 12, 3), ((16, 12, 10), 12, 4),
+                                       ((13, 7, 5), 5, 2)])
+def test_merge_domains(pkg, orc, dims, nd, G):
+    gp = pkg.gen_params(*dims, ndomains=nd, ghost_faces=1)
+    truth, _, nf_global = global_truth(pkg, orc, gp, pkg.VAR_HASH)
+    doms = [pkg.gen_domain(gp, d) for d in range(nd)]
+    gids = [pkg.gen_global_ids(gp, d, doms[d].nall) for d in range(nd)]
+    for d in range(nd):
+        pkg.fill_var(doms[d], gids[d], pkg.VAR_HASH, *dims)
+    parts, mgids = [], []
+    for r in range(G):
+        f, c = pkg.rank_domains(r, nd, G)
+        assert all(pkg.host_lib().cfdp_domain_rank(d, nd, G) == r for d in range(f, f + c))
+        part = pkg.merge_domains(doms[f:f + c], list(range(f, f + c)), nd, G, r)
+        mi = part.merge_info.contents
+        gid = np.full(part.nall, -1, np.int64)
+        for dl in range(c):
+            l2m = np.ctypeslib.as_array(mi.local2merged[dl], shape=(doms[f + dl].nall,))
+            assert np.all((gid[l2m] == -1) | (gid[l2m] == gids[f + dl]))  # one merged id per lattice point
+            gid[l2m] = gids[f + dl]
+            part.var[l2m] = doms[f + dl].var
+            assert np.array_equal(part.pvolume[l2m], doms[f + dl].pvolume)
+        assert (gid >= 0).all() and len(np.unique(gid)) == part.nall
+        parts.append(part)
+        mgids.append(gid)
+        # every face with an owned end is present exactly once
+        fp = part.fpoint
+        key = np.sort(np.stack([gid[fp[:, 0]], gid[fp[:, 1]]], 1), axis=1)
+        assert len(np.unique(key, axis=0)) == len(key)
+        assert ((fp[:, 0] < part.nown) | (fp[:, 1] < part.nown)).all()
+        g = orc.np_gradients(part.fpoint, part.fnormal, part.pvolume, part.var, part.nown)
+        assert np.abs(g[: part.nown] - truth[gid[: part.nown]]).max() <= 1e-12 * np.abs(truth).max()
+        if G == 1:
+            assert part.nall == part.nown and part.nfaces == nf_global and part.partners == []
+    pkg.merge_link_group(parts)
+    for r, part in enumerate(parts):
+        for s in part.partners:
+            si, ri = part.sendindex(s), parts[s].recvindex(r)
+            assert len(si) == len(ri) > 0
+            assert np.array_equal(mgids[r][si], mgids[s][ri])  # element j is the same lattice point on both sides
+            assert (si < part.nown).all() and (ri >= parts[s].nown).all()
+            assert np.array_equal(ri, np.arange(ri[0], ri[0] + len(ri)))  # a message is one block of ghost rows
+    # scatter back to file numbering reproduces owner values in ghost rows
+    part = parts[0]
+    f, c = pkg.rank_domains(0, nd, G)
+    field = np.arange(part.nall * 21, dtype=float).reshape(part.nall, 7, 3)
+    for dl in range(c):
+        back = pkg.merge_scatter(part, dl, doms[f + dl].nall, field)
+        l2m = np.ctypeslib.as_array(part.merge_info.contents.local2merged[dl], shape=(doms[f + dl].nall,))
+        assert np.array_equal(back, field[l2m])
+    for p in parts:
+        p.free()
+    for d in doms:
+        d.free()
+
+
+def interpret_plan(plan, var_new, vol_new):
+    """what gg_gradient_kernel computes, tile by tile, in numpy (owned rows only)"""
+    g = np.full((plan.nall, 7, 3), np.nan)
+    for t in range(plan.ntiles):
+        td = plan.tile(t)
+        fn, inc, ioff, halo = plan.tile_arrays(t)
+        ids = np.concatenate([np.arange(td.pstart, td.pstart + td.npts), halo]).astype(np.int64)
+        for li in range(td.npts):
+            ks, ke = int(ioff[li]), int(ioff[li + 1])
+            if ke == ks:
+                continue
+            w = inc[ks:ke].astype(np.int64)
+            nbr, f, neg = w & 0xFFFF, (w >> 16) & 0x7FFF, (w >> 31) & 1
+            val = np.where(neg[:, None] == 1, -0.5, 0.5) * (var_new[td.pstart + li][None, :] + var_new[ids[nbr]])
+            g[td.pstart + li] = (val[:, :, None] * fn[f][:, None, :]).sum(0) / vol_new[td.pstart + li]
+    return g
+
+
+@pytest.mark.parametrize("tile_points", [8, 32, 128, 1024])
+def test_plan_single_partition(pkg, orc, tile_points):
+    gp = pkg.gen_params(11, 9, 8, ndomains=1)
+    dom = pkg.gen_domain(gp, 0)
+    pkg.fill_var(dom, None, pkg.VAR_HASH)
+    plan = pkg.Plan(dom, tile_points=tile_points)
+    n2o, o2n = plan.new2old, plan.old2new
+    assert np.array_equal(np.sort(n2o), np.arange(dom.nall)) and np.array_equal(o2n[n2o], np.arange(dom.nall))
+    deg = np.bincount(dom.fpoint.ravel(), minlength=dom.nall)
+    cover = np.zeros(dom.nown, int)
+    faces_seen = 0
+    for t in range(plan.ntiles):
+        td = plan.tile(t)
+        assert 0 < td.npts <= tile_points and td.npts + td.nhalo <= 65535 and td.nfaces <= 32767
+        cover[td.pstart: td.pstart + td.npts] += 1
+        fn, inc, ioff, halo = plan.tile_arrays(t)
+        assert ioff[0] == 0 and ioff[-1] == td.ninc == len(inc)
+        assert np.array_equal(np.diff(ioff.astype(np.int64)), deg[n2o[td.pstart: td.pstart + td.npts]])
+        assert ((inc & 0xFFFF) < td.npts + td.nhalo).all() and (((inc >> 16) & 0x7FFF) < td.nfaces).all()
+        assert len(np.unique(halo)) == len(halo)
+        assert ((halo < td.pstart) | (halo >= td.pstart + td.npts)).all()
+        # every tile-local face is referenced once (cross-tile) or twice (internal)
+        refs = np.bincount(((inc >> 16) & 0x7FFF).astype(np.int64), minlength=td.nfaces)
+        assert refs.min() >= 1 and refs.max() <= 2
+        faces_seen += td.nfaces
+    assert (cover == 1).all()  # every owned point in exactly one tile (eval.c:126-199 analogue)
+    assert faces_seen == plan.nfaces_dup >= plan.nfaces_used == dom.nfaces
+    g = interpret_plan(plan, dom.var[n2o], dom.pvolume[n2o])
+    back = np.empty_like(g)
+    back[n2o] = g
+    ref = orc.np_gradients(dom.fpoint, dom.fnormal, dom.pvolume, dom.var, dom.nown)
+    assert np.abs(back - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert plan.lds_grad == max((plan.tile(t).blob_qw * 16 + (plan.tile(t).npts + plan.tile(t).nhalo) * 64)
+                                for t in range(plan.ntiles))
+    plan.free()
+    dom.free()
+
+
+def test_plan_with_partners_tiles_send_points_first(pkg, orc):
+    fx = load_golden("g4_12x10x9")
+    doms = [golden_domain(pkg, fx, d) for d in range(4)]
+    pkg.link_raw_group(doms)
+    for d, dom in enumerate(doms):
+        plan = pkg.Plan(dom, tile_points=32)
+        n2o, o2n = plan.new2old, plan.old2new
+        send = dom.send_points()
+        assert len(send) > 0 and plan.nbtiles > 0
+        bnd_end = plan.tile(plan.nbtiles - 1).pstart + plan.tile(plan.nbtiles - 1).npts
+        assert (o2n[send] < bnd_end).all()                       # every sent point is in a boundary tile
+        assert bnd_end == len(send)                              # ... and boundary tiles hold nothing else
+        # ghosts: grouped by partner, message order (zero-copy unpack)
+        pos = dom.nown
+        for s in range(plan.npartners):
+            k = plan.partner[s]
+            ri = dom.recvindex(k)
+            assert np.array_equal(o2n[ri], np.arange(pos, pos + len(ri)))
+            assert plan.recv_off[s] == pos - dom.nown
+            si = dom.sendindex(k)
+            assert np.array_equal(np.array(plan.send_idx[plan.send_off[s]: plan.send_off[s + 1]]), o2n[si])
+            pos += len(ri)
+        assert pos == dom.nall
+        g = interpret_plan(plan, dom.var[n2o], dom.pvolume[n2o])
+        back = np.empty_like(g)
+        back[n2o] = g
+        gold = fx[f"grad_mpi_bulk_sync_t1_d{d}"]
+        assert np.abs(back[: dom.nown] - gold[: dom.nown]).max() <= 1e-12 * np.abs(gold).max()
+        assert np.isnan(back[dom.nown:]).all()  # ghost rows are never written by the kernel
+        plan.free()
+    for dom in doms:
+        dom.free()
+
+
+def test_plan_handles_isolated_points_and_ghost_ghost_faces(pkg, orc):
+    """a point without faces is in no tile list's incidences (the reference leaves it alone);
+    faces between two ghosts are ignored (rangelist.c:513-523)"""
+    fp = np.array([[0, 1], [1, 2], [2, 4], [4, 5], [5, 4]], np.int32)  # point 3 isolated; 4,5 ghosts
+    fn = np.arange(15, dtype=float).reshape(5, 3) + 1
+    vol = np.arange(6, dtype=float) + 1
+    var = np.arange(42, dtype=float).reshape(6, 7) * 0.5 + 1
+    dom = pkg.domain_from_arrays(fp, fn, vol, 4, var=var)
+    plan = pkg.Plan(dom, tile_points=8)
+    assert plan.nfaces_used == 3
+    n2o = plan.new2old
+    g = interpret_plan(plan, var[n2o], vol[n2o])
+    back = np.empty_like(g)
+    back[n2o] = g
+    ref = orc.np_gradients(fp, fn, vol, var, 4)
+    assert np.isnan(back[3]).all()
+    assert np.allclose(back[[0, 1, 2]], ref[[0, 1, 2]], rtol=1e-14)
+    plan.free()
+    dom.free()
