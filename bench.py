@@ -32,6 +32,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
+def usable_cores() -> int:
+    """host cores this process may really use: the cgroup CPU quota if there is one (a GPU box
+    shows every CPU of the host but grants a share), else the affinity mask; CFDP_CPU_THREADS
+    overrides"""
+    if os.environ.get("CFDP_CPU_THREADS"):
+        return max(1, int(os.environ["CFDP_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return min(n, 64)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,7 +197,7 @@ def main() -> None:
         if not args.no_cpu:
             from __graft_entry__ import load_oracle
             orc = load_oracle()
-            cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+            cores = usable_cores()
             ref = orc.CpuRef(part.fpoint, part.fnormal, part.pvolume, part.nown, nthreads=cores)
             samples = sorted(ref.timed(part.var, niter=25, with_flux=True) for _ in range(args.cpu_samples))
             gsamples = sorted(ref.timed(part.var, niter=25, with_flux=False) for _ in range(3))

@@ -203,6 +203,7 @@ def _declare_hip(lib: C.CDLL) -> None:
     for n in ("set_var", "set_grad", "set_flux", "get_grad", "get_flux"):
         getattr(lib, "cfdp_gpu_" + n).argtypes = [vp, P(C.c_double)]
     lib.cfdp_gpu_set_variant.argtypes = [vp, C.c_int, C.c_int]
+    lib.cfdp_gpu_set_pipeline.argtypes = [vp, C.c_int]
     lib.cfdp_gpu_gradients.argtypes = [vp, C.c_int, vp]
     lib.cfdp_gpu_flux.argtypes = [vp, C.c_int, vp]
     lib.cfdp_gpu_pack.argtypes = [vp, vp]
@@ -515,9 +516,10 @@ class Plan:
         td = self.p.tiles[t]
         blob = np.ctypeslib.as_array(self.p.blob, shape=(self.p.blob_bytes,))
         b0 = td.blob_off * 16
-        fnb = (td.nfaces * 24 + 15) & ~15
+        plane = (td.nfaces * 8 + 15) & ~15   # one padded plane per normal component (SoA)
+        fnb = 3 * plane
         incb = (td.ninc * 4 + 15) & ~15
-        fn = blob[b0:b0 + td.nfaces * 24].view(np.float64).reshape(-1, 3)
+        fn = np.stack([blob[b0 + c * plane: b0 + c * plane + td.nfaces * 8].view(np.float64) for c in range(3)], 1)
         inc = blob[b0 + fnb:b0 + fnb + td.ninc * 4].view(np.uint32)
         ioff = blob[b0 + fnb + incb:b0 + fnb + incb + (td.npts + 1) * 4].view(np.uint32)
         halo = np.ctypeslib.as_array(self.p.halo_idx, shape=(max(self.p.nhalo_total, 1),))[
@@ -577,6 +579,9 @@ class GpuPartition:
 
     def set_variant(self, grad_lanes: int, flux_lanes: int = 0) -> None:
         self._ck(self.lib.cfdp_gpu_set_variant(self.h, grad_lanes, flux_lanes))
+
+    def set_pipeline(self, max_wg_per_cu: int) -> None:
+        self._ck(self.lib.cfdp_gpu_set_pipeline(self.h, max_wg_per_cu))
 
     def gradients(self, which: int = TILES_ALL, stream: int = 0) -> None:
         self._ck(self.lib.cfdp_gpu_gradients(self.h, which, C.c_void_p(stream)))

@@ -51,12 +51,136 @@ template <> struct grad_cfg<8> { static constexpr int NE = 1; };
 }  // namespace
 
 // ------------------------------------------------------------------------------ gradient
+// The per-tile arithmetic, shared by the simple and the pipelined kernel.  `buf` is the LDS
+// image of one tile: [nx | ny | nz | incidences | offsets | var rows (own, then halo)].
+// var rows are 8 doubles: 7 variables + the point's dual volume in slot 7.
+//
+// U consecutive incidences of a point are processed as one batch: all U incidence words are
+// read, then all their operands (normal components, neighbour row), then the FMAs -- so a
+// lane pays the LDS round trip once per batch, not twice per incidence (a wave only has its
+// own ~14 dependent steps; measured: the un-batched loop spent ~2/3 of its time parked on
+// lgkmcnt).  The accumulation order stays the file order of the point's faces.
+template <int U, int NE>
+__device__ __forceinline__ void grad_batch(const uint32_t *__restrict__ inc, int k,
+                                           const double *__restrict__ nx, const double *__restrict__ ny,
+                                           const double *__restrict__ nz,
+                                           const double *__restrict__ var_eq0, const double (&vs)[NE],
+                                           double (&acc)[NE][3]) {
+  uint32_t w[U];
+#pragma unroll
+  for (int i = 0; i < U; i++) w[i] = inc[k + i];
+  double n0[U], n1[U], n2[U], vn[U][NE];
+#pragma unroll
+  for (int i = 0; i < U; i++) {
+    const uint32_t f = (w[i] >> 16) & 0x7FFFu;
+    n0[i] = nx[f];
+    n1[i] = ny[f];
+    n2[i] = nz[f];
+    const double *vp = var_eq0 + (w[i] & 0xFFFFu) * 8;
+#pragma unroll
+    for (int j = 0; j < NE; j++) vn[i][j] = vp[j];
+  }
+#pragma unroll
+  for (int i = 0; i < U; i++) {
+    // val = 0.5*(var[p0][eq] + var[p1][eq]) (src/gradients.c:77,99,121); the owned end being
+    // p1 means the contribution is subtracted (:103-105,128-130): folded into the exact
+    // factor +-0.5 (bit 31 of the incidence word is the sign bit of the double)
+    const double sg = __hiloint2double((int)(0x3FE00000u | (w[i] & 0x80000000u)), 0);
+#pragma unroll
+    for (int j = 0; j < NE; j++) {
+      const double val = sg * (vs[j] + vn[i][j]);
+      acc[j][0] += n0[i] * val;
+      acc[j][1] += n1[i] * val;
+      acc[j][2] += n2[i] * val;
+    }
+  }
+}
+
+template <int LPP>
+__device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, const cfdp_tile_desc &td,
+                                                  int tid, double *__restrict__ grad,
+                                                  double *__restrict__ stage, int dbg = 0) {
+  constexpr int NE = grad_cfg<LPP>::NE;
+  constexpr int PPW = 64 / LPP;  // points per wave
+  const int li = tid / LPP, sub = tid % LPP;
+  const bool active = li < td.npts;
+  const int plane = (td.nfaces * 8 + 15) & ~15;
+  const int inc_bytes = (td.ninc * 4 + 15) & ~15;
+  const double *nx = reinterpret_cast<const double *>(buf);
+  const double *ny = reinterpret_cast<const double *>(buf + plane);
+  const double *nz = reinterpret_cast<const double *>(buf + 2 * plane);
+  const uint32_t *inc = reinterpret_cast<const uint32_t *>(buf + 3 * plane);
+  const uint32_t *ioff = reinterpret_cast<const uint32_t *>(buf + 3 * plane + inc_bytes);
+  const double *var_l = reinterpret_cast<const double *>(buf + (size_t)td.blob_qw * 16);
+
+  const int eq0 = sub * NE;
+  double vs[NE], acc[NE][3];
+#pragma unroll
+  for (int j = 0; j < NE; j++) acc[j][0] = acc[j][1] = acc[j][2] = 0.0;
+  int ks = 0, ke0 = 0;
+  double tmp = 0.0;
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < NE; j++) vs[j] = var_l[li * 8 + eq0 + j];
+    ks = (int)ioff[li];
+    ke0 = (int)ioff[li + 1];
+    const int ke = (dbg & 4) ? ks : ke0;  // timing experiment: no arithmetic, stores only
+    const double *var_eq0 = var_l + eq0;
+    int k = ks;
+    for (; k + 4 <= ke; k += 4) grad_batch<4, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
+    if (k + 2 <= ke) {
+      grad_batch<2, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
+      k += 2;
+    }
+    if (k < ke) grad_batch<1, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
+    tmp = 1.0 / var_l[li * 8 + 7];  // 1/pvolume, src/gradients.c:138
+  }
+  // ---- write the finished rows.  A lane holds NE*3 doubles of a 168-byte row; storing them
+  // directly is 8 bytes per lane at a 24..168-byte stride (measured: the stores alone then
+  // take longer than streaming the whole tile in).  Instead each wave transposes its PPW rows
+  // through a private LDS slab and writes them as one contiguous run, 8 bytes per lane x 64
+  // lanes per instruction.  Wave-private slab => no workgroup barrier.
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wp = wave * PPW;                                    // first point of this wave
+  const int nv = td.npts - wp < PPW ? td.npts - wp : PPW;       // its valid points (may be <= 0)
+  // a point without faces is in no colour list: the reference leaves its row alone
+  const bool faceless = active && ke0 == ks;
+  if (__any(faceless)) {  // rare: fall back to per-lane stores that can skip a row
+    if (active && !faceless) {
+      double *g = grad + (size_t)(td.pstart + li) * 21 + eq0 * 3;
+#pragma unroll
+      for (int j = 0; j < NE; j++)
+        if (eq0 + j < 7) {
+          g[3 * j + 0] = acc[j][0] * tmp;
+          g[3 * j + 1] = acc[j][1] * tmp;
+          g[3 * j + 2] = acc[j][2] * tmp;
+        }
+    }
+    return;
+  }
+  double *slab = stage + wave * (PPW * 21);
+  if (active) {
+    double *o = slab + (li - wp) * 21 + eq0 * 3;
+#pragma unroll
+    for (int j = 0; j < NE; j++)
+      if (eq0 + j < 7) {
+        o[3 * j + 0] = acc[j][0] * tmp;
+        o[3 * j + 1] = acc[j][1] * tmp;
+        o[3 * j + 2] = acc[j][2] * tmp;
+      }
+  }
+  __builtin_amdgcn_wave_barrier();  // LDS executes a wave's accesses in order; keep the compiler in order too
+  double *g = grad + (size_t)(td.pstart + wp) * 21;
+  const int nd = nv * 21;
+  for (int c = lane; c < nd; c += 64) g[c] = slab[c];
+}
+
+// Simple form: one workgroup per tile, stage through registers, barrier, compute.
 template <int LPP>
 __global__ __launch_bounds__(1024) void gg_gradient_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
     const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
-    const double *__restrict__ vol /*[nown]*/, double *__restrict__ grad /*[nall][21]*/) {
-  constexpr int NE = grad_cfg<LPP>::NE;
+    double *__restrict__ grad /*[nall][21]*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
@@ -80,51 +204,103 @@ __global__ __launch_bounds__(1024) void gg_gradient_kernel(
     }
   }
   __syncthreads();
+  double *stage = reinterpret_cast<double *>(smem + (size_t)td.blob_qw * 16 + (size_t)(npts + nhalo) * 64);
+  grad_tile_compute<LPP>(smem, td, tid, grad, stage);
+}
 
-  const int li = tid / LPP, sub = tid % LPP;
-  if (li >= npts) return;
-  const int fn_bytes = (td.nfaces * 24 + 15) & ~15;
-  const int inc_bytes = (td.ninc * 4 + 15) & ~15;
-  const double *fn = reinterpret_cast<const double *>(smem);
-  const uint32_t *inc = reinterpret_cast<const uint32_t *>(smem + fn_bytes);
-  const uint32_t *ioff = reinterpret_cast<const uint32_t *>(smem + fn_bytes + inc_bytes);
-  const double *var_l = reinterpret_cast<const double *>(v4);
+// Pipelined form: persistent workgroups walk a contiguous run of tiles with two LDS buffers.
+// While tile i is computed from one buffer, tile i+1 streams into the other by LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, asynchronous), so the HBM
+// stream never stops for the arithmetic.  The halo row numbers of tile i+2 are fetched one
+// iteration ahead into registers, so the gather of tile i+1 can be issued without waiting.
+constexpr int GG_HMAX = 4;  // halo 16-byte pieces per thread the pipelined kernel can hold
 
-  const int eq0 = sub * NE;
-  double vs[NE], acc[NE][3];
+__device__ __forceinline__ void glds16(const uint4 *src, unsigned char *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void pipe_issue_tile(unsigned char *buf, const cfdp_tile_desc &td,
+                                                const uint4 *__restrict__ blob,
+                                                const uint4 *__restrict__ gv4, const int (&hrow)[GG_HMAX],
+                                                int tid, int nthr) {
+  const int lane = tid & 63, w0 = tid & ~63;  // first thread of this wave
+  // region 1: the tile blob; region 2: own var rows -- both contiguous in HBM
+  const uint4 *b4 = blob + td.blob_off;
+  for (int q0 = w0; q0 < td.blob_qw; q0 += nthr)
+    if (q0 + lane < td.blob_qw) glds16(b4 + q0 + lane, buf + (size_t)q0 * 16);
+  unsigned char *vbuf = buf + (size_t)td.blob_qw * 16;
+  const uint4 *own = gv4 + (size_t)td.pstart * 4;
+  const int nown4 = td.npts * 4, nhalo4 = td.nhalo * 4;
+  for (int q0 = w0; q0 < nown4; q0 += nthr)
+    if (q0 + lane < nown4) glds16(own + q0 + lane, vbuf + (size_t)q0 * 16);
+  // region 3: halo var rows, gathered by row number (4 lanes per 64-byte row)
+  unsigned char *hbuf = vbuf + (size_t)nown4 * 16;
 #pragma unroll
-  for (int j = 0; j < NE; j++) {
-    vs[j] = var_l[li * 8 + eq0 + j];
-    acc[j][0] = acc[j][1] = acc[j][2] = 0.0;
+  for (int k = 0; k < GG_HMAX; k++) {
+    const int q0 = w0 + k * nthr;
+    if (q0 < nhalo4 && q0 + lane < nhalo4)
+      glds16(gv4 + (size_t)hrow[k] * 4 + (lane & 3), hbuf + (size_t)q0 * 16);
   }
-  const int ks = (int)ioff[li], ke = (int)ioff[li + 1];
-  for (int k = ks; k < ke; k++) {
-    const uint32_t w = inc[k];
-    const int nbr = (int)(w & 0xFFFFu), f = (int)((w >> 16) & 0x7FFFu);
-    const double sg = (w >> 31) ? -0.5 : 0.5;  // owned end is p1: contribution is subtracted
-    const double anx = fn[3 * f + 0], any = fn[3 * f + 1], anz = fn[3 * f + 2];
-    const double *vn = var_l + nbr * 8 + eq0;
+}
+
+__device__ __forceinline__ void pipe_load_hrows(int (&hrow)[GG_HMAX], const cfdp_tile_desc &td,
+                                                const int *__restrict__ halo_idx, int tid, int nthr) {
+  const int *hid = halo_idx + td.halo_off;
 #pragma unroll
-    for (int j = 0; j < NE; j++) {
-      // val = 0.5*(var[p0][eq] + var[p1][eq])  (src/gradients.c:77,99,121); the sign of
-      // the p1 side is folded into the exact factor +-0.5
-      const double val = sg * (vs[j] + vn[j]);
-      acc[j][0] += anx * val;
-      acc[j][1] += any * val;
-      acc[j][2] += anz * val;
-    }
+  for (int k = 0; k < GG_HMAX; k++) {
+    const int q = tid + k * nthr;
+    hrow[k] = q < td.nhalo * 4 ? hid[q >> 2] : 0;
   }
-  if (ke > ks) {  // a point without faces is in no colour list: the reference leaves it alone
-    const double tmp = 1.0 / vol[td.pstart + li];  // src/gradients.c:138
-    double *g = grad + (size_t)(td.pstart + li) * 21 + eq0 * 3;
-#pragma unroll
-    for (int j = 0; j < NE; j++) {
-      if (eq0 + j < 7) {
-        g[3 * j + 0] = acc[j][0] * tmp;
-        g[3 * j + 1] = acc[j][1] * tmp;
-        g[3 * j + 2] = acc[j][2] * tmp;
-      }
+}
+
+template <int LPP>
+__global__ __launch_bounds__(1024) void gg_gradient_pipe_kernel(
+    const cfdp_tile_desc *__restrict__ tiles, int tile_begin, int ntiles,
+    const uint4 *__restrict__ blob, const int *__restrict__ halo_idx,
+    const double *__restrict__ var /*[nall][8]*/, double *__restrict__ grad /*[nall][21]*/,
+    int buf_bytes, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
+
+  // contiguous tile run of this workgroup; workgroups b, b+8, ... share an XCD and own
+  // neighbouring runs (their halo rows and duplicated faces meet in that XCD's L2)
+  const int b = blockIdx.x, nwg = gridDim.x, x = b & 7, j = b >> 3;
+  const int nwx = (nwg - x + 7) >> 3;
+  const long xt0 = (long)ntiles * x / 8, xt1 = (long)ntiles * (x + 1) / 8;
+  int t = tile_begin + (int)(xt0 + (xt1 - xt0) * j / nwx);
+  const int tend = tile_begin + (int)(xt0 + (xt1 - xt0) * (j + 1) / nwx);
+  if (t >= tend) return;
+
+  int hrow[GG_HMAX];
+  cfdp_tile_desc td = tiles[t];
+  pipe_load_hrows(hrow, td, halo_idx, tid, nthr);
+  pipe_issue_tile(smem, td, blob, gv4, hrow, tid, nthr);
+  cfdp_tile_desc tn = td;
+  if (t + 1 < tend) {
+    tn = tiles[t + 1];
+    pipe_load_hrows(hrow, tn, halo_idx, tid, nthr);
+  }
+  __syncthreads();  // drains this wave's DMA (vmcnt(0)) and publishes everybody's
+  int cur = 0;
+  const cfdp_tile_desc td0 = td;
+  double *stage = reinterpret_cast<double *>(smem + 2 * (size_t)buf_bytes);
+  for (; t < tend; ++t) {
+    unsigned char *bcur = smem + (size_t)cur * buf_bytes;
+    unsigned char *bnxt = smem + (size_t)(cur ^ 1) * buf_bytes;
+    if (t + 1 < tend && !(dbg & 2)) pipe_issue_tile(bnxt, tn, blob, gv4, hrow, tid, nthr);
+    cfdp_tile_desc tnn = tn;
+    if (t + 2 < tend) {
+      tnn = tiles[t + 2];
+      pipe_load_hrows(hrow, tnn, halo_idx, tid, nthr);  // used one iteration from now
     }
+    if (dbg & 2) grad_tile_compute<LPP>(smem, td0, tid, grad, stage, dbg);  // timing experiment: buffer 0 only
+    else if (!(dbg & 1)) grad_tile_compute<LPP>(bcur, td, tid, grad, stage, dbg);
+    __syncthreads();  // (a) everyone is done reading bcur, (b) tile t+1 has landed in bnxt
+    td = tn;
+    tn = tnn;
+    cur ^= 1;
   }
 }
 
@@ -157,11 +333,13 @@ __global__ __launch_bounds__(1024) void gg_flux_kernel(
 
   const int li = tid / LPP, sub = tid % LPP;
   const bool active = li < npts;
-  const int fn_bytes = (td.nfaces * 24 + 15) & ~15;
+  const int plane = (td.nfaces * 8 + 15) & ~15;
   const int inc_bytes = (td.ninc * 4 + 15) & ~15;
-  const double *fn = reinterpret_cast<const double *>(smem);
-  const uint32_t *inc = reinterpret_cast<const uint32_t *>(smem + fn_bytes);
-  const uint32_t *ioff = reinterpret_cast<const uint32_t *>(smem + fn_bytes + inc_bytes);
+  const double *fnx = reinterpret_cast<const double *>(smem);
+  const double *fny = reinterpret_cast<const double *>(smem + plane);
+  const double *fnz = reinterpret_cast<const double *>(smem + 2 * plane);
+  const uint32_t *inc = reinterpret_cast<const uint32_t *>(smem + 3 * plane);
+  const uint32_t *ioff = reinterpret_cast<const uint32_t *>(smem + 3 * plane + inc_bytes);
 
   double f0 = 0.0, f1 = 0.0, f2 = 0.0;
   int ks = 0, ke = 0;
@@ -181,7 +359,7 @@ __global__ __launch_bounds__(1024) void gg_flux_kernel(
         const bool nbr_ghost = nbr >= npts && hid[nbr - npts] >= nown;
         if (!nbr_ghost) continue;
       }
-      const double nx = fn[3 * f + 0], ny = fn[3 * f + 1], nz = fn[3 * f + 2];
+      const double nx = fnx[f], ny = fny[f], nz = fnz[f];
       const double *gn = g_l + nbr * 10;
       const double dvx_dx = 0.5 * (gs[0] + gn[0]), dvx_dy = 0.5 * (gs[1] + gn[1]),
                    dvx_dz = 0.5 * (gs[2] + gn[2]);
@@ -235,15 +413,43 @@ __global__ __launch_bounds__(256) void gg_unpack_kernel(const double *__restrict
 }
 
 // ------------------------------------------------------------------------------ launchers
+int gg_debug_flags = 0;  // timing experiments only: 1 = skip arithmetic, 2 = skip tile streaming
+
 #define LAUNCH_GRAD(L)                                                                         \
-  hipLaunchKernelGGL((gg_gradient_kernel<L>), dim3(ntiles), dim3(block), lds, stream, a.tiles, \
-                     tile_begin, a.blob, a.halo_idx, a.var, a.vol, a.grad)
+  hipLaunchKernelGGL((gg_gradient_kernel<L>), dim3(ntiles), dim3(block), lds + stage_bytes,   \
+                     stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad)
+#define LAUNCH_GRAD_PIPE(L)                                                                    \
+  hipLaunchKernelGGL((gg_gradient_pipe_kernel<L>), dim3(nwg), dim3(block),                     \
+                     2 * buf + stage_bytes, stream,                                            \
+                     a.tiles, tile_begin, ntiles, a.blob, a.halo_idx, a.var, a.grad, (int)buf, gg_debug_flags)
 
 hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int ntiles,
-                              int tile_points, size_t lds, hipStream_t stream) {
+                              int tile_points, size_t lds, int max_halo, int pipeline,
+                              hipStream_t stream) {
   if (ntiles <= 0) return hipSuccess;
   const int block = ((tile_points * lanes + 63) / 64) * 64;
   if (block > 1024) return hipErrorInvalidConfiguration;
+  const size_t buf = (lds + 15) & ~(size_t)15;
+  lds = buf;
+  const size_t stage_bytes = (size_t)(block / lanes) * 21 * 8;  // one 168-byte row per point slot
+  if (pipeline && 2 * buf + stage_bytes <= 160 * 1024 && (long)max_halo * 4 <= (long)GG_HMAX * block) {
+    // persistent grid: as many workgroups per CU as LDS (two buffers each) and waves allow
+    int per_cu = (int)((160 * 1024) / (2 * buf + stage_bytes));
+    const int by_waves = 2048 / block;
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu > pipeline) per_cu = pipeline;
+    if (per_cu < 1) per_cu = 1;
+    int nwg = 256 * per_cu;
+    if (nwg > ntiles) nwg = ntiles;
+    switch (lanes) {
+      case 1: LAUNCH_GRAD_PIPE(1); break;
+      case 2: LAUNCH_GRAD_PIPE(2); break;
+      case 4: LAUNCH_GRAD_PIPE(4); break;
+      case 8: LAUNCH_GRAD_PIPE(8); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (lanes) {
     case 1: LAUNCH_GRAD(1); break;
     case 2: LAUNCH_GRAD(2); break;
@@ -306,13 +512,18 @@ hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, int nown, double *
 hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
   hipError_t e = hipSuccess;
 #define SET_LDS(K, B)                                                                          \
-  if (e == hipSuccess && (B) > 65536)                                                          \
+  if (e == hipSuccess && (B) > 65536 && (B) <= 163840)                                                        \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K),                                \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B));
-  SET_LDS(gg_gradient_kernel<1>, lds_grad)
-  SET_LDS(gg_gradient_kernel<2>, lds_grad)
-  SET_LDS(gg_gradient_kernel<4>, lds_grad)
-  SET_LDS(gg_gradient_kernel<8>, lds_grad)
+  const size_t all = 160 * 1024;  // per-launch sizes are checked by the launchers
+  SET_LDS(gg_gradient_kernel<1>, all)
+  SET_LDS(gg_gradient_kernel<2>, all)
+  SET_LDS(gg_gradient_kernel<4>, all)
+  SET_LDS(gg_gradient_kernel<8>, all)
+  SET_LDS(gg_gradient_pipe_kernel<1>, all)
+  SET_LDS(gg_gradient_pipe_kernel<2>, all)
+  SET_LDS(gg_gradient_pipe_kernel<4>, all)
+  SET_LDS(gg_gradient_pipe_kernel<8>, all)
   SET_LDS((gg_flux_kernel<1, false>), lds_flux)
   SET_LDS((gg_flux_kernel<2, false>), lds_flux)
   SET_LDS((gg_flux_kernel<4, false>), lds_flux)

@@ -45,18 +45,21 @@ struct cfdp_gpu {
   cfdp_tile_desc *d_tiles = nullptr;
   uint4 *d_blob = nullptr;
   int *d_halo = nullptr, *d_sendidx = nullptr;
-  double *d_var = nullptr, *d_vol = nullptr, *d_grad = nullptr, *d_flux = nullptr,
+  double *d_var = nullptr, *d_grad = nullptr, *d_flux = nullptr,
          *d_sendbuf = nullptr;
   bool own_grad = true, own_sendbuf = true;
   std::vector<int> new2old, partner, send_off, recv_off;
-  int grad_lanes = 4, flux_lanes = 4;
+  std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
+  int max_halo[2] = {0, 0};
+  int pipeline = -1;           // -1: auto; 0: one workgroup per tile; k: persistent LDS-DMA kernel, <= k WG/CU
+  int grad_lanes = 8, flux_lanes = 8;
   bool pending_exchange = false;
   hipGraphExec_t graph = nullptr;
   int graph_iters = 0, graph_flux = -1, graph_mode = -1, graph_gl = 0, graph_fl = 0;
 
   gg_args args() const {
     gg_args a;
-    a.tiles = d_tiles; a.blob = d_blob; a.halo_idx = d_halo; a.var = d_var; a.vol = d_vol;
+    a.tiles = d_tiles; a.blob = d_blob; a.halo_idx = d_halo; a.var = d_var;
     a.grad = d_grad; a.flux = d_flux; a.nown = nown;
     return a;
   }
@@ -81,6 +84,8 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
   HIP_TRY(hipSetDevice(device));
   cfdp_gpu *g = new cfdp_gpu();
   g->device = device;
+  if (const char *e = getenv("CFDP_PIPELINE")) g->pipeline = atoi(e);
+  if (const char *e = getenv("CFDP_DEBUG_ABLATE")) gg_debug_flags = atoi(e);
   HIP_TRY(hipStreamCreateWithFlags(&g->s_main, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&g->s_comm, hipStreamNonBlocking));
   HIP_TRY(hipEventCreate(&g->ev_a));
@@ -93,26 +98,26 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
 }
 
 static void free_device(cfdp_gpu *g) {
-  if (g->graph) { hipGraphExecDestroy(g->graph); g->graph = nullptr; }
-  hipFree(g->d_tiles); hipFree(g->d_blob); hipFree(g->d_halo); hipFree(g->d_sendidx);
-  hipFree(g->d_var); hipFree(g->d_vol); hipFree(g->d_flux);
-  if (g->own_grad) hipFree(g->d_grad);
-  if (g->own_sendbuf) hipFree(g->d_sendbuf);
+  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  (void)hipFree(g->d_tiles); (void)hipFree(g->d_blob); (void)hipFree(g->d_halo); (void)hipFree(g->d_sendidx);
+  (void)hipFree(g->d_var); (void)hipFree(g->d_flux);
+  if (g->own_grad) (void)hipFree(g->d_grad);
+  if (g->own_sendbuf) (void)hipFree(g->d_sendbuf);
   g->d_tiles = nullptr; g->d_blob = nullptr; g->d_halo = g->d_sendidx = nullptr;
-  g->d_var = g->d_vol = g->d_grad = g->d_flux = g->d_sendbuf = nullptr;
+  g->d_var = g->d_grad = g->d_flux = g->d_sendbuf = nullptr;
   g->own_grad = g->own_sendbuf = true;
   g->uploaded = false;
 }
 
 void cfdp_gpu_destroy(cfdp_gpu *g) {
   if (!g) return;
-  hipSetDevice(g->device);
-  hipDeviceSynchronize();
+  (void)hipSetDevice(g->device);
+  (void)hipDeviceSynchronize();
   free_device(g);
-  if (g->s_main) hipStreamDestroy(g->s_main);
-  if (g->s_comm) hipStreamDestroy(g->s_comm);
+  if (g->s_main) (void)hipStreamDestroy(g->s_main);
+  if (g->s_comm) (void)hipStreamDestroy(g->s_comm);
   for (hipEvent_t e : {g->ev_a, g->ev_b, g->ev_pack, g->ev_senddone, g->ev_fluxdone})
-    if (e) hipEventDestroy(e);
+    if (e) (void)hipEventDestroy(e);
   delete g;
 }
 
@@ -122,9 +127,11 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   if (g->uploaded) free_device(g);
   g->nown = p->nown; g->nall = p->nall; g->ntiles = p->ntiles; g->nbtiles = p->nbtiles;
   g->tp[0] = g->tp[1] = 0;
+  g->max_halo[0] = g->max_halo[1] = 0;
   for (int t = 0; t < p->ntiles; t++) {
     int c = t < p->nbtiles ? 0 : 1;
     if (p->tiles[t].npts > g->tp[c]) g->tp[c] = p->tiles[t].npts;
+    if (p->tiles[t].nhalo > g->max_halo[c]) g->max_halo[c] = p->tiles[t].nhalo;
   }
   for (int c = 0; c < 2; c++) {
     g->lds_grad[c] = (size_t)p->lds_grad_cls[c];
@@ -146,7 +153,6 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   HIP_TRY(hipMalloc(&g->d_blob, (size_t)p->blob_bytes + 16));
   HIP_TRY(hipMalloc(&g->d_halo, sizeof(int) * (size_t)(p->nhalo_total + 1)));
   HIP_TRY(hipMalloc(&g->d_var, sizeof(double) * 8 * (size_t)p->nall));
-  HIP_TRY(hipMalloc(&g->d_vol, sizeof(double) * (size_t)p->nown));
   HIP_TRY(hipMalloc(&g->d_grad, sizeof(double) * 21 * (size_t)p->nall));
   HIP_TRY(hipMalloc(&g->d_flux, sizeof(double) * 3 * (size_t)p->nown));
   HIP_TRY(hipMalloc(&g->d_sendidx, sizeof(int) * (nsend + 1)));
@@ -156,7 +162,7 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   HIP_TRY(hipMemcpy(g->d_blob, p->blob, (size_t)p->blob_bytes, hipMemcpyHostToDevice));
   if (p->nhalo_total)
     HIP_TRY(hipMemcpy(g->d_halo, p->halo_idx, sizeof(int) * (size_t)p->nhalo_total, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(g->d_vol, p->vol, sizeof(double) * (size_t)p->nown, hipMemcpyHostToDevice));
+  g->vol.assign(p->vol, p->vol + p->nown);
   if (nsend)
     HIP_TRY(hipMemcpy(g->d_sendidx, p->send_idx, sizeof(int) * nsend, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(g->d_var, 0, sizeof(double) * 8 * (size_t)p->nall));
@@ -178,10 +184,10 @@ int cfdp_gpu_bind_grad(cfdp_gpu *g, void *dev_grad) {
   if (!dev_grad) return fail("null device pointer");
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(dev_grad, g->d_grad, sizeof(double) * 21 * (size_t)g->nall, hipMemcpyDeviceToDevice));
-  if (g->own_grad) hipFree(g->d_grad);
+  if (g->own_grad) (void)hipFree(g->d_grad);
   g->d_grad = static_cast<double *>(dev_grad);
   g->own_grad = false;
-  if (g->graph) { hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
   return 0;
 }
 
@@ -189,7 +195,7 @@ int cfdp_gpu_bind_sendbuf(cfdp_gpu *g, void *dev_sendbuf) {
   NEED_UPLOAD(g);
   if (!dev_sendbuf) return fail("null device pointer");
   HIP_TRY(hipDeviceSynchronize());
-  if (g->own_sendbuf) hipFree(g->d_sendbuf);
+  if (g->own_sendbuf) (void)hipFree(g->d_sendbuf);
   g->d_sendbuf = static_cast<double *>(dev_sendbuf);
   g->own_sendbuf = false;
   return 0;
@@ -200,6 +206,7 @@ int cfdp_gpu_set_var(cfdp_gpu *g, const double *var) {
   std::vector<double> tmp((size_t)g->nall * 8, 0.0);
   for (int i = 0; i < g->nall; i++)
     memcpy(&tmp[(size_t)i * 8], var + (size_t)g->new2old[i] * 7, 7 * sizeof(double));
+  for (int i = 0; i < g->nown; i++) tmp[(size_t)i * 8 + 7] = g->vol[i];  // pvolume rides in the row's pad
   HIP_TRY(hipMemcpy(g->d_var, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
@@ -242,24 +249,40 @@ int cfdp_gpu_get_flux(cfdp_gpu *g, double *flux) {
   return 0;
 }
 
+int cfdp_gpu_set_pipeline(cfdp_gpu *g, int max_wg_per_cu) {
+  if (!g) return fail("null context");
+  if (max_wg_per_cu < -1 || max_wg_per_cu > 16) return fail("pipeline depth must be in [-1,16]");
+  g->pipeline = max_wg_per_cu;
+  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  return 0;
+}
+
 int cfdp_gpu_set_variant(cfdp_gpu *g, int grad_lanes, int flux_lanes) {
   if (!g) return fail("null context");
   auto ok = [](int l) { return l == 1 || l == 2 || l == 4 || l == 8; };
-  if (grad_lanes == 0) grad_lanes = 4;
-  if (flux_lanes == 0) flux_lanes = 4;
+  if (grad_lanes == 0) grad_lanes = 8;
+  if (flux_lanes == 0) flux_lanes = 8;
   if (!ok(grad_lanes) || !ok(flux_lanes)) return fail("lanes per point must be 1, 2, 4 or 8");
   g->grad_lanes = grad_lanes;
   g->flux_lanes = flux_lanes;
   return 0;
 }
 
+// auto: the persistent LDS-DMA kernel pays off once a CU walks a long run of tiles (its
+// prologue/epilogue are not overlapped); short launches use one workgroup per tile
+static int pipe_for(const cfdp_gpu *g, int ntiles) {
+  if (g->pipeline >= 0) return g->pipeline;
+  return ntiles >= 24 * 256 ? 2 : 0;
+}
+
 static int launch_grad(cfdp_gpu *g, int which, hipStream_t st) {
   const gg_args a = g->args();
   if (which == CFDP_TILES_ALL || which == CFDP_TILES_BOUNDARY)
-    HIP_TRY(gg_launch_gradient(a, g->grad_lanes, 0, g->nbtiles, g->tp[0], g->lds_grad[0], st));
+    HIP_TRY(gg_launch_gradient(a, g->grad_lanes, 0, g->nbtiles, g->tp[0], g->lds_grad[0], g->max_halo[0],
+                               pipe_for(g, g->nbtiles), st));
   if (which == CFDP_TILES_ALL || which == CFDP_TILES_INTERIOR)
     HIP_TRY(gg_launch_gradient(a, g->grad_lanes, g->nbtiles, g->ntiles - g->nbtiles, g->tp[1],
-                               g->lds_grad[1], st));
+                               g->lds_grad[1], g->max_halo[1], pipe_for(g, g->ntiles - g->nbtiles), st));
   return 0;
 }
 
@@ -434,7 +457,7 @@ int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode
     const bool stale = !g->graph || g->graph_flux != with_flux || g->graph_mode != flux_mode ||
                        g->graph_gl != g->grad_lanes || g->graph_fl != g->flux_lanes;
     if (stale) {
-      if (g->graph) { hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+      if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
       hipGraph_t gr = nullptr;
       HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
       int rc = 0;
@@ -443,7 +466,7 @@ int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode
         if (!rc && with_flux) rc = launch_flux(g, flux_mode, st);
       }
       hipError_t ec = hipStreamEndCapture(st, &gr);
-      if (rc) { if (gr) hipGraphDestroy(gr); return 1; }
+      if (rc) { if (gr) (void)hipGraphDestroy(gr); return 1; }
       HIP_TRY(ec);
       HIP_TRY(hipGraphInstantiate(&g->graph, gr, nullptr, nullptr, 0));
       HIP_TRY(hipGraphDestroy(gr));

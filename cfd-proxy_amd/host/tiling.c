@@ -29,7 +29,7 @@
 #include <string.h>
 
 void cfdp_plan_default_opts(cfdp_plan_opts *o) {
-  o->tile_points = 128;
+  o->tile_points = 64;
   o->boundary_first = 1;
 }
 
@@ -294,6 +294,7 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
     unsigned char *bp = bb_reserve(&blob, (size_t)(b_fn + b_inc + b_off));
     int *hp = bb_reserve(&halo, (size_t)H * 4);
     double *fn = (double *)bp;
+    const long plane = cfdp_blob_plane_bytes(E) / 8; /* doubles per normal-component plane */
     uint32_t *inc = (uint32_t *)(bp + b_fn);
     uint32_t *ioff = (uint32_t *)(bp + b_fn + b_inc);
     /* fill: faces were numbered in first-touch order above; re-walk identically */
@@ -308,9 +309,9 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
         int in_tile = q < nown && T.tile_of[q] == t;
         int lf = fval[f];
         /* an internal face is listed by both ends; the normal is stored once */
-        fn[3 * lf + 0] = sd->fnormal[f][0];
-        fn[3 * lf + 1] = sd->fnormal[f][1];
-        fn[3 * lf + 2] = sd->fnormal[f][2];
+        fn[lf] = sd->fnormal[f][0];
+        fn[plane + lf] = sd->fnormal[f][1];
+        fn[2 * plane + lf] = sd->fnormal[f][2];
         unsigned nbr;
         if (in_tile) nbr = (unsigned)(P->old2new[q] - ts);
         else { nbr = (unsigned)(np + hval[q]); hp[hval[q]] = P->old2new[q]; }

@@ -18,8 +18,9 @@
  *   cfdp_gpu_pack             <- exchange_dbl_copy_in[_local]()        src/threads.c:791-813,842-854
  *   cfdp_gpu_unpack           <- exchange_dbl_copy_out[_local]()       src/threads.c:816-839,857-869
  *   cfdp_gpu_send_ptr/recv_ptr<- cd->sendbuf[i] / cd->recvbuf[i]       src/exchange_data_mpi.c:27-76
- *   cfdp_gpu_exchange_peer    <- exchange_dbl_mpi_bulk_sync / _async, exchange_dbl_gaspi_*
- *                                (in-process ranks, peer copies over xGMI)
+ *   cfdp_gpu_rank_gradients / <- exchange_dbl_mpi_bulk_sync / _async, exchange_dbl_gaspi_*
+ *   cfdp_gpu_rank_flux           (in-process ranks, peer copies over xGMI; the write +
+ *                                notify pattern of src/exchange_data_gaspi.c:105-151)
  *                                                                      src/exchange_data_mpi.c:199-543
  */
 #ifndef CFDPROXY_HIP_H
@@ -70,6 +71,10 @@ int  cfdp_gpu_get_flux(cfdp_gpu *g, double *psd_flux);
 
 /* launches (asynchronous) */
 int  cfdp_gpu_set_variant(cfdp_gpu *g, int grad_lanes, int flux_lanes);
+/* gradient kernel form.  -1: choose by launch size (default); 0: one workgroup per tile,
+ * staged through registers; k > 0: persistent workgroups (<= k per CU) with two LDS
+ * buffers, the next tile streaming in by LDS-DMA while the current one is computed       */
+int  cfdp_gpu_set_pipeline(cfdp_gpu *g, int max_wg_per_cu);
 int  cfdp_gpu_gradients(cfdp_gpu *g, int which_tiles, void *stream);
 int  cfdp_gpu_flux(cfdp_gpu *g, int mode, void *stream);
 int  cfdp_gpu_pack(cfdp_gpu *g, void *stream);   /* grad rows of send points -> send arena */

@@ -137,8 +137,10 @@ typedef struct cfdp_plan {
 void cfdp_plan_default_opts(cfdp_plan_opts *o);
 cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *o);
 void cfdp_plan_free(cfdp_plan *p);
-/* layout of a tile blob: byte offsets of its three sections */
-static inline long cfdp_blob_fn_bytes(int nfaces) { return ((long)nfaces * 24 + 15) & ~15L; }
+/* layout of a tile blob: [nx[E] | ny[E] | nz[E]] (one 16-byte padded plane per normal component),
+ * then the incidence words, then the per-point offsets */
+static inline long cfdp_blob_plane_bytes(int nfaces) { return ((long)nfaces * 8 + 15) & ~15L; }
+static inline long cfdp_blob_fn_bytes(int nfaces) { return 3 * cfdp_blob_plane_bytes(nfaces); }
 static inline long cfdp_blob_inc_bytes(int ninc) { return ((long)ninc * 4 + 15) & ~15L; }
 static inline long cfdp_blob_off_bytes(int npts) { return ((long)(npts + 1) * 4 + 15) & ~15L; }
 /* algorithmic bytes of one gradient / flux pass */

@@ -8,7 +8,7 @@ m = load_package(); orc = load_oracle()
 out = open(os.environ.get("EXPLORE_OUT", "gpurun_out/explore.log"), "a")
 def log(*a):
     s = " ".join(str(x) for x in a); print(s, flush=True); out.write(s + "\n"); out.flush()
-smoke()
+if not os.environ.get("CFDP_DEBUG_ABLATE"): smoke()
 sizes = [int(x) for x in os.environ.get("SIZES", "64,128").split(",")]
 tps = [int(x) for x in os.environ.get("TPS", "64,128,256").split(",")]
 lanes = [int(x) for x in os.environ.get("LANES", "1,2,4,8").split(",")]
@@ -31,15 +31,18 @@ for n in sizes:
                 log("n", n, "tp", tp, "L", L, "FAILED", e); continue
             t_up = time.time() - t0
             iters = 50 if n <= 64 else 20
-            mg, mf = part.time_kernels(iters)
-            mg, mf = part.time_kernels(iters)
-            err = ""
-            if n <= 64:
-                part.gradients(); part.flux(); part.pull_fields()
-                e1 = np.abs(dom.grad - g_ref).max() / np.abs(g_ref).max()
-                e2 = np.abs(dom.psd_flux - f_ref).max() / np.abs(f_ref).max()
-                err = "relerr grad %.2e flux %.2e" % (e1, e2)
-            log("n", n, "tp", tp, "L", L, "grad %.1f us %.0f GB/s (%.1f%% of 8TB/s)" % (mg * 1e3, bg / mg / 1e6, bg / mg / 1e6 / 80),
-                "flux %.1f us %.0f GB/s" % (mf * 1e3, bf / mf / 1e6), "lds", part.stats["lds_grad"], "setup %.1fs" % t_up, err)
+            for pipe in [int(x) for x in os.environ.get("PIPES", "0,1,2,4").split(",")]:
+                part.set_pipeline(pipe)
+                mg, mf = part.time_kernels(iters)
+                mg, mf = part.time_kernels(iters)
+                err = ""
+                if n <= 64:
+                    dom.grad[:] = 7.0; part.push_fields()
+                    part.gradients(); part.flux(); part.pull_fields()
+                    e1 = np.abs(dom.grad - g_ref).max() / np.abs(g_ref).max()
+                    e2 = np.abs(dom.psd_flux - f_ref).max() / np.abs(f_ref).max()
+                    err = "relerr grad %.2e flux %.2e" % (e1, e2)
+                log("n", n, "tp", tp, "L", L, "pipe", pipe, "grad %.1f us %.0f GB/s (%.1f%% of 8TB/s)" % (mg * 1e3, bg / mg / 1e6, bg / mg / 1e6 / 80),
+                    "flux %.1f us %.0f GB/s" % (mf * 1e3, bf / mf / 1e6), "lds", part.stats["lds_grad"], err)
             part.close()
     dom.free()
