@@ -25,3 +25,30 @@ def test_bench_line(gpu):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert out["cpu_baseline"]["kind"] in ("port", "reference") and out["cpu_baseline"]["cores"] >= 1
     assert out["value"] > 0 and out["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_staged_transport(gpu):
+    """the N>1 code path of bench.py (mesh partitioning across ranks, request exchange, overlapped
+    halo exchange, overlap report) with 2 ranks sharing this GPU and the host-staged transport"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
+                                       "--warmup", "3", "--transport", "staged", "--no-files"], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-1500:] + se[-1500:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["points_per_gpu"] == 262144
+    assert out["config"]["ghost_points_per_gpu"] > 0 and "overlap" in out
+    assert 0 < out["overlap"]["efficiency_async"] <= 1.5
+    assert "cpu_baseline" not in out

@@ -23,10 +23,10 @@ for n in sizes:
         g_ref = r.gradients(var); f_ref = r.flux(g_ref, 0); r.close()
     for tp in tps:
         for L in lanes:
-            if tp * L > 1024: continue
+            if tp * abs(L) > 1024: continue
             t0 = time.time()
             try:
-                part = m.GpuPartition(dom, tile_points=tp, grad_lanes=L, flux_lanes=min(L, 8))
+                part = m.GpuPartition(dom, tile_points=tp, grad_lanes=L, flux_lanes=8)
             except Exception as e:
                 log("n", n, "tp", tp, "L", L, "FAILED", e); continue
             t_up = time.time() - t0
