@@ -114,7 +114,7 @@ class TileDesc(C.Structure):
 
 
 class PlanOpts(C.Structure):
-    _fields_ = [("tile_points", C.c_int), ("boundary_first", C.c_int)]
+    _fields_ = [("tile_points", C.c_int), ("boundary_first", C.c_int), ("supertile", C.c_int)]
 
 
 class PlanStruct(C.Structure):

@@ -42,6 +42,27 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {
   return x * base + (x < rem ? x : rem) + i;
 }
 
+// non-temporal 16-byte load: for data that is streamed exactly once per launch
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_nt(const uint4 *p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// NT = the launch streams more than the Infinity Cache holds: blobs are read and rows written
+// with the non-temporal policy so that they do not evict the var / grad rows that neighbouring
+// tiles re-read as halo rows (measured on 128^3: -8 % kernel time).  For cache-resident meshes
+// (64^3: everything stays in the 256 MiB Infinity Cache across iterations) the default policy
+// is faster (+20 % with nt), so the host picks per launch.
+template <bool NT> __device__ __forceinline__ uint4 ld_blob(const uint4 *p) {
+  if constexpr (NT) return ld_nt(p);
+  else return *p;
+}
+template <bool NT> __device__ __forceinline__ void st_row(double v, double *p) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 template <int LPP> struct grad_cfg;
 template <> struct grad_cfg<1> { static constexpr int NE = 7; };
 template <> struct grad_cfg<2> { static constexpr int NE = 4; };
@@ -96,7 +117,7 @@ __device__ __forceinline__ void grad_batch(const uint32_t *__restrict__ inc, int
   }
 }
 
-template <int LPP>
+template <int LPP, bool NT>
 __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, const cfdp_tile_desc &td,
                                                   int tid, double *__restrict__ grad,
                                                   double *__restrict__ stage, int dbg = 0) {
@@ -172,11 +193,11 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   __builtin_amdgcn_wave_barrier();  // LDS executes a wave's accesses in order; keep the compiler in order too
   double *g = grad + (size_t)(td.pstart + wp) * 21;
   const int nd = nv * 21;
-  for (int c = lane; c < nd; c += 64) g[c] = slab[c];
+  for (int c = lane; c < nd; c += 64) st_row<NT>(slab[c], &g[c]);
 }
 
 // Simple form: one workgroup per tile, stage through registers, barrier, compute.
-template <int LPP>
+template <int LPP, bool NT>
 __global__ __launch_bounds__(1024) void gg_gradient_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
     const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
@@ -191,7 +212,7 @@ __global__ __launch_bounds__(1024) void gg_gradient_kernel(
   // ---- stage: blob (normals | incidences | offsets), own var rows, halo var rows ----
   uint4 *s4 = reinterpret_cast<uint4 *>(smem);
   const uint4 *b4 = blob + td.blob_off;
-  for (int q = tid; q < td.blob_qw; q += nthr) s4[q] = b4[q];
+  for (int q = tid; q < td.blob_qw; q += nthr) s4[q] = ld_blob<NT>(&b4[q]);
   uint4 *v4 = s4 + td.blob_qw;  // var_l[(npts+nhalo)][8 doubles] = 4 x uint4 per row
   const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
   {
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(1024) void gg_gradient_kernel(
   }
   __syncthreads();
   double *stage = reinterpret_cast<double *>(smem + (size_t)td.blob_qw * 16 + (size_t)(npts + nhalo) * 64);
-  grad_tile_compute<LPP>(smem, td, tid, grad, stage);
+  grad_tile_compute<LPP, NT>(smem, td, tid, grad, stage);
 }
 
 // Pipelined form: persistent workgroups walk a contiguous run of tiles with two LDS buffers.
@@ -219,7 +240,15 @@ __device__ __forceinline__ void glds16(const uint4 *src, unsigned char *lds_wave
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                    (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
+// the same with the non-temporal policy (aux = 2): for the tile blobs, which are read exactly
+// once per launch and would otherwise push the var rows (re-read as halo rows by the
+// neighbouring tiles) out of the XCD's L2
+__device__ __forceinline__ void glds16_nt(const uint4 *src, unsigned char *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 2);
+}
 
+template <bool NT>
 __device__ __forceinline__ void pipe_issue_tile(unsigned char *buf, const cfdp_tile_desc &td,
                                                 const uint4 *__restrict__ blob,
                                                 const uint4 *__restrict__ gv4, const int (&hrow)[GG_HMAX],
@@ -228,7 +257,10 @@ __device__ __forceinline__ void pipe_issue_tile(unsigned char *buf, const cfdp_t
   // region 1: the tile blob; region 2: own var rows -- both contiguous in HBM
   const uint4 *b4 = blob + td.blob_off;
   for (int q0 = w0; q0 < td.blob_qw; q0 += nthr)
-    if (q0 + lane < td.blob_qw) glds16(b4 + q0 + lane, buf + (size_t)q0 * 16);
+    if (q0 + lane < td.blob_qw) {
+      if constexpr (NT) glds16_nt(b4 + q0 + lane, buf + (size_t)q0 * 16);
+      else glds16(b4 + q0 + lane, buf + (size_t)q0 * 16);
+    }
   unsigned char *vbuf = buf + (size_t)td.blob_qw * 16;
   const uint4 *own = gv4 + (size_t)td.pstart * 4;
   const int nown4 = td.npts * 4, nhalo4 = td.nhalo * 4;
@@ -254,7 +286,7 @@ __device__ __forceinline__ void pipe_load_hrows(int (&hrow)[GG_HMAX], const cfdp
   }
 }
 
-template <int LPP>
+template <int LPP, bool NT>
 __global__ __launch_bounds__(1024) void gg_gradient_pipe_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, int ntiles,
     const uint4 *__restrict__ blob, const int *__restrict__ halo_idx,
@@ -264,39 +296,43 @@ __global__ __launch_bounds__(1024) void gg_gradient_pipe_kernel(
   const int tid = threadIdx.x, nthr = blockDim.x;
   const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
 
-  // contiguous tile run of this workgroup; workgroups b, b+8, ... share an XCD and own
-  // neighbouring runs (their halo rows and duplicated faces meet in that XCD's L2)
+  // Workgroups b, b+8, ... share an XCD (round-robin dispatch) and together own one contiguous
+  // chunk of the tile sequence; inside the chunk they take tiles round-robin (stride = the
+  // XCD's workgroup count), so at any moment the XCD works on ~nwx CONSECUTIVE tiles -- spatial
+  // neighbours (host/tiling.c orders tiles supertile by supertile) whose var rows, gathered as
+  // halo rows by each other, meet in that XCD's 4 MiB L2.  Placement is speed only.
   const int b = blockIdx.x, nwg = gridDim.x, x = b & 7, j = b >> 3;
-  const int nwx = (nwg - x + 7) >> 3;
-  const long xt0 = (long)ntiles * x / 8, xt1 = (long)ntiles * (x + 1) / 8;
-  int t = tile_begin + (int)(xt0 + (xt1 - xt0) * j / nwx);
-  const int tend = tile_begin + (int)(xt0 + (xt1 - xt0) * (j + 1) / nwx);
+  const int nwx = (nwg - x + 7) >> 3;  // workgroups on this XCD
+  const int xt0 = (int)((long)ntiles * x / 8), xt1 = (int)((long)ntiles * (x + 1) / 8);
+  int t = tile_begin + xt0 + j;
+  const int tend = tile_begin + xt1;
+  const int tstep = nwx;
   if (t >= tend) return;
 
   int hrow[GG_HMAX];
   cfdp_tile_desc td = tiles[t];
   pipe_load_hrows(hrow, td, halo_idx, tid, nthr);
-  pipe_issue_tile(smem, td, blob, gv4, hrow, tid, nthr);
+  pipe_issue_tile<NT>(smem, td, blob, gv4, hrow, tid, nthr);
   cfdp_tile_desc tn = td;
-  if (t + 1 < tend) {
-    tn = tiles[t + 1];
+  if (t + tstep < tend) {
+    tn = tiles[t + tstep];
     pipe_load_hrows(hrow, tn, halo_idx, tid, nthr);
   }
   __syncthreads();  // drains this wave's DMA (vmcnt(0)) and publishes everybody's
   int cur = 0;
   const cfdp_tile_desc td0 = td;
   double *stage = reinterpret_cast<double *>(smem + 2 * (size_t)buf_bytes);
-  for (; t < tend; ++t) {
+  for (; t < tend; t += tstep) {
     unsigned char *bcur = smem + (size_t)cur * buf_bytes;
     unsigned char *bnxt = smem + (size_t)(cur ^ 1) * buf_bytes;
-    if (t + 1 < tend && !(dbg & 2)) pipe_issue_tile(bnxt, tn, blob, gv4, hrow, tid, nthr);
+    if (t + tstep < tend && !(dbg & 2)) pipe_issue_tile<NT>(bnxt, tn, blob, gv4, hrow, tid, nthr);
     cfdp_tile_desc tnn = tn;
-    if (t + 2 < tend) {
-      tnn = tiles[t + 2];
+    if (t + 2 * tstep < tend) {
+      tnn = tiles[t + 2 * tstep];
       pipe_load_hrows(hrow, tnn, halo_idx, tid, nthr);  // used one iteration from now
     }
-    if (dbg & 2) grad_tile_compute<LPP>(smem, td0, tid, grad, stage, dbg);  // timing experiment: buffer 0 only
-    else if (!(dbg & 1)) grad_tile_compute<LPP>(bcur, td, tid, grad, stage, dbg);
+    if (dbg & 2) grad_tile_compute<LPP, NT>(smem, td0, tid, grad, stage, dbg);  // timing experiment: buffer 0 only
+    else if (!(dbg & 1)) grad_tile_compute<LPP, NT>(bcur, td, tid, grad, stage, dbg);
     __syncthreads();  // (a) everyone is done reading bcur, (b) tile t+1 has landed in bnxt
     td = tn;
     tn = tnn;
@@ -307,7 +343,7 @@ __global__ __launch_bounds__(1024) void gg_gradient_pipe_kernel(
 // ---------------------------------------------------------------------------------- flux
 // LPP lanes share a point and split its incidence list; partial sums are combined with
 // wave shuffles in a fixed order (deterministic).
-template <int LPP, bool REFMODE>
+template <int LPP, bool REFMODE, bool NT>
 __global__ __launch_bounds__(1024) void gg_flux_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
     const int *__restrict__ halo_idx, const double *__restrict__ grad /*[nall][21]*/,
@@ -320,7 +356,7 @@ __global__ __launch_bounds__(1024) void gg_flux_kernel(
 
   uint4 *s4 = reinterpret_cast<uint4 *>(smem);
   const uint4 *b4 = blob + td.blob_off;
-  for (int q = tid; q < td.blob_qw; q += nthr) s4[q] = b4[q];
+  for (int q = tid; q < td.blob_qw; q += nthr) s4[q] = ld_blob<NT>(&b4[q]);
   // velocity-gradient block grad[p][IVX..IVZ][0..2] = first 9 doubles of each 21-double row
   double *g_l = reinterpret_cast<double *>(s4 + td.blob_qw);  // [(npts+nhalo)][10]
   const int *hid = halo_idx + td.halo_off;
@@ -415,17 +451,17 @@ __global__ __launch_bounds__(256) void gg_unpack_kernel(const double *__restrict
 // ------------------------------------------------------------------------------ launchers
 int gg_debug_flags = 0;  // timing experiments only: 1 = skip arithmetic, 2 = skip tile streaming
 
-#define LAUNCH_GRAD(L)                                                                         \
-  hipLaunchKernelGGL((gg_gradient_kernel<L>), dim3(ntiles), dim3(block), lds + stage_bytes,   \
+#define LAUNCH_GRAD(L, N)                                                                         \
+  hipLaunchKernelGGL((gg_gradient_kernel<L, N>), dim3(ntiles), dim3(block), lds + stage_bytes,   \
                      stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad)
-#define LAUNCH_GRAD_PIPE(L)                                                                    \
-  hipLaunchKernelGGL((gg_gradient_pipe_kernel<L>), dim3(nwg), dim3(block),                     \
+#define LAUNCH_GRAD_PIPE(L, N)                                                                    \
+  hipLaunchKernelGGL((gg_gradient_pipe_kernel<L, N>), dim3(nwg), dim3(block),                     \
                      2 * buf + stage_bytes, stream,                                            \
                      a.tiles, tile_begin, ntiles, a.blob, a.halo_idx, a.var, a.grad, (int)buf, gg_debug_flags)
 
 hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int ntiles,
                               int tile_points, size_t lds, int max_halo, int pipeline,
-                              hipStream_t stream) {
+                              bool nt, hipStream_t stream) {
   if (ntiles <= 0) return hipSuccess;
   const int block = ((tile_points * lanes + 63) / 64) * 64;
   if (block > 1024) return hipErrorInvalidConfiguration;
@@ -442,47 +478,47 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
     int nwg = 256 * per_cu;
     if (nwg > ntiles) nwg = ntiles;
     switch (lanes) {
-      case 1: LAUNCH_GRAD_PIPE(1); break;
-      case 2: LAUNCH_GRAD_PIPE(2); break;
-      case 4: LAUNCH_GRAD_PIPE(4); break;
-      case 8: LAUNCH_GRAD_PIPE(8); break;
+      case 1: if (nt) LAUNCH_GRAD_PIPE(1, true); else LAUNCH_GRAD_PIPE(1, false); break;
+      case 2: if (nt) LAUNCH_GRAD_PIPE(2, true); else LAUNCH_GRAD_PIPE(2, false); break;
+      case 4: if (nt) LAUNCH_GRAD_PIPE(4, true); else LAUNCH_GRAD_PIPE(4, false); break;
+      case 8: if (nt) LAUNCH_GRAD_PIPE(8, true); else LAUNCH_GRAD_PIPE(8, false); break;
       default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
   }
   switch (lanes) {
-    case 1: LAUNCH_GRAD(1); break;
-    case 2: LAUNCH_GRAD(2); break;
-    case 4: LAUNCH_GRAD(4); break;
-    case 8: LAUNCH_GRAD(8); break;
+    case 1: if (nt) LAUNCH_GRAD(1, true); else LAUNCH_GRAD(1, false); break;
+    case 2: if (nt) LAUNCH_GRAD(2, true); else LAUNCH_GRAD(2, false); break;
+    case 4: if (nt) LAUNCH_GRAD(4, true); else LAUNCH_GRAD(4, false); break;
+    case 8: if (nt) LAUNCH_GRAD(8, true); else LAUNCH_GRAD(8, false); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-#define LAUNCH_FLUX(L, R)                                                                        \
-  hipLaunchKernelGGL((gg_flux_kernel<L, R>), dim3(ntiles), dim3(block), lds, stream, a.tiles,    \
+#define LAUNCH_FLUX(L, R, N)                                                                      \
+  hipLaunchKernelGGL((gg_flux_kernel<L, R, N>), dim3(ntiles), dim3(block), lds, stream, a.tiles,    \
                      tile_begin, a.blob, a.halo_idx, a.grad, a.flux, a.nown)
 
 hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_begin, int ntiles,
-                          int tile_points, size_t lds, hipStream_t stream) {
+                          int tile_points, size_t lds, bool nt, hipStream_t stream) {
   if (ntiles <= 0) return hipSuccess;
   const int block = ((tile_points * lanes + 63) / 64) * 64;
   if (block > 1024) return hipErrorInvalidConfiguration;
   if (refmode) {
     switch (lanes) {
-      case 1: LAUNCH_FLUX(1, true); break;
-      case 2: LAUNCH_FLUX(2, true); break;
-      case 4: LAUNCH_FLUX(4, true); break;
-      case 8: LAUNCH_FLUX(8, true); break;
+      case 1: if (nt) LAUNCH_FLUX(1, true, true); else LAUNCH_FLUX(1, true, false); break;
+      case 2: if (nt) LAUNCH_FLUX(2, true, true); else LAUNCH_FLUX(2, true, false); break;
+      case 4: if (nt) LAUNCH_FLUX(4, true, true); else LAUNCH_FLUX(4, true, false); break;
+      case 8: if (nt) LAUNCH_FLUX(8, true, true); else LAUNCH_FLUX(8, true, false); break;
       default: return hipErrorInvalidValue;
     }
   } else {
     switch (lanes) {
-      case 1: LAUNCH_FLUX(1, false); break;
-      case 2: LAUNCH_FLUX(2, false); break;
-      case 4: LAUNCH_FLUX(4, false); break;
-      case 8: LAUNCH_FLUX(8, false); break;
+      case 1: if (nt) LAUNCH_FLUX(1, false, true); else LAUNCH_FLUX(1, false, false); break;
+      case 2: if (nt) LAUNCH_FLUX(2, false, true); else LAUNCH_FLUX(2, false, false); break;
+      case 4: if (nt) LAUNCH_FLUX(4, false, true); else LAUNCH_FLUX(4, false, false); break;
+      case 8: if (nt) LAUNCH_FLUX(8, false, true); else LAUNCH_FLUX(8, false, false); break;
       default: return hipErrorInvalidValue;
     }
   }
@@ -516,22 +552,38 @@ hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K),                                \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B));
   const size_t all = 160 * 1024;  // per-launch sizes are checked by the launchers
-  SET_LDS(gg_gradient_kernel<1>, all)
-  SET_LDS(gg_gradient_kernel<2>, all)
-  SET_LDS(gg_gradient_kernel<4>, all)
-  SET_LDS(gg_gradient_kernel<8>, all)
-  SET_LDS(gg_gradient_pipe_kernel<1>, all)
-  SET_LDS(gg_gradient_pipe_kernel<2>, all)
-  SET_LDS(gg_gradient_pipe_kernel<4>, all)
-  SET_LDS(gg_gradient_pipe_kernel<8>, all)
-  SET_LDS((gg_flux_kernel<1, false>), lds_flux)
-  SET_LDS((gg_flux_kernel<2, false>), lds_flux)
-  SET_LDS((gg_flux_kernel<4, false>), lds_flux)
-  SET_LDS((gg_flux_kernel<8, false>), lds_flux)
-  SET_LDS((gg_flux_kernel<1, true>), lds_flux)
-  SET_LDS((gg_flux_kernel<2, true>), lds_flux)
-  SET_LDS((gg_flux_kernel<4, true>), lds_flux)
-  SET_LDS((gg_flux_kernel<8, true>), lds_flux)
+  SET_LDS((gg_gradient_kernel<1, false>), all)
+  SET_LDS((gg_gradient_kernel<1, true>), all)
+  SET_LDS((gg_gradient_kernel<2, false>), all)
+  SET_LDS((gg_gradient_kernel<2, true>), all)
+  SET_LDS((gg_gradient_kernel<4, false>), all)
+  SET_LDS((gg_gradient_kernel<4, true>), all)
+  SET_LDS((gg_gradient_kernel<8, false>), all)
+  SET_LDS((gg_gradient_kernel<8, true>), all)
+  SET_LDS((gg_gradient_pipe_kernel<1, false>), all)
+  SET_LDS((gg_gradient_pipe_kernel<1, true>), all)
+  SET_LDS((gg_gradient_pipe_kernel<2, false>), all)
+  SET_LDS((gg_gradient_pipe_kernel<2, true>), all)
+  SET_LDS((gg_gradient_pipe_kernel<4, false>), all)
+  SET_LDS((gg_gradient_pipe_kernel<4, true>), all)
+  SET_LDS((gg_gradient_pipe_kernel<8, false>), all)
+  SET_LDS((gg_gradient_pipe_kernel<8, true>), all)
+  SET_LDS((gg_flux_kernel<1, false, false>), lds_flux)
+  SET_LDS((gg_flux_kernel<1, false, true>), lds_flux)
+  SET_LDS((gg_flux_kernel<2, false, false>), lds_flux)
+  SET_LDS((gg_flux_kernel<2, false, true>), lds_flux)
+  SET_LDS((gg_flux_kernel<4, false, false>), lds_flux)
+  SET_LDS((gg_flux_kernel<4, false, true>), lds_flux)
+  SET_LDS((gg_flux_kernel<8, false, false>), lds_flux)
+  SET_LDS((gg_flux_kernel<8, false, true>), lds_flux)
+  SET_LDS((gg_flux_kernel<1, true, false>), lds_flux)
+  SET_LDS((gg_flux_kernel<1, true, true>), lds_flux)
+  SET_LDS((gg_flux_kernel<2, true, false>), lds_flux)
+  SET_LDS((gg_flux_kernel<2, true, true>), lds_flux)
+  SET_LDS((gg_flux_kernel<4, true, false>), lds_flux)
+  SET_LDS((gg_flux_kernel<4, true, true>), lds_flux)
+  SET_LDS((gg_flux_kernel<8, true, false>), lds_flux)
+  SET_LDS((gg_flux_kernel<8, true, true>), lds_flux)
 #undef SET_LDS
   return e;
 }

@@ -51,6 +51,7 @@ struct cfdp_gpu {
   std::vector<int> new2old, partner, send_off, recv_off;
   std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
   int max_halo[2] = {0, 0};
+  bool streaming = false;      // per-iteration bytes exceed the Infinity Cache: non-temporal blobs/rows
   int pipeline = -1;           // -1: auto; 0: one workgroup per tile; k: persistent LDS-DMA kernel, <= k WG/CU
   int grad_lanes = 8, flux_lanes = 8;
   bool pending_exchange = false;
@@ -163,6 +164,11 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   if (p->nhalo_total)
     HIP_TRY(hipMemcpy(g->d_halo, p->halo_idx, sizeof(int) * (size_t)p->nhalo_total, hipMemcpyHostToDevice));
   g->vol.assign(p->vol, p->vol + p->nown);
+  {  // blob + var rows + grad rows streamed per iteration vs the 256 MiB Infinity Cache
+    const double per_iter = (double)p->blob_bytes + (double)p->nall * (64.0 + 168.0);
+    g->streaming = per_iter > 192.0 * 1024 * 1024;
+    if (const char *e = getenv("CFDP_STREAMING")) g->streaming = atoi(e) != 0;
+  }
   if (nsend)
     HIP_TRY(hipMemcpy(g->d_sendidx, p->send_idx, sizeof(int) * nsend, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(g->d_var, 0, sizeof(double) * 8 * (size_t)p->nall));
@@ -279,19 +285,19 @@ static int launch_grad(cfdp_gpu *g, int which, hipStream_t st) {
   const gg_args a = g->args();
   if (which == CFDP_TILES_ALL || which == CFDP_TILES_BOUNDARY)
     HIP_TRY(gg_launch_gradient(a, g->grad_lanes, 0, g->nbtiles, g->tp[0], g->lds_grad[0], g->max_halo[0],
-                               pipe_for(g, g->nbtiles), st));
+                               pipe_for(g, g->nbtiles), g->streaming, st));
   if (which == CFDP_TILES_ALL || which == CFDP_TILES_INTERIOR)
     HIP_TRY(gg_launch_gradient(a, g->grad_lanes, g->nbtiles, g->ntiles - g->nbtiles, g->tp[1],
-                               g->lds_grad[1], g->max_halo[1], pipe_for(g, g->ntiles - g->nbtiles), st));
+                               g->lds_grad[1], g->max_halo[1], pipe_for(g, g->ntiles - g->nbtiles), g->streaming, st));
   return 0;
 }
 
 static int launch_flux(cfdp_gpu *g, int mode, hipStream_t st) {
   const gg_args a = g->args();
   const bool ref = mode == CFDP_FLUX_REFERENCE;
-  HIP_TRY(gg_launch_flux(a, g->flux_lanes, ref, 0, g->nbtiles, g->tp[0], g->lds_flux[0], st));
+  HIP_TRY(gg_launch_flux(a, g->flux_lanes, ref, 0, g->nbtiles, g->tp[0], g->lds_flux[0], g->streaming, st));
   HIP_TRY(gg_launch_flux(a, g->flux_lanes, ref, g->nbtiles, g->ntiles - g->nbtiles, g->tp[1],
-                         g->lds_flux[1], st));
+                         g->lds_flux[1], g->streaming, st));
   return 0;
 }
 

@@ -26,11 +26,15 @@
 #include "cfdproxy_host.h"
 #include "host_util.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 void cfdp_plan_default_opts(cfdp_plan_opts *o) {
   o->tile_points = 64;
   o->boundary_first = 1;
+  o->supertile = 64;
+  const char *e = getenv("CFDP_SUPERTILE"); /* experiments */
+  if (e) o->supertile = atoi(e);
 }
 
 typedef struct {
@@ -203,6 +207,83 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
   CFDP_ASSERT(T.norder == nown);
   T.tile_first[T.ntiles] = nown;
   P->ntiles = T.ntiles;
+
+  /* ---- 3b. order the tiles for L2 reuse.  Growth order sweeps the mesh in layers, so a
+   * tile's neighbours (whose var rows it gathers as halo rows) can be a whole layer --
+   * hundreds of tiles, several MB of stream -- apart.  Cluster the TILE graph the same way
+   * the point graph was clustered ("supertiles" of o.supertile tiles) and visit the tiles
+   * supertile by supertile: most neighbours are then a few dozen tiles apart and their rows
+   * are still in the XCD's 4 MiB L2.  Boundary tiles stay in front (their own clustering). */
+  if (o.supertile > 1 && T.ntiles > 2 * o.supertile) {
+    const int nt = T.ntiles;
+    int *txadj = cfdp_calloc((size_t)nt + 2, sizeof(int));
+    int *tstamp = cfdp_malloc((size_t)nt * sizeof(int));
+    for (int t = 0; t < nt; t++) tstamp[t] = -1;
+    for (int pass = 0; pass < 2; pass++) { /* count, then fill */
+      int *tadj = NULL, *tfill = NULL;
+      if (pass == 1) {
+        for (int t = 0; t < nt; t++) txadj[t + 1] += txadj[t];
+        tadj = cfdp_malloc((size_t)(txadj[nt] ? txadj[nt] : 1) * sizeof(int));
+        tfill = cfdp_malloc((size_t)nt * sizeof(int));
+        memcpy(tfill, txadj, (size_t)nt * sizeof(int));
+        for (int t = 0; t < nt; t++) tstamp[t] = -1;
+      }
+      for (int t = 0; t < nt; t++)
+        for (int i = T.tile_first[t]; i < T.tile_first[t + 1]; i++) {
+          int p = T.order[i];
+          for (int e = xadj[p]; e < xadj[p + 1]; e++) {
+            int q = adj_other[e];
+            if (q >= nown) continue;
+            int u = T.tile_of[q];
+            if (u == t || tstamp[u] == t) continue;
+            tstamp[u] = t;
+            if (pass == 0) txadj[t + 1]++;
+            else tadj[tfill[t]++] = u;
+          }
+        }
+      if (pass == 1) {
+        tiler S;
+        memset(&S, 0, sizeof S);
+        S.nown = nt; S.xadj = txadj; S.adj_other = tadj;
+        S.tile_of = cfdp_malloc((size_t)nt * sizeof(int));
+        for (int t = 0; t < nt; t++) S.tile_of[t] = -1;
+        S.stamp = cfdp_calloc((size_t)nt, sizeof(int));
+        S.seeded = cfdp_calloc((size_t)nt, 1);
+        S.seedq = cfdp_malloc((size_t)nt * sizeof(int));
+        S.lq = cfdp_malloc((size_t)nt * sizeof(int));
+        S.order = cfdp_malloc((size_t)nt * sizeof(int));
+        unsigned char *cls = cfdp_malloc((size_t)nt);
+        for (int t = 0; t < nt; t++) cls[t] = t < P->nbtiles ? 1 : 0;
+        if (P->nbtiles) tiler_pass(&S, cls, 1, o.supertile);
+        memset(S.seeded, 0, (size_t)nt);
+        S.sq_head = S.sq_tail = 0;
+        tiler_pass(&S, cls, 0, o.supertile);
+        CFDP_ASSERT(S.norder == nt);
+        /* rebuild the point order, tile starts and tile_of for the new tile sequence */
+        int *norder = cfdp_malloc((size_t)nown * sizeof(int));
+        int *nfirst = cfdp_malloc((size_t)(nt + 1) * sizeof(int));
+        int n = 0;
+        for (int k = 0; k < nt; k++) {
+          int t = S.order[k];
+          nfirst[k] = n;
+          for (int i = T.tile_first[t]; i < T.tile_first[t + 1]; i++) {
+            norder[n] = T.order[i];
+            T.tile_of[T.order[i]] = k;
+            n++;
+          }
+        }
+        nfirst[nt] = n;
+        CFDP_ASSERT(n == nown);
+        memcpy(T.order, norder, (size_t)nown * sizeof(int));
+        memcpy(T.tile_first, nfirst, (size_t)(nt + 1) * sizeof(int));
+        free(norder); free(nfirst); free(cls);
+        free(S.tile_of); free(S.stamp); free(S.seeded); free(S.seedq); free(S.lq); free(S.order);
+        free(S.tile_first);
+        free(tadj); free(tfill);
+      }
+    }
+    free(txadj); free(tstamp);
+  }
 
   /* ---- 4. renumber: owned points tile-major; ghosts grouped by partner, message order ---- */
   P->new2old = cfdp_malloc((size_t)nall * sizeof(int));

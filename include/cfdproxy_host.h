@@ -110,6 +110,7 @@ typedef struct {
 typedef struct {
   int tile_points;         /* owned points per tile (<= 1024)                              */
   int boundary_first;      /* tile send points first (comm/compute overlap)                */
+  int supertile;           /* tiles per cluster of the launch order (L2 reuse); <= 1: off  */
 } cfdp_plan_opts;
 
 typedef struct cfdp_plan {
