@@ -19,10 +19,11 @@ struct gg_args {
 // pipeline: 0 = one workgroup per tile; k > 0 = persistent double-buffered LDS-DMA kernel
 // with at most k workgroups per CU (falls back to 0 when two buffers do not fit in LDS)
 hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int ntiles,
-                              int tile_points, size_t lds, int max_halo, int pipeline,
-                              bool nt, hipStream_t stream);
+                              int tile_points, size_t lds, int max_halo, int max_blob_qw,
+                              int pipeline, bool nt, hipStream_t stream);
 hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_begin, int ntiles,
-                          int tile_points, size_t lds, bool nt, hipStream_t stream);
+                          int tile_points, size_t lds, int max_halo, int max_blob_qw, bool nt,
+                          hipStream_t stream);
 hipError_t gg_launch_pack(const int *send_idx, int nsend, const double *grad, double *sendbuf,
                           hipStream_t stream);
 hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, int nown, double *grad,

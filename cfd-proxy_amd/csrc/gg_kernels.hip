@@ -120,7 +120,8 @@ __device__ __forceinline__ void grad_batch(const uint32_t *__restrict__ inc, int
 template <int LPP, bool NT>
 __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, const cfdp_tile_desc &td,
                                                   int tid, double *__restrict__ grad,
-                                                  double *__restrict__ stage, int dbg = 0) {
+                                                  double *__restrict__ stage, int dbg = 0,
+                                                  int var_off = -1) {
   constexpr int NE = grad_cfg<LPP>::NE;
   constexpr int PPW = 64 / LPP;  // points per wave
   const int li = tid / LPP, sub = tid % LPP;
@@ -132,7 +133,8 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   const double *nz = reinterpret_cast<const double *>(buf + 2 * plane);
   const uint32_t *inc = reinterpret_cast<const uint32_t *>(buf + 3 * plane);
   const uint32_t *ioff = reinterpret_cast<const uint32_t *>(buf + 3 * plane + inc_bytes);
-  const double *var_l = reinterpret_cast<const double *>(buf + (size_t)td.blob_qw * 16);
+  // var rows follow the blob (packed image) or sit at a fixed offset (fixed-capacity image)
+  const double *var_l = reinterpret_cast<const double *>(buf + (var_off >= 0 ? (size_t)var_off : (size_t)td.blob_qw * 16));
 
   const int eq0 = sub * NE;
   double vs[NE], acc[NE][3];
@@ -148,6 +150,8 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     const int ke = (dbg & 4) ? ks : ke0;  // timing experiment: no arithmetic, stores only
     const double *var_eq0 = var_l + eq0;
     int k = ks;
+    if constexpr (NE <= 2)  // few registers per incidence: deeper batches (a point has ~14 incidences)
+      for (; k + 7 <= ke; k += 7) grad_batch<7, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
     for (; k + 4 <= ke; k += 4) grad_batch<4, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
     if (k + 2 <= ke) {
       grad_batch<2, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
@@ -227,6 +231,79 @@ __global__ __launch_bounds__(1024) void gg_gradient_kernel(
   __syncthreads();
   double *stage = reinterpret_cast<double *>(smem + (size_t)td.blob_qw * 16 + (size_t)(npts + nhalo) * 64);
   grad_tile_compute<LPP, NT>(smem, td, tid, grad, stage);
+}
+
+// ---- fixed-count LDS-DMA staging ------------------------------------------------------------
+// The register-staged form above serialises ~5 global round trips per tile (the compiler
+// waits between the blob, own-row, halo-index and halo-row loops).  Here every wave issues a
+// FIXED number of LDS-DMA instructions with full EXEC and clamped addresses (out-of-range
+// pieces re-read the last valid 16 bytes into the padding of a fixed-capacity LDS region), so
+// that the only true dependency -- halo row numbers -> halo rows -- can be waited for with a
+// COUNTED vmcnt while the CB blob pieces issued after the index loads stay in flight.
+// LDS image: [blob region: CB*nthr*16 B][var rows, own then halo: KV*nthr*16 B].
+__device__ __forceinline__ int ld_i32_nowait(const int *p) {
+  int v;  // the compiler does not track this load: the caller waits for it (counted vmcnt)
+  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void glds16(const uint4 *src, unsigned char *lds_wave_base);
+__device__ __forceinline__ void glds16_nt(const uint4 *src, unsigned char *lds_wave_base);
+
+template <bool NT, int CB, int KV>
+__device__ __forceinline__ void dma_stage_tile(unsigned char *buf, const cfdp_tile_desc &td,
+                                               const uint4 *__restrict__ blob, const uint4 *__restrict__ gv4,
+                                               const int *__restrict__ halo_idx, int tid, int nthr) {
+  const int lane = tid & 63, w0 = tid & ~63;
+  // (1) halo row numbers of the pieces this thread will gather (always issued, clamped)
+  int hrow[KV];
+  const int *hid = halo_idx + td.halo_off;
+  const int hmax = td.nhalo > 0 ? td.nhalo - 1 : 0;
+#pragma unroll
+  for (int k = 0; k < KV; k++) {
+    int h = ((tid + k * nthr) >> 2) - td.npts;
+    h = h < 0 ? 0 : (h > hmax ? hmax : h);
+    hrow[k] = ld_i32_nowait(hid + h);
+  }
+  // (2) the blob: CB pieces per wave, source clamped to the last valid 16 bytes
+  const uint4 *b4 = blob + td.blob_off;
+  const int qmax = td.blob_qw - 1;
+#pragma unroll
+  for (int i = 0; i < CB; i++) {
+    const int q0 = w0 + i * nthr;
+    const int q = q0 + lane < qmax ? q0 + lane : qmax;
+    if constexpr (NT) glds16_nt(b4 + q, buf + (size_t)q0 * 16);
+    else glds16(b4 + q, buf + (size_t)q0 * 16);
+  }
+  // (3) wait for the index loads only: the CB DMA instructions issued after them stay in flight
+  if constexpr (KV == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hrow[0]) : "n"(CB) : "memory");
+  if constexpr (KV == 2)
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(hrow[0]), "+v"(hrow[1]) : "n"(CB) : "memory");
+  if constexpr (KV == 3)
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(hrow[0]), "+v"(hrow[1]), "+v"(hrow[2]) : "n"(CB) : "memory");
+  // (4) var rows: own rows by position, halo rows by number; 4 lanes per 64-byte row
+  unsigned char *vbuf = buf + (size_t)CB * nthr * 16;
+#pragma unroll
+  for (int k = 0; k < KV; k++) {
+    const int q = tid + k * nthr, r = q >> 2;
+    const int row = r < td.npts ? td.pstart + r : hrow[k];
+    glds16(gv4 + (size_t)row * 4 + (q & 3), vbuf + (size_t)(w0 + k * nthr) * 16);
+  }
+}
+
+template <int LPP, bool NT, int CB, int KV>
+__global__ __launch_bounds__(1024) void gg_gradient_dma_kernel(
+    const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
+    const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
+    double *__restrict__ grad /*[nall][21]*/) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
+  const cfdp_tile_desc td = tiles[t];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  dma_stage_tile<NT, CB, KV>(smem, td, blob, reinterpret_cast<const uint4 *>(var), halo_idx, tid, nthr);
+  __syncthreads();  // vmcnt(0) + barrier: every wave's pieces have landed
+  const int var_off = CB * nthr * 16;
+  double *stage = reinterpret_cast<double *>(smem + (size_t)(CB + KV) * nthr * 16);
+  grad_tile_compute<LPP, NT>(smem, td, tid, grad, stage, 0, var_off);
 }
 
 // Pipelined form: persistent workgroups walk a contiguous run of tiles with two LDS buffers.
@@ -343,30 +420,13 @@ __global__ __launch_bounds__(1024) void gg_gradient_pipe_kernel(
 // ---------------------------------------------------------------------------------- flux
 // LPP lanes share a point and split its incidence list; partial sums are combined with
 // wave shuffles in a fixed order (deterministic).
-template <int LPP, bool REFMODE, bool NT>
-__global__ __launch_bounds__(1024) void gg_flux_kernel(
-    const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
-    const int *__restrict__ halo_idx, const double *__restrict__ grad /*[nall][21]*/,
-    double *__restrict__ flux /*[nown][3]*/, int nown) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
-  const cfdp_tile_desc td = tiles[t];
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int npts = td.npts, nhalo = td.nhalo;
-
-  uint4 *s4 = reinterpret_cast<uint4 *>(smem);
-  const uint4 *b4 = blob + td.blob_off;
-  for (int q = tid; q < td.blob_qw; q += nthr) s4[q] = ld_blob<NT>(&b4[q]);
-  // velocity-gradient block grad[p][IVX..IVZ][0..2] = first 9 doubles of each 21-double row
-  double *g_l = reinterpret_cast<double *>(s4 + td.blob_qw);  // [(npts+nhalo)][10]
-  const int *hid = halo_idx + td.halo_off;
-  for (int q = tid; q < (npts + nhalo) * 9; q += nthr) {
-    const int r = q / 9, c = q - 9 * r;
-    const int row = r < npts ? td.pstart + r : hid[r - npts];
-    g_l[r * 10 + c] = grad[(size_t)row * 21 + c];
-  }
-  __syncthreads();
-
+// The per-tile flux arithmetic.  `smem` holds the tile blob, `g_l` the 3x3 velocity-gradient
+// blocks of own + halo points, 10 doubles (80 bytes) per row.
+template <int LPP, bool REFMODE>
+__device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, const double *g_l,
+                                                  const cfdp_tile_desc &td, const int *__restrict__ hid,
+                                                  int tid, double *__restrict__ flux, int nown) {
+  const int npts = td.npts;
   const int li = tid / LPP, sub = tid % LPP;
   const bool active = li < npts;
   const int plane = (td.nfaces * 8 + 15) & ~15;
@@ -430,6 +490,90 @@ __global__ __launch_bounds__(1024) void gg_flux_kernel(
   }
 }
 
+template <int LPP, bool REFMODE, bool NT>
+__global__ __launch_bounds__(1024) void gg_flux_kernel(
+    const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
+    const int *__restrict__ halo_idx, const double *__restrict__ grad /*[nall][21]*/,
+    double *__restrict__ flux /*[nown][3]*/, int nown) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
+  const cfdp_tile_desc td = tiles[t];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int npts = td.npts, nhalo = td.nhalo;
+
+  uint4 *s4 = reinterpret_cast<uint4 *>(smem);
+  const uint4 *b4 = blob + td.blob_off;
+  for (int q = tid; q < td.blob_qw; q += nthr) s4[q] = ld_blob<NT>(&b4[q]);
+  // velocity-gradient block grad[p][IVX..IVZ][0..2] = first 9 doubles of each 21-double row
+  double *g_l = reinterpret_cast<double *>(s4 + td.blob_qw);  // [(npts+nhalo)][10]
+  const int *hid = halo_idx + td.halo_off;
+  for (int q = tid; q < (npts + nhalo) * 9; q += nthr) {
+    const int r = q / 9, c = q - 9 * r;
+    const int row = r < npts ? td.pstart + r : hid[r - npts];
+    g_l[r * 10 + c] = grad[(size_t)row * 21 + c];
+  }
+  __syncthreads();
+
+  flux_tile_compute<LPP, REFMODE>(smem, g_l, td, hid, tid, flux, nown);
+}
+
+// one workgroup per tile, fixed-count LDS-DMA staging (see gg_gradient_dma_kernel): the blob as CB
+// pieces per wave, the gradient rows as KV pieces per wave -- 5 pieces (80 bytes) of every
+// 168-byte row, own rows by position, halo rows by number
+template <int LPP, bool REFMODE, bool NT, int CB, int KV>
+__global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
+    const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
+    const int *__restrict__ halo_idx, const double *__restrict__ grad /*[nall][21]*/,
+    double *__restrict__ flux /*[nown][3]*/, int nown) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
+  const cfdp_tile_desc td = tiles[t];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, w0 = tid & ~63;
+  const int *hid = halo_idx + td.halo_off;
+  // (1) halo row numbers for this thread's pieces (always issued, clamped)
+  int hrow[KV], part[KV], rloc[KV];
+  const int hmax = td.nhalo > 0 ? td.nhalo - 1 : 0;
+#pragma unroll
+  for (int k = 0; k < KV; k++) {
+    const int q = tid + k * nthr;
+    rloc[k] = q / 5;
+    part[k] = q - 5 * rloc[k];
+    int h = rloc[k] - td.npts;
+    h = h < 0 ? 0 : (h > hmax ? hmax : h);
+    hrow[k] = ld_i32_nowait(hid + h);
+  }
+  // (2) blob pieces
+  const uint4 *b4 = blob + td.blob_off;
+  const int qmax = td.blob_qw - 1;
+#pragma unroll
+  for (int i = 0; i < CB; i++) {
+    const int q0 = w0 + i * nthr;
+    const int q = q0 + lane < qmax ? q0 + lane : qmax;
+    if constexpr (NT) glds16_nt(b4 + q, smem + (size_t)q0 * 16);
+    else glds16(b4 + q, smem + (size_t)q0 * 16);
+  }
+  // (3) only the index loads are awaited; the CB blob pieces stay in flight
+  if constexpr (KV == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hrow[0]) : "n"(CB) : "memory");
+  if constexpr (KV == 2)
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(hrow[0]), "+v"(hrow[1]) : "n"(CB) : "memory");
+  if constexpr (KV == 3)
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(hrow[0]), "+v"(hrow[1]), "+v"(hrow[2]) : "n"(CB) : "memory");
+  if constexpr (KV == 4)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(hrow[0]), "+v"(hrow[1]), "+v"(hrow[2]), "+v"(hrow[3]) : "n"(CB) : "memory");
+  // (4) gradient rows: first 80 bytes of each row
+  unsigned char *gbuf = smem + (size_t)CB * nthr * 16;
+  const unsigned char *gbytes = reinterpret_cast<const unsigned char *>(grad);
+#pragma unroll
+  for (int k = 0; k < KV; k++) {
+    const int row = rloc[k] < td.npts ? td.pstart + rloc[k] : hrow[k];
+    glds16(reinterpret_cast<const uint4 *>(gbytes + (size_t)row * 168 + part[k] * 16),
+           gbuf + (size_t)(w0 + k * nthr) * 16);
+  }
+  __syncthreads();
+  flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<const double *>(gbuf), td, hid, tid, flux, nown);
+}
+
 // --------------------------------------------------------------------------- pack/unpack
 __global__ __launch_bounds__(256) void gg_pack_kernel(const int *__restrict__ send_idx, int nsend,
                                                       const double *__restrict__ grad,
@@ -460,8 +604,8 @@ int gg_debug_flags = 0;  // timing experiments only: 1 = skip arithmetic, 2 = sk
                      a.tiles, tile_begin, ntiles, a.blob, a.halo_idx, a.var, a.grad, (int)buf, gg_debug_flags)
 
 hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int ntiles,
-                              int tile_points, size_t lds, int max_halo, int pipeline,
-                              bool nt, hipStream_t stream) {
+                              int tile_points, size_t lds, int max_halo, int max_blob_qw,
+                              int pipeline, bool nt, hipStream_t stream) {
   if (ntiles <= 0) return hipSuccess;
   const int block = ((tile_points * lanes + 63) / 64) * 64;
   if (block > 1024) return hipErrorInvalidConfiguration;
@@ -486,6 +630,33 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
     }
     return hipGetLastError();
   }
+  // one workgroup per tile.  Preferred: fixed-count LDS-DMA staging (8 lanes per point), when
+  // the tile sizes of this launch fit one of the instantiated (CB, KV) capacities
+  if (lanes == 8 && !(gg_debug_flags & 16)) {
+    const int cb = (max_blob_qw + block - 1) / block;                       // blob pieces per wave
+    const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;      // var-row pieces per wave
+#define LAUNCH_GRAD_DMA(CB, KV)                                                                   \
+  do {                                                                                            \
+    const size_t dma_lds = (size_t)((CB) + (KV)) * block * 16 + stage_bytes;                      \
+    if (dma_lds > 160 * 1024) break;                                                              \
+    if (nt) hipLaunchKernelGGL((gg_gradient_dma_kernel<8, true, CB, KV>), dim3(ntiles), dim3(block),  \
+                               dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad); \
+    else hipLaunchKernelGGL((gg_gradient_dma_kernel<8, false, CB, KV>), dim3(ntiles), dim3(block),    \
+                            dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad); \
+    return hipGetLastError();                                                                     \
+  } while (0)
+    if (cb >= 1 && kv >= 1 && kv <= 2) {
+      if (cb <= 2) LAUNCH_GRAD_DMA(2, 2);
+      if (cb <= 3) LAUNCH_GRAD_DMA(3, 2);
+      if (cb <= 4) LAUNCH_GRAD_DMA(4, 2);
+      if (cb <= 6) LAUNCH_GRAD_DMA(6, 2);
+    } else if (cb >= 1 && kv == 3) {
+      if (cb <= 3) LAUNCH_GRAD_DMA(3, 3);
+      if (cb <= 4) LAUNCH_GRAD_DMA(4, 3);
+      if (cb <= 6) LAUNCH_GRAD_DMA(6, 3);
+    }
+#undef LAUNCH_GRAD_DMA
+  }
   switch (lanes) {
     case 1: if (nt) LAUNCH_GRAD(1, true); else LAUNCH_GRAD(1, false); break;
     case 2: if (nt) LAUNCH_GRAD(2, true); else LAUNCH_GRAD(2, false); break;
@@ -501,10 +672,46 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
                      tile_begin, a.blob, a.halo_idx, a.grad, a.flux, a.nown)
 
 hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_begin, int ntiles,
-                          int tile_points, size_t lds, bool nt, hipStream_t stream) {
+                          int tile_points, size_t lds, int max_halo, int max_blob_qw, bool nt,
+                          hipStream_t stream) {
   if (ntiles <= 0) return hipSuccess;
   const int block = ((tile_points * lanes + 63) / 64) * 64;
   if (block > 1024) return hipErrorInvalidConfiguration;
+  if (lanes == 8 && !(gg_debug_flags & 16)) {  // fixed-count LDS-DMA staging
+    const int cb = (max_blob_qw + block - 1) / block;
+    const int kv = ((tile_points + max_halo) * 5 + block - 1) / block;
+#define LAUNCH_FLUX_DMA(CB, KV)                                                                   \
+  do {                                                                                            \
+    const size_t dma_lds = (size_t)((CB) + (KV)) * block * 16;                                    \
+    if (dma_lds > 160 * 1024) break;                                                              \
+    if (refmode) {                                                                                \
+      if (nt) hipLaunchKernelGGL((gg_flux_dma_kernel<8, true, true, CB, KV>), dim3(ntiles), dim3(block), dma_lds, \
+                                 stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad, a.flux, a.nown); \
+      else hipLaunchKernelGGL((gg_flux_dma_kernel<8, true, false, CB, KV>), dim3(ntiles), dim3(block), dma_lds, \
+                              stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad, a.flux, a.nown); \
+    } else {                                                                                      \
+      if (nt) hipLaunchKernelGGL((gg_flux_dma_kernel<8, false, true, CB, KV>), dim3(ntiles), dim3(block), dma_lds, \
+                                 stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad, a.flux, a.nown); \
+      else hipLaunchKernelGGL((gg_flux_dma_kernel<8, false, false, CB, KV>), dim3(ntiles), dim3(block), dma_lds, \
+                              stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad, a.flux, a.nown); \
+    }                                                                                             \
+    return hipGetLastError();                                                                     \
+  } while (0)
+    if (cb >= 1 && kv >= 1 && kv <= 2) {
+      if (cb <= 2) LAUNCH_FLUX_DMA(2, 2);
+      if (cb <= 3) LAUNCH_FLUX_DMA(3, 2);
+      if (cb <= 4) LAUNCH_FLUX_DMA(4, 2);
+      if (cb <= 6) LAUNCH_FLUX_DMA(6, 2);
+    } else if (cb >= 1 && kv == 3) {
+      if (cb <= 3) LAUNCH_FLUX_DMA(3, 3);
+      if (cb <= 4) LAUNCH_FLUX_DMA(4, 3);
+      if (cb <= 6) LAUNCH_FLUX_DMA(6, 3);
+    } else if (cb >= 1 && kv == 4) {
+      if (cb <= 3) LAUNCH_FLUX_DMA(3, 4);
+      if (cb <= 6) LAUNCH_FLUX_DMA(6, 4);
+    }
+#undef LAUNCH_FLUX_DMA
+  }
   if (refmode) {
     switch (lanes) {
       case 1: if (nt) LAUNCH_FLUX(1, true, true); else LAUNCH_FLUX(1, true, false); break;
@@ -546,7 +753,14 @@ hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, int nown, double *
 }
 
 hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
-  hipError_t e = hipSuccess;
+  // raise the dynamic-LDS limit of every kernel to the full 160 KiB once per device (the
+  // launchers check the per-launch size); ~100 attribute calls are too slow to repeat per plan
+  (void)lds_grad; (void)lds_flux;
+  static bool done[64] = {false};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
 #define SET_LDS(K, B)                                                                          \
   if (e == hipSuccess && (B) > 65536 && (B) <= 163840)                                                        \
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K),                                \
@@ -560,6 +774,20 @@ hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
   SET_LDS((gg_gradient_kernel<4, true>), all)
   SET_LDS((gg_gradient_kernel<8, false>), all)
   SET_LDS((gg_gradient_kernel<8, true>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, false, 2, 2>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, true, 2, 2>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, false, 3, 2>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, true, 3, 2>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, false, 4, 2>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, true, 4, 2>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, false, 6, 2>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, true, 6, 2>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, false, 3, 3>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, true, 3, 3>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, false, 4, 3>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, true, 4, 3>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, false, 6, 3>), all)
+  SET_LDS((gg_gradient_dma_kernel<8, true, 6, 3>), all)
   SET_LDS((gg_gradient_pipe_kernel<1, false>), all)
   SET_LDS((gg_gradient_pipe_kernel<1, true>), all)
   SET_LDS((gg_gradient_pipe_kernel<2, false>), all)
@@ -568,22 +796,59 @@ hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
   SET_LDS((gg_gradient_pipe_kernel<4, true>), all)
   SET_LDS((gg_gradient_pipe_kernel<8, false>), all)
   SET_LDS((gg_gradient_pipe_kernel<8, true>), all)
-  SET_LDS((gg_flux_kernel<1, false, false>), lds_flux)
-  SET_LDS((gg_flux_kernel<1, false, true>), lds_flux)
-  SET_LDS((gg_flux_kernel<2, false, false>), lds_flux)
-  SET_LDS((gg_flux_kernel<2, false, true>), lds_flux)
-  SET_LDS((gg_flux_kernel<4, false, false>), lds_flux)
-  SET_LDS((gg_flux_kernel<4, false, true>), lds_flux)
-  SET_LDS((gg_flux_kernel<8, false, false>), lds_flux)
-  SET_LDS((gg_flux_kernel<8, false, true>), lds_flux)
-  SET_LDS((gg_flux_kernel<1, true, false>), lds_flux)
-  SET_LDS((gg_flux_kernel<1, true, true>), lds_flux)
-  SET_LDS((gg_flux_kernel<2, true, false>), lds_flux)
-  SET_LDS((gg_flux_kernel<2, true, true>), lds_flux)
-  SET_LDS((gg_flux_kernel<4, true, false>), lds_flux)
-  SET_LDS((gg_flux_kernel<4, true, true>), lds_flux)
-  SET_LDS((gg_flux_kernel<8, true, false>), lds_flux)
-  SET_LDS((gg_flux_kernel<8, true, true>), lds_flux)
+  SET_LDS((gg_flux_dma_kernel<8, false, false, 2, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, true, 2, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, false, 2, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, true, 2, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, false, 3, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, true, 3, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, false, 3, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, true, 3, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, false, 4, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, true, 4, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, false, 4, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, true, 4, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, false, 6, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, true, 6, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, false, 6, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, true, 6, 2>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, false, 3, 3>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, true, 3, 3>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, false, 3, 3>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, true, 3, 3>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, false, 4, 3>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, true, 4, 3>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, false, 4, 3>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, true, 4, 3>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, false, 6, 3>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, true, 6, 3>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, false, 6, 3>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, true, 6, 3>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, false, 3, 4>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, true, 3, 4>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, false, 3, 4>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, true, 3, 4>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, false, 6, 4>), all)
+  SET_LDS((gg_flux_dma_kernel<8, false, true, 6, 4>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, false, 6, 4>), all)
+  SET_LDS((gg_flux_dma_kernel<8, true, true, 6, 4>), all)
+  SET_LDS((gg_flux_kernel<1, false, false>), all)
+  SET_LDS((gg_flux_kernel<1, false, true>), all)
+  SET_LDS((gg_flux_kernel<2, false, false>), all)
+  SET_LDS((gg_flux_kernel<2, false, true>), all)
+  SET_LDS((gg_flux_kernel<4, false, false>), all)
+  SET_LDS((gg_flux_kernel<4, false, true>), all)
+  SET_LDS((gg_flux_kernel<8, false, false>), all)
+  SET_LDS((gg_flux_kernel<8, false, true>), all)
+  SET_LDS((gg_flux_kernel<1, true, false>), all)
+  SET_LDS((gg_flux_kernel<1, true, true>), all)
+  SET_LDS((gg_flux_kernel<2, true, false>), all)
+  SET_LDS((gg_flux_kernel<2, true, true>), all)
+  SET_LDS((gg_flux_kernel<4, true, false>), all)
+  SET_LDS((gg_flux_kernel<4, true, true>), all)
+  SET_LDS((gg_flux_kernel<8, true, false>), all)
+  SET_LDS((gg_flux_kernel<8, true, true>), all)
 #undef SET_LDS
+  if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
   return e;
 }

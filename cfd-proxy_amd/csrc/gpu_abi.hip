@@ -50,7 +50,7 @@ struct cfdp_gpu {
   bool own_grad = true, own_sendbuf = true;
   std::vector<int> new2old, partner, send_off, recv_off;
   std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
-  int max_halo[2] = {0, 0};
+  int max_halo[2] = {0, 0}, max_blob[2] = {0, 0};  // per tile class: halo rows, blob 16-byte units
   bool streaming = false;      // per-iteration bytes exceed the Infinity Cache: non-temporal blobs/rows
   int pipeline = -1;           // -1: auto; 0: one workgroup per tile; k: persistent LDS-DMA kernel, <= k WG/CU
   int grad_lanes = 8, flux_lanes = 8;
@@ -129,10 +129,12 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   g->nown = p->nown; g->nall = p->nall; g->ntiles = p->ntiles; g->nbtiles = p->nbtiles;
   g->tp[0] = g->tp[1] = 0;
   g->max_halo[0] = g->max_halo[1] = 0;
+  g->max_blob[0] = g->max_blob[1] = 0;
   for (int t = 0; t < p->ntiles; t++) {
     int c = t < p->nbtiles ? 0 : 1;
     if (p->tiles[t].npts > g->tp[c]) g->tp[c] = p->tiles[t].npts;
     if (p->tiles[t].nhalo > g->max_halo[c]) g->max_halo[c] = p->tiles[t].nhalo;
+    if (p->tiles[t].blob_qw > g->max_blob[c]) g->max_blob[c] = p->tiles[t].blob_qw;
   }
   for (int c = 0; c < 2; c++) {
     g->lds_grad[c] = (size_t)p->lds_grad_cls[c];
@@ -161,6 +163,7 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   g->own_grad = g->own_sendbuf = true;
   HIP_TRY(hipMemcpy(g->d_tiles, p->tiles, sizeof(cfdp_tile_desc) * (size_t)p->ntiles, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(g->d_blob, p->blob, (size_t)p->blob_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(g->d_halo, 0, sizeof(int) * (size_t)(p->nhalo_total + 1)));
   if (p->nhalo_total)
     HIP_TRY(hipMemcpy(g->d_halo, p->halo_idx, sizeof(int) * (size_t)p->nhalo_total, hipMemcpyHostToDevice));
   g->vol.assign(p->vol, p->vol + p->nown);
@@ -274,30 +277,33 @@ int cfdp_gpu_set_variant(cfdp_gpu *g, int grad_lanes, int flux_lanes) {
   return 0;
 }
 
-// auto: the persistent LDS-DMA kernel pays off once a CU walks a long run of tiles (its
-// prologue/epilogue are not overlapped); short launches use one workgroup per tile
+// default: one workgroup per tile with fixed-count LDS-DMA staging (3 workgroups per CU keep
+// ~24 waves busy; measured faster than the persistent double-buffered form at every size,
+// whose single workgroup per CU cannot hide the LDS latency of the arithmetic)
 static int pipe_for(const cfdp_gpu *g, int ntiles) {
-  if (g->pipeline >= 0) return g->pipeline;
-  return ntiles >= 24 * 256 ? 2 : 0;
+  (void)ntiles;
+  return g->pipeline >= 0 ? g->pipeline : 0;
 }
 
 static int launch_grad(cfdp_gpu *g, int which, hipStream_t st) {
   const gg_args a = g->args();
   if (which == CFDP_TILES_ALL || which == CFDP_TILES_BOUNDARY)
     HIP_TRY(gg_launch_gradient(a, g->grad_lanes, 0, g->nbtiles, g->tp[0], g->lds_grad[0], g->max_halo[0],
-                               pipe_for(g, g->nbtiles), g->streaming, st));
+                               g->max_blob[0], pipe_for(g, g->nbtiles), g->streaming, st));
   if (which == CFDP_TILES_ALL || which == CFDP_TILES_INTERIOR)
     HIP_TRY(gg_launch_gradient(a, g->grad_lanes, g->nbtiles, g->ntiles - g->nbtiles, g->tp[1],
-                               g->lds_grad[1], g->max_halo[1], pipe_for(g, g->ntiles - g->nbtiles), g->streaming, st));
+                               g->lds_grad[1], g->max_halo[1], g->max_blob[1],
+                               pipe_for(g, g->ntiles - g->nbtiles), g->streaming, st));
   return 0;
 }
 
 static int launch_flux(cfdp_gpu *g, int mode, hipStream_t st) {
   const gg_args a = g->args();
   const bool ref = mode == CFDP_FLUX_REFERENCE;
-  HIP_TRY(gg_launch_flux(a, g->flux_lanes, ref, 0, g->nbtiles, g->tp[0], g->lds_flux[0], g->streaming, st));
+  HIP_TRY(gg_launch_flux(a, g->flux_lanes, ref, 0, g->nbtiles, g->tp[0], g->lds_flux[0], g->max_halo[0],
+                         g->max_blob[0], g->streaming, st));
   HIP_TRY(gg_launch_flux(a, g->flux_lanes, ref, g->nbtiles, g->ntiles - g->nbtiles, g->tp[1],
-                         g->lds_flux[1], g->streaming, st));
+                         g->lds_flux[1], g->max_halo[1], g->max_blob[1], g->streaming, st));
   return 0;
 }
 
