@@ -170,7 +170,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   const int nv = td.npts - wp < PPW ? td.npts - wp : PPW;       // its valid points (may be <= 0)
   // a point without faces is in no colour list: the reference leaves its row alone
   const bool faceless = active && ke0 == ks;
-  if (__any(faceless)) {  // rare: fall back to per-lane stores that can skip a row
+  if (__any(faceless) || (dbg & 64)) {  // rare: fall back to per-lane stores that can skip a row
     if (active && !faceless) {
       double *g = grad + (size_t)(td.pstart + li) * 21 + eq0 * 3;
 #pragma unroll
@@ -294,7 +294,7 @@ template <int LPP, bool NT, int CB, int KV>
 __global__ __launch_bounds__(1024) void gg_gradient_dma_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
     const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
-    double *__restrict__ grad /*[nall][21]*/) {
+    double *__restrict__ grad /*[nall][21]*/, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
   const cfdp_tile_desc td = tiles[t];
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(1024) void gg_gradient_dma_kernel(
   __syncthreads();  // vmcnt(0) + barrier: every wave's pieces have landed
   const int var_off = CB * nthr * 16;
   double *stage = reinterpret_cast<double *>(smem + (size_t)(CB + KV) * nthr * 16);
-  grad_tile_compute<LPP, NT>(smem, td, tid, grad, stage, 0, var_off);
+  grad_tile_compute<LPP, NT>(smem, td, tid, grad, stage, dbg, var_off);
 }
 
 // Pipelined form: persistent workgroups walk a contiguous run of tiles with two LDS buffers.
@@ -611,7 +611,7 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
   if (block > 1024) return hipErrorInvalidConfiguration;
   const size_t buf = (lds + 15) & ~(size_t)15;
   lds = buf;
-  const size_t stage_bytes = (size_t)(block / lanes) * 21 * 8;  // one 168-byte row per point slot
+  const size_t stage_bytes = (gg_debug_flags & 64) ? 0 : (size_t)(block / lanes) * 21 * 8;  // one 168-byte row per point slot
   if (pipeline && 2 * buf + stage_bytes <= 160 * 1024 && (long)max_halo * 4 <= (long)GG_HMAX * block) {
     // persistent grid: as many workgroups per CU as LDS (two buffers each) and waves allow
     int per_cu = (int)((160 * 1024) / (2 * buf + stage_bytes));
@@ -640,9 +640,9 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
     const size_t dma_lds = (size_t)((CB) + (KV)) * block * 16 + stage_bytes;                      \
     if (dma_lds > 160 * 1024) break;                                                              \
     if (nt) hipLaunchKernelGGL((gg_gradient_dma_kernel<8, true, CB, KV>), dim3(ntiles), dim3(block),  \
-                               dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad); \
+                               dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags); \
     else hipLaunchKernelGGL((gg_gradient_dma_kernel<8, false, CB, KV>), dim3(ntiles), dim3(block),    \
-                            dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad); \
+                            dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags); \
     return hipGetLastError();                                                                     \
   } while (0)
     if (cb >= 1 && kv >= 1 && kv <= 2) {
