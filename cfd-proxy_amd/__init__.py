@@ -225,6 +225,8 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_rank_gradients.argtypes = [P(vp), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_rank_flux.argtypes = [P(vp), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_sync_group.argtypes = [P(vp), C.c_int]
+    lib.cfdp_gpu_step_pre.argtypes = [vp, C.c_int, C.c_int]
+    lib.cfdp_gpu_step_post.argtypes = [vp, C.c_int, C.c_int]
     lib.cfdp_gpu_time_kernels.argtypes = [vp, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]
     lib.cfdp_gpu_run_iterations.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]
     lib.cfdp_gpu_counts.argtypes = [vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
@@ -594,6 +596,12 @@ class GpuPartition:
 
     def unpack(self, dev_ptr: int, stream: int = 0) -> None:
         self._ck(self.lib.cfdp_gpu_unpack(self.h, C.c_void_p(dev_ptr), C.c_void_p(stream)))
+
+    def step_pre(self, with_exchange: bool, overlap: bool) -> None:
+        self._ck(self.lib.cfdp_gpu_step_pre(self.h, int(with_exchange), int(overlap)))
+
+    def step_post(self, with_flux: bool = True, flux_mode: int = FLUX_CONSISTENT) -> None:
+        self._ck(self.lib.cfdp_gpu_step_post(self.h, int(with_flux), flux_mode))
 
     def sync(self) -> None:
         self._ck(self.lib.cfdp_gpu_sync(self.h))

@@ -55,6 +55,7 @@ struct cfdp_gpu {
   int pipeline = -1;           // -1: auto; 0: one workgroup per tile; k: persistent LDS-DMA kernel, <= k WG/CU
   int grad_lanes = 8, flux_lanes = 8;
   bool pending_exchange = false;
+  bool streams_exported = false;  // handed to the caller: not destroyed with the context
   hipGraphExec_t graph = nullptr;
   int graph_iters = 0, graph_flux = -1, graph_mode = -1, graph_gl = 0, graph_fl = 0;
 
@@ -115,8 +116,10 @@ void cfdp_gpu_destroy(cfdp_gpu *g) {
   (void)hipSetDevice(g->device);
   (void)hipDeviceSynchronize();
   free_device(g);
-  if (g->s_main) (void)hipStreamDestroy(g->s_main);
-  if (g->s_comm) (void)hipStreamDestroy(g->s_comm);
+  if (!g->streams_exported) {  // exported streams may still be referenced by the caller's runtime
+    if (g->s_main) (void)hipStreamDestroy(g->s_main);
+    if (g->s_comm) (void)hipStreamDestroy(g->s_comm);
+  }
   for (hipEvent_t e : {g->ev_a, g->ev_b, g->ev_pack, g->ev_senddone, g->ev_fluxdone})
     if (e) (void)hipEventDestroy(e);
   delete g;
@@ -340,7 +343,10 @@ int cfdp_gpu_sync(cfdp_gpu *g) {
   return 0;
 }
 
-void *cfdp_gpu_stream(cfdp_gpu *g, int which) { return which ? g->s_comm : g->s_main; }
+void *cfdp_gpu_stream(cfdp_gpu *g, int which) {
+  g->streams_exported = true;  // a foreign runtime may keep references (events, allocator bookkeeping)
+  return which ? g->s_comm : g->s_main;
+}
 int cfdp_gpu_npartners(const cfdp_gpu *g) { return (int)g->partner.size(); }
 int cfdp_gpu_partner_rank(const cfdp_gpu *g, int s) {
   return (s >= 0 && s < (int)g->partner.size()) ? g->partner[s] : -1;
@@ -364,6 +370,39 @@ int cfdp_gpu_counts(const cfdp_gpu *g, int *nown, int *nall, int *nsend, int *nr
   if (nall) *nall = g->nall;
   if (nsend) *nsend = g->send_off.back();
   if (nrecv) *nrecv = g->recv_off.back();
+  return 0;
+}
+
+// --------------------------------------------------- one rank per process: step brackets
+// The caller owns the transport (e.g. RCCL send/recv enqueued on this context's comm stream
+// between the two calls); these two calls enqueue everything else of one iteration, so a
+// host pays two ABI calls + one communication call per step.
+//   pre : [boundary tiles -> pack -> ev_pack] on main; comm waits ev_pack and the previous
+//         flux (ghost rows are still being read); interior tiles on main
+//   post: main waits for everything enqueued on comm so far; flux; ev_fluxdone
+int cfdp_gpu_step_pre(cfdp_gpu *g, int with_exchange, int overlap) {
+  NEED_UPLOAD(g);
+  const bool comm = with_exchange && !g->partner.empty();
+  g->pending_exchange = comm;
+  if (!comm) return launch_grad(g, CFDP_TILES_ALL, g->s_main);
+  if (launch_grad(g, overlap ? CFDP_TILES_BOUNDARY : CFDP_TILES_ALL, g->s_main)) return 1;
+  HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), g->d_grad, g->d_sendbuf, g->s_main));
+  HIP_TRY(hipEventRecord(g->ev_pack, g->s_main));
+  HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_pack, 0));
+  HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fluxdone, 0));
+  if (overlap && launch_grad(g, CFDP_TILES_INTERIOR, g->s_main)) return 1;
+  return 0;
+}
+
+int cfdp_gpu_step_post(cfdp_gpu *g, int with_flux, int flux_mode) {
+  NEED_UPLOAD(g);
+  if (g->pending_exchange) {
+    HIP_TRY(hipEventRecord(g->ev_senddone, g->s_comm));
+    HIP_TRY(hipStreamWaitEvent(g->s_main, g->ev_senddone, 0));
+  }
+  g->pending_exchange = false;
+  if (with_flux && launch_flux(g, flux_mode, g->s_main)) return 1;
+  HIP_TRY(hipEventRecord(g->ev_fluxdone, g->s_main));
   return 0;
 }
 

@@ -117,10 +117,10 @@ class RankSolver:
         self.send_t = torch.empty(max(self.nsend, 1) * ROWLEN, dtype=torch.float64, device=self.device)
         self.gpu.bind_grad(self.grad_t.data_ptr())
         self.gpu.bind_sendbuf(self.send_t.data_ptr())
-        self.s_main = torch.cuda.Stream(device=self.device)
-        self.s_comm = torch.cuda.Stream(device=self.device)
-        self.ev_pack = torch.cuda.Event()
-        self.ev_flux = torch.cuda.Event()
+        # the context's own HIP streams, seen from torch (the transport enqueues on the comm stream;
+        # all stream ordering of an iteration lives in cfdp_gpu_step_pre/_post)
+        self.s_main = torch.cuda.ExternalStream(self.gpu.stream(0), device=self.device)
+        self.s_comm = torch.cuda.ExternalStream(self.gpu.stream(1), device=self.device)
         self.send_views, self.recv_views = [], []
         so = ro = 0
         for s in range(len(self.partners)):
@@ -137,14 +137,10 @@ class RankSolver:
 
     # ------------------------------------------------------------------------------ pieces
     def _exchange(self) -> None:
-        """halo exchange on the comm stream; the caller has recorded ev_pack on s_main"""
+        """halo exchange, enqueued on the context's comm stream (step_pre has made that stream wait
+        for the pack and for the previous flux, step_post makes the flux wait for it)"""
         torch, dist = self.torch, self.dist
-        if not self.partners or self.world == 1:
-            return
         with torch.cuda.stream(self.s_comm):
-            self.s_comm.wait_event(self.ev_pack)
-            # ghost rows are still read by the previous flux kernel (write-after-read)
-            self.s_comm.wait_event(self.ev_flux)
             if self.transport == "rccl":
                 ops = []
                 for s, peer in enumerate(self.partners):
@@ -171,22 +167,13 @@ class RankSolver:
 
     def step(self, with_exchange: bool = True, overlap: bool = True, with_flux: bool = True,
              flux_mode: int = FLUX_CONSISTENT) -> None:
-        """one iteration = what test_solver times (reference src/solver.c:48-54)"""
-        sm = self.s_main.cuda_stream
+        """one iteration = what test_solver times (reference src/solver.c:48-54): two ABI calls
+        around one communication call"""
         comm = with_exchange and self.world > 1 and bool(self.partners)
-        if not comm:
-            self.gpu.gradients(TILES_ALL, sm)
-        else:
-            self.gpu.gradients(TILES_BOUNDARY if overlap else TILES_ALL, sm)
-            self.gpu.pack(sm)
-            self.ev_pack.record(self.s_main)
-            if overlap:
-                self.gpu.gradients(TILES_INTERIOR, sm)
+        self.gpu.step_pre(comm, overlap)
+        if comm:
             self._exchange()
-            self.s_main.wait_stream(self.s_comm)
-        if with_flux:
-            self.gpu.flux(flux_mode, sm)
-        self.ev_flux.record(self.s_main)
+        self.gpu.step_post(with_flux, flux_mode)
 
     def synchronize(self) -> None:
         self.torch.cuda.synchronize(self.device)

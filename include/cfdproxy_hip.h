@@ -101,6 +101,14 @@ int  cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, 
 int  cfdp_gpu_rank_flux(cfdp_gpu **ranks, int G, int b, int with_flux, int flux_mode);
 int  cfdp_gpu_sync_group(cfdp_gpu **ranks, int G);
 
+/* one rank per process: the two brackets of an iteration around the caller's transport.
+ * Between them the caller enqueues its sends (from cfdp_gpu_send_ptr) and receives (into
+ * cfdp_gpu_recv_ptr) on cfdp_gpu_stream(g, 1); pre() has made that stream wait for the
+ * pack, post() makes the flux wait for it.  Replaces the send_fn/exch_fn call-backs of
+ * the colour iterator (src/rangelist.c:838-889) by stream order.                         */
+int  cfdp_gpu_step_pre(cfdp_gpu *g, int with_exchange, int overlap);
+int  cfdp_gpu_step_post(cfdp_gpu *g, int with_flux, int flux_mode);
+
 /* measurement: `iters` back-to-back launches bracketed by HIP events on the context's
  * main stream; average milliseconds per launch (gradient over all tiles; flux)           */
 int  cfdp_gpu_time_kernels(cfdp_gpu *g, int iters, int flux_mode, float *ms_grad, float *ms_flux);
