@@ -219,6 +219,28 @@ def main() -> None:
                                    "sample": f"same 64^3 merged mesh, {args.cpu_samples} samples x 25 iterations "
                                              f"(gradients+flux), median; oracle/cpu_ref.c OpenMP",
                                    "gradient_only_iterations_per_s": 25.0 / gsamples[len(gsamples) // 2]}
+            # the compiled reference itself (oracle/_ref/ref_dump, built in the build container from the
+            # reference's own sources, see oracle/Makefile), timed on the same mesh written as ONE
+            # dualgrid file; reported next to the port so that the two can be compared
+            ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+            if os.path.exists(ref_bin):
+                import re
+                import subprocess
+                import tempfile
+                try:
+                    with tempfile.TemporaryDirectory() as tmp:
+                        part.write(os.path.join(tmp, "merged_domain_0_lvl_2"))
+                        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="true")
+                        r = subprocess.run([ref_bin, "time", os.path.join(tmp, "merged"), "2", str(args.cpu_samples), "1"],
+                                           env=env, capture_output=True, text=True, timeout=300)
+                    m = re.search(r"median_s=([0-9.]+)", r.stdout)
+                    if r.returncode == 0 and m:
+                        out["cpu_baseline"]["reference_binary"] = {
+                            "value": 25.0 / float(m.group(1)), "unit": "iterations/s", "cores": cores, "kind": "reference",
+                            "sample": f"compiled reference (comm_free, gradients+flux), {args.cpu_samples} samples x 25 "
+                                      f"iterations, median, same mesh as one dualgrid file"}
+                except Exception as e:  # the baseline is optional; the bench line must still print
+                    out["cpu_baseline"]["reference_binary_error"] = str(e)[:200]
     if rank == 0:
         print(json.dumps(out))
     solver.close()
