@@ -50,7 +50,8 @@ def build(verbose: bool = False) -> None:
 
 
 def _load(name: str) -> C.CDLL:
-    path = os.path.join(_HERE, "lib", name)
+    # CFDP_LIBDIR: load a differently built library (kernel experiments); default = in-tree lib/
+    path = os.path.join(os.environ.get("CFDP_LIBDIR") or os.path.join(_HERE, "lib"), name)
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `make -C cfd-proxy_amd` (or __graft_entry__.build())")
     return C.CDLL(path, mode=C.RTLD_GLOBAL)

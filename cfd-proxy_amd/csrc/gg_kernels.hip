@@ -63,6 +63,12 @@ template <bool NT> __device__ __forceinline__ void st_row(double v, double *p) {
   else *p = v;
 }
 
+#ifndef GG_DEEP_BATCH
+#define GG_DEEP_BATCH 7
+#endif
+#ifndef GG_WAVES_EU
+#define GG_WAVES_EU 4
+#endif
 template <int LPP> struct grad_cfg;
 template <> struct grad_cfg<1> { static constexpr int NE = 7; };
 template <> struct grad_cfg<2> { static constexpr int NE = 4; };
@@ -151,7 +157,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     const double *var_eq0 = var_l + eq0;
     int k = ks;
     if constexpr (NE <= 2)  // few registers per incidence: deeper batches (a point has ~14 incidences)
-      for (; k + 7 <= ke; k += 7) grad_batch<7, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
+      for (; k + GG_DEEP_BATCH <= ke; k += GG_DEEP_BATCH) grad_batch<GG_DEEP_BATCH, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
     for (; k + 4 <= ke; k += 4) grad_batch<4, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
     if (k + 2 <= ke) {
       grad_batch<2, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
@@ -163,7 +169,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   // ---- write the finished rows.  A lane holds NE*3 doubles of a 168-byte row; storing them
   // directly is 8 bytes per lane at a 24..168-byte stride (measured: the stores alone then
   // take longer than streaming the whole tile in).  Instead each wave transposes its PPW rows
-  // through a private LDS slab and writes them as one contiguous run, 8 bytes per lane x 64
+  // through a private LDS slab and writes them as contiguous runs, 8 bytes per lane x 64
   // lanes per instruction.  Wave-private slab => no workgroup barrier.
   const int wave = tid >> 6, lane = tid & 63;
   const int wp = wave * PPW;                                    // first point of this wave
@@ -183,21 +189,30 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     }
     return;
   }
-  double *slab = stage + wave * (PPW * 21);
-  if (active) {
-    double *o = slab + (li - wp) * 21 + eq0 * 3;
+  // 8 points (1344 bytes) per pass: the slab stays small enough for four workgroups per CU
+  constexpr int SPP = 8, NPASS = PPW / SPP;
+  double *slab = stage + wave * (SPP * 21);
 #pragma unroll
-    for (int j = 0; j < NE; j++)
-      if (eq0 + j < 7) {
-        o[3 * j + 0] = acc[j][0] * tmp;
-        o[3 * j + 1] = acc[j][1] * tmp;
-        o[3 * j + 2] = acc[j][2] * tmp;
-      }
+  for (int h = 0; h < NPASS; h++) {
+    const int lp = li - wp - h * SPP;  // this lane's point within the pass
+    if (active && lp >= 0 && lp < SPP) {
+      double *o = slab + lp * 21 + eq0 * 3;
+#pragma unroll
+      for (int j = 0; j < NE; j++)
+        if (eq0 + j < 7) {
+          o[3 * j + 0] = acc[j][0] * tmp;
+          o[3 * j + 1] = acc[j][1] * tmp;
+          o[3 * j + 2] = acc[j][2] * tmp;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // LDS executes a wave's accesses in order; keep the compiler in order too
+    int nvh = nv - h * SPP;
+    nvh = nvh < 0 ? 0 : (nvh > SPP ? SPP : nvh);
+    double *g = grad + (size_t)(td.pstart + wp + h * SPP) * 21;
+    const int nd = nvh * 21;
+    for (int c = lane; c < nd; c += 64) st_row<NT>(slab[c], &g[c]);
+    __builtin_amdgcn_wave_barrier();
   }
-  __builtin_amdgcn_wave_barrier();  // LDS executes a wave's accesses in order; keep the compiler in order too
-  double *g = grad + (size_t)(td.pstart + wp) * 21;
-  const int nd = nv * 21;
-  for (int c = lane; c < nd; c += 64) st_row<NT>(slab[c], &g[c]);
 }
 
 // Simple form: one workgroup per tile, stage through registers, barrier, compute.
@@ -275,11 +290,9 @@ __device__ __forceinline__ void dma_stage_tile(unsigned char *buf, const cfdp_ti
     else glds16(b4 + q, buf + (size_t)q0 * 16);
   }
   // (3) wait for the index loads only: the CB DMA instructions issued after them stay in flight
-  if constexpr (KV == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hrow[0]) : "n"(CB) : "memory");
-  if constexpr (KV == 2)
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(hrow[0]), "+v"(hrow[1]) : "n"(CB) : "memory");
-  if constexpr (KV == 3)
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(hrow[0]), "+v"(hrow[1]), "+v"(hrow[2]) : "n"(CB) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CB) : "memory");
+#pragma unroll
+  for (int k = 0; k < KV; k++) asm volatile("" : "+v"(hrow[k]));  // uses stay behind the wait
   // (4) var rows: own rows by position, halo rows by number; 4 lanes per 64-byte row
   unsigned char *vbuf = buf + (size_t)CB * nthr * 16;
 #pragma unroll
@@ -291,7 +304,8 @@ __device__ __forceinline__ void dma_stage_tile(unsigned char *buf, const cfdp_ti
 }
 
 template <int LPP, bool NT, int CB, int KV>
-__global__ __launch_bounds__(1024) void gg_gradient_dma_kernel(
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LPP == 8 ? GG_WAVES_EU : LPP == 4 ? 4 : 2)))
+void gg_gradient_dma_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
     const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
     double *__restrict__ grad /*[nall][21]*/, int dbg) {
@@ -554,11 +568,9 @@ __global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
     else glds16(b4 + q, smem + (size_t)q0 * 16);
   }
   // (3) only the index loads are awaited; the CB blob pieces stay in flight
-  if constexpr (KV == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(hrow[0]) : "n"(CB) : "memory");
-  if constexpr (KV == 2)
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(hrow[0]), "+v"(hrow[1]) : "n"(CB) : "memory");
-  if constexpr (KV == 3)
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(hrow[0]), "+v"(hrow[1]), "+v"(hrow[2]) : "n"(CB) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CB) : "memory");
+#pragma unroll
+  for (int k = 0; k < KV; k++) asm volatile("" : "+v"(hrow[k]));  // uses stay behind the wait
   if constexpr (KV == 4)
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(hrow[0]), "+v"(hrow[1]), "+v"(hrow[2]), "+v"(hrow[3]) : "n"(CB) : "memory");
   // (4) gradient rows: first 80 bytes of each row
@@ -611,7 +623,7 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
   if (block > 1024) return hipErrorInvalidConfiguration;
   const size_t buf = (lds + 15) & ~(size_t)15;
   lds = buf;
-  const size_t stage_bytes = (gg_debug_flags & 64) ? 0 : (size_t)(block / lanes) * 21 * 8;  // one 168-byte row per point slot
+  const size_t stage_bytes = (gg_debug_flags & 64) ? 0 : (size_t)(block / 64) * 8 * 21 * 8;  // 8 rows of 168 bytes per wave
   if (pipeline && 2 * buf + stage_bytes <= 160 * 1024 && (long)max_halo * 4 <= (long)GG_HMAX * block) {
     // persistent grid: as many workgroups per CU as LDS (two buffers each) and waves allow
     int per_cu = (int)((160 * 1024) / (2 * buf + stage_bytes));
@@ -635,16 +647,17 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
   if (lanes == 8 && !(gg_debug_flags & 16)) {
     const int cb = (max_blob_qw + block - 1) / block;                       // blob pieces per wave
     const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;      // var-row pieces per wave
-#define LAUNCH_GRAD_DMA(CB, KV)                                                                   \
+#define LAUNCH_GRAD_DMA_L(L, CB, KV)                                                              \
   do {                                                                                            \
     const size_t dma_lds = (size_t)((CB) + (KV)) * block * 16 + stage_bytes;                      \
     if (dma_lds > 160 * 1024) break;                                                              \
-    if (nt) hipLaunchKernelGGL((gg_gradient_dma_kernel<8, true, CB, KV>), dim3(ntiles), dim3(block),  \
+    if (nt) hipLaunchKernelGGL((gg_gradient_dma_kernel<L, true, CB, KV>), dim3(ntiles), dim3(block),  \
                                dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags); \
-    else hipLaunchKernelGGL((gg_gradient_dma_kernel<8, false, CB, KV>), dim3(ntiles), dim3(block),    \
+    else hipLaunchKernelGGL((gg_gradient_dma_kernel<L, false, CB, KV>), dim3(ntiles), dim3(block),    \
                             dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags); \
     return hipGetLastError();                                                                     \
   } while (0)
+#define LAUNCH_GRAD_DMA(CB, KV) LAUNCH_GRAD_DMA_L(8, CB, KV)
     if (cb >= 1 && kv >= 1 && kv <= 2) {
       if (cb <= 2) LAUNCH_GRAD_DMA(2, 2);
       if (cb <= 3) LAUNCH_GRAD_DMA(3, 2);
@@ -657,6 +670,23 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
     }
 #undef LAUNCH_GRAD_DMA
   }
+  if (lanes == 4 && !(gg_debug_flags & 16)) {  // two equations per lane: half the LDS reads per point
+    const int cb = (max_blob_qw + block - 1) / block;
+    const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;
+    if (cb >= 1 && cb <= 5 && kv >= 1 && kv <= 3) LAUNCH_GRAD_DMA_L(4, 5, 3);
+    if (cb >= 1 && cb <= 5 && kv >= 1 && kv <= 4) LAUNCH_GRAD_DMA_L(4, 5, 4);
+    if (cb >= 1 && cb <= 6 && kv >= 1 && kv <= 5) LAUNCH_GRAD_DMA_L(4, 6, 5);
+    if (cb >= 1 && cb <= 8 && kv >= 1 && kv <= 6) LAUNCH_GRAD_DMA_L(4, 8, 6);
+  }
+  if (lanes == 2 && !(gg_debug_flags & 16)) {  // four equations per lane
+    const int cb = (max_blob_qw + block - 1) / block;
+    const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;
+    if (cb >= 1 && cb <= 10 && kv >= 1 && kv <= 6) LAUNCH_GRAD_DMA_L(2, 10, 6);
+    if (cb >= 1 && cb <= 10 && kv >= 1 && kv <= 8) LAUNCH_GRAD_DMA_L(2, 10, 8);
+    if (cb >= 1 && cb <= 12 && kv >= 1 && kv <= 8) LAUNCH_GRAD_DMA_L(2, 12, 8);
+    if (cb >= 1 && cb <= 16 && kv >= 1 && kv <= 12) LAUNCH_GRAD_DMA_L(2, 16, 12);
+  }
+#undef LAUNCH_GRAD_DMA_L
   switch (lanes) {
     case 1: if (nt) LAUNCH_GRAD(1, true); else LAUNCH_GRAD(1, false); break;
     case 2: if (nt) LAUNCH_GRAD(2, true); else LAUNCH_GRAD(2, false); break;
@@ -788,6 +818,22 @@ hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
   SET_LDS((gg_gradient_dma_kernel<8, true, 4, 3>), all)
   SET_LDS((gg_gradient_dma_kernel<8, false, 6, 3>), all)
   SET_LDS((gg_gradient_dma_kernel<8, true, 6, 3>), all)
+  SET_LDS((gg_gradient_dma_kernel<4, false, 5, 3>), all)
+  SET_LDS((gg_gradient_dma_kernel<4, true, 5, 3>), all)
+  SET_LDS((gg_gradient_dma_kernel<2, false, 10, 6>), all)
+  SET_LDS((gg_gradient_dma_kernel<2, true, 10, 6>), all)
+  SET_LDS((gg_gradient_dma_kernel<2, false, 10, 8>), all)
+  SET_LDS((gg_gradient_dma_kernel<2, true, 10, 8>), all)
+  SET_LDS((gg_gradient_dma_kernel<2, false, 12, 8>), all)
+  SET_LDS((gg_gradient_dma_kernel<2, true, 12, 8>), all)
+  SET_LDS((gg_gradient_dma_kernel<2, false, 16, 12>), all)
+  SET_LDS((gg_gradient_dma_kernel<2, true, 16, 12>), all)
+  SET_LDS((gg_gradient_dma_kernel<4, false, 5, 4>), all)
+  SET_LDS((gg_gradient_dma_kernel<4, true, 5, 4>), all)
+  SET_LDS((gg_gradient_dma_kernel<4, false, 6, 5>), all)
+  SET_LDS((gg_gradient_dma_kernel<4, true, 6, 5>), all)
+  SET_LDS((gg_gradient_dma_kernel<4, false, 8, 6>), all)
+  SET_LDS((gg_gradient_dma_kernel<4, true, 8, 6>), all)
   SET_LDS((gg_gradient_pipe_kernel<1, false>), all)
   SET_LDS((gg_gradient_pipe_kernel<1, true>), all)
   SET_LDS((gg_gradient_pipe_kernel<2, false>), all)

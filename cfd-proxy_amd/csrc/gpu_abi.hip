@@ -53,7 +53,7 @@ struct cfdp_gpu {
   int max_halo[2] = {0, 0}, max_blob[2] = {0, 0};  // per tile class: halo rows, blob 16-byte units
   bool streaming = false;      // per-iteration bytes exceed the Infinity Cache: non-temporal blobs/rows
   int pipeline = -1;           // -1: auto; 0: one workgroup per tile; k: persistent LDS-DMA kernel, <= k WG/CU
-  int grad_lanes = 8, flux_lanes = 8;
+  int grad_lanes = 4, flux_lanes = 8;
   bool pending_exchange = false;
   bool streams_exported = false;  // handed to the caller: not destroyed with the context
   hipGraphExec_t graph = nullptr;
@@ -272,7 +272,7 @@ int cfdp_gpu_set_pipeline(cfdp_gpu *g, int max_wg_per_cu) {
 int cfdp_gpu_set_variant(cfdp_gpu *g, int grad_lanes, int flux_lanes) {
   if (!g) return fail("null context");
   auto ok = [](int l) { return l == 1 || l == 2 || l == 4 || l == 8; };
-  if (grad_lanes == 0) grad_lanes = 8;
+  if (grad_lanes == 0) grad_lanes = 4;
   if (flux_lanes == 0) flux_lanes = 8;
   if (!ok(grad_lanes) || !ok(flux_lanes)) return fail("lanes per point must be 1, 2, 4 or 8");
   g->grad_lanes = grad_lanes;

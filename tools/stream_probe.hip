@@ -2,6 +2,7 @@
 // (measurement helper, not part of the product)   hipcc --offload-arch=gfx950 -O3 stream_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -35,8 +36,11 @@ __global__ void k_mix_tiles(const uint4* __restrict__ a, const uint4* __restrict
     }
   }
 }
-int main() {
-  const size_t nA = (360u << 20) / 16, nO = (352u << 20) / 16;  // 360 MB per read stream, 352 MB written
+int main(int argc, char **argv) {
+  // default: 360 MB per read stream, 352 MB written (the 128^3 mix); `stream_probe 45` = the
+  // Infinity-Cache-resident 64^3 mix
+  const size_t mb = argc > 1 ? (size_t)atoi(argv[1]) : 360;
+  const size_t nA = (mb << 20) / 16, nO = nA;
   uint4 *a, *b, *o, *sink;
   CK(hipMalloc(&a, nA * 16)); CK(hipMalloc(&b, nA * 16)); CK(hipMalloc(&o, nA * 16)); CK(hipMalloc(&sink, 64));
   CK(hipMemset(a, 1, nA * 16)); CK(hipMemset(b, 2, nA * 16)); CK(hipMemset(o, 0, nA * 16));
@@ -48,10 +52,10 @@ int main() {
     printf("%-28s %8.1f us  %7.0f GB/s\n", name, ms * 1e3, bytes / ms / 1e6);
   };
   for (int blocks : {2048, 8192}) {
-    printf("blocks %d x 256\n", blocks);
-    timeit("read 720 MB", 2.0 * nA * 16, [&] { k_read<<<blocks, 256>>>(a, nA, sink); k_read<<<blocks, 256>>>(b, nA, sink); });
-    timeit("write 352 MB", (double)nO * 16, [&] { k_write<<<blocks, 256>>>(o, nO); });
-    timeit("mix r720 w360", 3.0 * nA * 16, [&] { k_mix<<<blocks, 256>>>(a, b, o, nA); });
+    printf("blocks %d x 256, %zu MB per stream\n", blocks, mb);
+    timeit("read 2 streams", 2.0 * nA * 16, [&] { k_read<<<blocks, 256>>>(a, nA, sink); k_read<<<blocks, 256>>>(b, nA, sink); });
+    timeit("write 1 stream", (double)nO * 16, [&] { k_write<<<blocks, 256>>>(o, nO); });
+    timeit("mix 2 read : 1 write", 3.0 * nA * 16, [&] { k_mix<<<blocks, 256>>>(a, b, o, nA); });
   }
   for (int chunk : {1024, 2048, 4096})
     timeit(chunk == 1024 ? "mix tiles 16KB" : chunk == 2048 ? "mix tiles 32KB" : "mix tiles 64KB", 3.0 * nA * 16,
