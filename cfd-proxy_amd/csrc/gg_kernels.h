@@ -6,12 +6,26 @@
 
 #include "cfdproxy_host.h"  // cfdp_tile_desc
 
+// grad in HBM: one allocation of nall*21 doubles.  An owned row's 21 doubles are split into
+// part A (doubles 0..9: the 3x3 velocity-gradient block + 1) and part B (doubles 10..20);
+// ghost rows stay whole, in message order:  [A: nown x 10][ghost: nghost x 21][B: nown x 11]
+struct gg_grad_view {
+  double *a, *ghost, *b;
+  static gg_grad_view of(double *base, int nown, int nall) {
+    gg_grad_view v;
+    v.a = base;
+    v.ghost = base + (size_t)nown * 10;
+    v.b = v.ghost + (size_t)(nall - nown) * 21;
+    return v;
+  }
+};
+
 struct gg_args {
   const cfdp_tile_desc *tiles;  // device copies
   const uint4 *blob;
   const int *halo_idx;
   const double *var;            // [nall][8]: 7 variables + the dual volume in slot 7
-  double *grad;                 // [nall][21]
+  gg_grad_view grad;
   double *flux;                 // [nown][3]
   int nown;
 };
@@ -24,9 +38,9 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
 hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_begin, int ntiles,
                           int tile_points, size_t lds, int max_halo, int max_blob_qw, bool nt,
                           hipStream_t stream);
-hipError_t gg_launch_pack(const int *send_idx, int nsend, const double *grad, double *sendbuf,
+hipError_t gg_launch_pack(const int *send_idx, int nsend, const gg_grad_view &grad, double *sendbuf,
                           hipStream_t stream);
-hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, int nown, double *grad,
+hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view &grad,
                             hipStream_t stream);
 extern int gg_debug_flags;
 hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux);

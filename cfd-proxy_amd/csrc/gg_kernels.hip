@@ -27,6 +27,14 @@
 //   * deterministic: a point's faces are added in file order, independent of the launch.
 //
 // Algorithmic bytes per launch: 32*F + 232*P_own + 56*P_add.
+//
+// grad in HBM (one allocation of nall*21 doubles, see gg_grad_view in gg_kernels.h): the 21
+// doubles of an OWNED row are split into part A = doubles 0..9 (the 3x3 velocity-gradient
+// block the flux loop reads, + 1) and part B = doubles 10..20, stored as
+//   [A: nown x 10][ghost rows: nghost x 21, message order][B: nown x 11]
+// so that the flux kernel streams contiguous, 16-byte aligned 80-byte rows instead of the
+// first 80 bytes of every 168-byte row (measured: its gradient-row reads were 3x algorithmic),
+// while the halo exchange still delivers whole 168-byte rows straight into the ghost block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -125,7 +133,8 @@ __device__ __forceinline__ void grad_batch(const uint32_t *__restrict__ inc, int
 
 template <int LPP, bool NT>
 __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, const cfdp_tile_desc &td,
-                                                  int tid, double *__restrict__ grad,
+                                                  int tid, double *__restrict__ gradA,
+                                                  double *__restrict__ gradB,
                                                   double *__restrict__ stage, int dbg = 0,
                                                   int var_off = -1) {
   constexpr int NE = grad_cfg<LPP>::NE;
@@ -178,39 +187,48 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   const bool faceless = active && ke0 == ks;
   if (__any(faceless) || (dbg & 64)) {  // rare: fall back to per-lane stores that can skip a row
     if (active && !faceless) {
-      double *g = grad + (size_t)(td.pstart + li) * 21 + eq0 * 3;
+      double *ga = gradA + (size_t)(td.pstart + li) * 10, *gb = gradB + (size_t)(td.pstart + li) * 11 - 10;
 #pragma unroll
       for (int j = 0; j < NE; j++)
         if (eq0 + j < 7) {
-          g[3 * j + 0] = acc[j][0] * tmp;
-          g[3 * j + 1] = acc[j][1] * tmp;
-          g[3 * j + 2] = acc[j][2] * tmp;
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const int d = (eq0 + j) * 3 + c;  // position in the 21-double row
+            (d < 10 ? ga : gb)[d] = acc[j][c] * tmp;
+          }
         }
     }
     return;
   }
-  // 8 points (1344 bytes) per pass: the slab stays small enough for four workgroups per CU
+  // 8 points (1344 bytes) per pass: the slab stays small enough for four workgroups per CU.
+  // Slab image of a pass: [A parts: 8 x 10][B parts: 8 x 11], the two runs it is stored as.
   constexpr int SPP = 8, NPASS = PPW / SPP;
   double *slab = stage + wave * (SPP * 21);
 #pragma unroll
   for (int h = 0; h < NPASS; h++) {
     const int lp = li - wp - h * SPP;  // this lane's point within the pass
     if (active && lp >= 0 && lp < SPP) {
-      double *o = slab + lp * 21 + eq0 * 3;
+      double *oa = slab + lp * 10, *ob = slab + SPP * 10 + lp * 11 - 10;
 #pragma unroll
       for (int j = 0; j < NE; j++)
         if (eq0 + j < 7) {
-          o[3 * j + 0] = acc[j][0] * tmp;
-          o[3 * j + 1] = acc[j][1] * tmp;
-          o[3 * j + 2] = acc[j][2] * tmp;
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const int d = (eq0 + j) * 3 + c;
+            (d < 10 ? oa : ob)[d] = acc[j][c] * tmp;
+          }
         }
     }
     __builtin_amdgcn_wave_barrier();  // LDS executes a wave's accesses in order; keep the compiler in order too
     int nvh = nv - h * SPP;
     nvh = nvh < 0 ? 0 : (nvh > SPP ? SPP : nvh);
-    double *g = grad + (size_t)(td.pstart + wp + h * SPP) * 21;
-    const int nd = nvh * 21;
-    for (int c = lane; c < nd; c += 64) st_row<NT>(slab[c], &g[c]);
+    const size_t p0 = (size_t)(td.pstart + wp + h * SPP);
+    double *ga = gradA + p0 * 10, *gb = gradB + p0 * 11;
+    const int na = nvh * 10, nd = nvh * 21;
+    for (int c = lane; c < nd; c += 64) {
+      if (c < na) st_row<NT>(slab[c], &ga[c]);
+      else st_row<NT>(slab[SPP * 10 + c - na], &gb[c - na]);
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -220,7 +238,7 @@ template <int LPP, bool NT>
 __global__ __launch_bounds__(1024) void gg_gradient_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
     const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
-    double *__restrict__ grad /*[nall][21]*/) {
+    double *__restrict__ gradA /*[nown][10]*/, double *__restrict__ gradB /*[nown][11]*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
@@ -245,7 +263,7 @@ __global__ __launch_bounds__(1024) void gg_gradient_kernel(
   }
   __syncthreads();
   double *stage = reinterpret_cast<double *>(smem + (size_t)td.blob_qw * 16 + (size_t)(npts + nhalo) * 64);
-  grad_tile_compute<LPP, NT>(smem, td, tid, grad, stage);
+  grad_tile_compute<LPP, NT>(smem, td, tid, gradA, gradB, stage);
 }
 
 // ---- fixed-count LDS-DMA staging ------------------------------------------------------------
@@ -308,7 +326,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LPP == 8 ?
 void gg_gradient_dma_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
     const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
-    double *__restrict__ grad /*[nall][21]*/, int dbg) {
+    double *__restrict__ gradA /*[nown][10]*/, double *__restrict__ gradB /*[nown][11]*/, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
   const cfdp_tile_desc td = tiles[t];
@@ -317,7 +335,7 @@ void gg_gradient_dma_kernel(
   __syncthreads();  // vmcnt(0) + barrier: every wave's pieces have landed
   const int var_off = CB * nthr * 16;
   double *stage = reinterpret_cast<double *>(smem + (size_t)(CB + KV) * nthr * 16);
-  grad_tile_compute<LPP, NT>(smem, td, tid, grad, stage, dbg, var_off);
+  grad_tile_compute<LPP, NT>(smem, td, tid, gradA, gradB, stage, dbg, var_off);
 }
 
 // Pipelined form: persistent workgroups walk a contiguous run of tiles with two LDS buffers.
@@ -381,8 +399,8 @@ template <int LPP, bool NT>
 __global__ __launch_bounds__(1024) void gg_gradient_pipe_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, int ntiles,
     const uint4 *__restrict__ blob, const int *__restrict__ halo_idx,
-    const double *__restrict__ var /*[nall][8]*/, double *__restrict__ grad /*[nall][21]*/,
-    int buf_bytes, int dbg) {
+    const double *__restrict__ var /*[nall][8]*/, double *__restrict__ gradA /*[nown][10]*/,
+    double *__restrict__ gradB /*[nown][11]*/, int buf_bytes, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
@@ -422,8 +440,8 @@ __global__ __launch_bounds__(1024) void gg_gradient_pipe_kernel(
       tnn = tiles[t + 2 * tstep];
       pipe_load_hrows(hrow, tnn, halo_idx, tid, nthr);  // used one iteration from now
     }
-    if (dbg & 2) grad_tile_compute<LPP, NT>(smem, td0, tid, grad, stage, dbg);  // timing experiment: buffer 0 only
-    else if (!(dbg & 1)) grad_tile_compute<LPP, NT>(bcur, td, tid, grad, stage, dbg);
+    if (dbg & 2) grad_tile_compute<LPP, NT>(smem, td0, tid, gradA, gradB, stage, dbg);  // timing experiment: buffer 0 only
+    else if (!(dbg & 1)) grad_tile_compute<LPP, NT>(bcur, td, tid, gradA, gradB, stage, dbg);
     __syncthreads();  // (a) everyone is done reading bcur, (b) tile t+1 has landed in bnxt
     td = tn;
     tn = tnn;
@@ -507,8 +525,8 @@ __device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, con
 template <int LPP, bool REFMODE, bool NT>
 __global__ __launch_bounds__(1024) void gg_flux_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
-    const int *__restrict__ halo_idx, const double *__restrict__ grad /*[nall][21]*/,
-    double *__restrict__ flux /*[nown][3]*/, int nown) {
+    const int *__restrict__ halo_idx, const double *__restrict__ gradA /*[nown][10]*/,
+    const double *__restrict__ ghost /*[nghost][21]*/, double *__restrict__ flux /*[nown][3]*/, int nown) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
   const cfdp_tile_desc td = tiles[t];
@@ -524,7 +542,7 @@ __global__ __launch_bounds__(1024) void gg_flux_kernel(
   for (int q = tid; q < (npts + nhalo) * 9; q += nthr) {
     const int r = q / 9, c = q - 9 * r;
     const int row = r < npts ? td.pstart + r : hid[r - npts];
-    g_l[r * 10 + c] = grad[(size_t)row * 21 + c];
+    g_l[r * 10 + c] = row < nown ? gradA[(size_t)row * 10 + c] : ghost[(size_t)(row - nown) * 21 + c];
   }
   __syncthreads();
 
@@ -532,13 +550,14 @@ __global__ __launch_bounds__(1024) void gg_flux_kernel(
 }
 
 // one workgroup per tile, fixed-count LDS-DMA staging (see gg_gradient_dma_kernel): the blob as CB
-// pieces per wave, the gradient rows as KV pieces per wave -- 5 pieces (80 bytes) of every
-// 168-byte row, own rows by position, halo rows by number
+// pieces per wave, the gradient rows as KV pieces per wave -- 5 pieces (80 bytes) per row: own
+// rows by position and owned halo rows by number from part A, ghost halo rows = the first 80
+// bytes of their 168-byte row in the ghost block
 template <int LPP, bool REFMODE, bool NT, int CB, int KV>
 __global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
-    const int *__restrict__ halo_idx, const double *__restrict__ grad /*[nall][21]*/,
-    double *__restrict__ flux /*[nown][3]*/, int nown) {
+    const int *__restrict__ halo_idx, const double *__restrict__ gradA /*[nown][10]*/,
+    const double *__restrict__ ghost /*[nghost][21]*/, double *__restrict__ flux /*[nown][3]*/, int nown) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
   const cfdp_tile_desc td = tiles[t];
@@ -571,16 +590,15 @@ __global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CB) : "memory");
 #pragma unroll
   for (int k = 0; k < KV; k++) asm volatile("" : "+v"(hrow[k]));  // uses stay behind the wait
-  if constexpr (KV == 4)
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(hrow[0]), "+v"(hrow[1]), "+v"(hrow[2]), "+v"(hrow[3]) : "n"(CB) : "memory");
-  // (4) gradient rows: first 80 bytes of each row
+  // (4) gradient rows, 80 bytes each
   unsigned char *gbuf = smem + (size_t)CB * nthr * 16;
-  const unsigned char *gbytes = reinterpret_cast<const unsigned char *>(grad);
+  const unsigned char *abytes = reinterpret_cast<const unsigned char *>(gradA);
+  const unsigned char *hbytes = reinterpret_cast<const unsigned char *>(ghost);
 #pragma unroll
   for (int k = 0; k < KV; k++) {
     const int row = rloc[k] < td.npts ? td.pstart + rloc[k] : hrow[k];
-    glds16(reinterpret_cast<const uint4 *>(gbytes + (size_t)row * 168 + part[k] * 16),
-           gbuf + (size_t)(w0 + k * nthr) * 16);
+    const unsigned char *src = row < nown ? abytes + (size_t)row * 80 : hbytes + (size_t)(row - nown) * 168;
+    glds16(reinterpret_cast<const uint4 *>(src + part[k] * 16), gbuf + (size_t)(w0 + k * nthr) * 16);
   }
   __syncthreads();
   flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<const double *>(gbuf), td, hid, tid, flux, nown);
@@ -588,20 +606,22 @@ __global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
 
 // --------------------------------------------------------------------------- pack/unpack
 __global__ __launch_bounds__(256) void gg_pack_kernel(const int *__restrict__ send_idx, int nsend,
-                                                      const double *__restrict__ grad,
+                                                      const double *__restrict__ gradA,
+                                                      const double *__restrict__ gradB,
                                                       double *__restrict__ sendbuf) {
   const int n = nsend * 21;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int j = i / 21, c = i - 21 * j;
-    sendbuf[i] = grad[(size_t)send_idx[j] * 21 + c];
+    const size_t p = (size_t)send_idx[j];  // send points are owned points
+    sendbuf[i] = c < 10 ? gradA[p * 10 + c] : gradB[p * 11 + c - 10];  // whole 168-byte rows on the wire
   }
 }
 
 __global__ __launch_bounds__(256) void gg_unpack_kernel(const double *__restrict__ recvbuf, int nrecv,
-                                                        int nown, double *__restrict__ grad) {
+                                                        double *__restrict__ ghost) {
   const int n = nrecv * 21;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    grad[(size_t)nown * 21 + i] = recvbuf[i];  // ghost rows are in message order (host/tiling.c)
+    ghost[i] = recvbuf[i];  // ghost rows are in message order (host/tiling.c)
 }
 
 // ------------------------------------------------------------------------------ launchers
@@ -609,11 +629,11 @@ int gg_debug_flags = 0;  // timing experiments only: 1 = skip arithmetic, 2 = sk
 
 #define LAUNCH_GRAD(L, N)                                                                         \
   hipLaunchKernelGGL((gg_gradient_kernel<L, N>), dim3(ntiles), dim3(block), lds + stage_bytes,   \
-                     stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad)
+                     stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b)
 #define LAUNCH_GRAD_PIPE(L, N)                                                                    \
   hipLaunchKernelGGL((gg_gradient_pipe_kernel<L, N>), dim3(nwg), dim3(block),                     \
                      2 * buf + stage_bytes, stream,                                            \
-                     a.tiles, tile_begin, ntiles, a.blob, a.halo_idx, a.var, a.grad, (int)buf, gg_debug_flags)
+                     a.tiles, tile_begin, ntiles, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b, (int)buf, gg_debug_flags)
 
 hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int ntiles,
                               int tile_points, size_t lds, int max_halo, int max_blob_qw,
@@ -652,9 +672,9 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
     const size_t dma_lds = (size_t)((CB) + (KV)) * block * 16 + stage_bytes;                      \
     if (dma_lds > 160 * 1024) break;                                                              \
     if (nt) hipLaunchKernelGGL((gg_gradient_dma_kernel<L, true, CB, KV>), dim3(ntiles), dim3(block),  \
-                               dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags); \
+                               dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b, gg_debug_flags); \
     else hipLaunchKernelGGL((gg_gradient_dma_kernel<L, false, CB, KV>), dim3(ntiles), dim3(block),    \
-                            dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags); \
+                            dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b, gg_debug_flags); \
     return hipGetLastError();                                                                     \
   } while (0)
 #define LAUNCH_GRAD_DMA(CB, KV) LAUNCH_GRAD_DMA_L(8, CB, KV)
@@ -699,7 +719,7 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
 
 #define LAUNCH_FLUX(L, R, N)                                                                      \
   hipLaunchKernelGGL((gg_flux_kernel<L, R, N>), dim3(ntiles), dim3(block), lds, stream, a.tiles,    \
-                     tile_begin, a.blob, a.halo_idx, a.grad, a.flux, a.nown)
+                     tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown)
 
 hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_begin, int ntiles,
                           int tile_points, size_t lds, int max_halo, int max_blob_qw, bool nt,
@@ -716,14 +736,14 @@ hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_be
     if (dma_lds > 160 * 1024) break;                                                              \
     if (refmode) {                                                                                \
       if (nt) hipLaunchKernelGGL((gg_flux_dma_kernel<8, true, true, CB, KV>), dim3(ntiles), dim3(block), dma_lds, \
-                                 stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad, a.flux, a.nown); \
+                                 stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown); \
       else hipLaunchKernelGGL((gg_flux_dma_kernel<8, true, false, CB, KV>), dim3(ntiles), dim3(block), dma_lds, \
-                              stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad, a.flux, a.nown); \
+                              stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown); \
     } else {                                                                                      \
       if (nt) hipLaunchKernelGGL((gg_flux_dma_kernel<8, false, true, CB, KV>), dim3(ntiles), dim3(block), dma_lds, \
-                                 stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad, a.flux, a.nown); \
+                                 stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown); \
       else hipLaunchKernelGGL((gg_flux_dma_kernel<8, false, false, CB, KV>), dim3(ntiles), dim3(block), dma_lds, \
-                              stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad, a.flux, a.nown); \
+                              stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown); \
     }                                                                                             \
     return hipGetLastError();                                                                     \
   } while (0)
@@ -762,23 +782,23 @@ hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_be
   return hipGetLastError();
 }
 
-hipError_t gg_launch_pack(const int *send_idx, int nsend, const double *grad, double *sendbuf,
+hipError_t gg_launch_pack(const int *send_idx, int nsend, const gg_grad_view &grad, double *sendbuf,
                           hipStream_t stream) {
   if (nsend <= 0) return hipSuccess;
   const int n = nsend * 21;
   int blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gg_pack_kernel, dim3(blocks), dim3(256), 0, stream, send_idx, nsend, grad, sendbuf);
+  hipLaunchKernelGGL(gg_pack_kernel, dim3(blocks), dim3(256), 0, stream, send_idx, nsend, grad.a, grad.b, sendbuf);
   return hipGetLastError();
 }
 
-hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, int nown, double *grad,
+hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view &grad,
                             hipStream_t stream) {
   if (nrecv <= 0) return hipSuccess;
   const int n = nrecv * 21;
   int blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gg_unpack_kernel, dim3(blocks), dim3(256), 0, stream, recvbuf, nrecv, nown, grad);
+  hipLaunchKernelGGL(gg_unpack_kernel, dim3(blocks), dim3(256), 0, stream, recvbuf, nrecv, grad.ghost);
   return hipGetLastError();
 }
 

@@ -59,10 +59,38 @@ struct cfdp_gpu {
   hipGraphExec_t graph = nullptr;
   int graph_iters = 0, graph_flux = -1, graph_mode = -1, graph_gl = 0, graph_fl = 0;
 
+  // d_grad: nall*21 doubles laid out [A: nown x 10][ghost rows: nghost x 21][B: nown x 11]
+  gg_grad_view grad_view() const { return gg_grad_view::of(d_grad, nown, nall); }
+  // device image <-> rows in FILE numbering
+  void rows_to_device(const double *rows, std::vector<double> &img) const {
+    img.resize((size_t)nall * 21);
+    double *a = img.data(), *gh = a + (size_t)nown * 10, *b = gh + (size_t)(nall - nown) * 21;
+    for (int i = 0; i < nall; i++) {
+      const double *r = rows + (size_t)new2old[i] * 21;
+      if (i < nown) {
+        memcpy(a + (size_t)i * 10, r, 10 * sizeof(double));
+        memcpy(b + (size_t)i * 11, r + 10, 11 * sizeof(double));
+      } else {
+        memcpy(gh + (size_t)(i - nown) * 21, r, 21 * sizeof(double));
+      }
+    }
+  }
+  void device_to_rows(const std::vector<double> &img, double *rows) const {
+    const double *a = img.data(), *gh = a + (size_t)nown * 10, *b = gh + (size_t)(nall - nown) * 21;
+    for (int i = 0; i < nall; i++) {
+      double *r = rows + (size_t)new2old[i] * 21;
+      if (i < nown) {
+        memcpy(r, a + (size_t)i * 10, 10 * sizeof(double));
+        memcpy(r + 10, b + (size_t)i * 11, 11 * sizeof(double));
+      } else {
+        memcpy(r, gh + (size_t)(i - nown) * 21, 21 * sizeof(double));
+      }
+    }
+  }
   gg_args args() const {
     gg_args a;
     a.tiles = d_tiles; a.blob = d_blob; a.halo_idx = d_halo; a.var = d_var;
-    a.grad = d_grad; a.flux = d_flux; a.nown = nown;
+    a.grad = grad_view(); a.flux = d_flux; a.nown = nown;
     return a;
   }
 };
@@ -194,6 +222,7 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
 int cfdp_gpu_bind_grad(cfdp_gpu *g, void *dev_grad) {
   NEED_UPLOAD(g);
   if (!dev_grad) return fail("null device pointer");
+  if ((uintptr_t)dev_grad & 15) return fail("grad buffer must be 16-byte aligned");
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(dev_grad, g->d_grad, sizeof(double) * 21 * (size_t)g->nall, hipMemcpyDeviceToDevice));
   if (g->own_grad) (void)hipFree(g->d_grad);
@@ -225,9 +254,8 @@ int cfdp_gpu_set_var(cfdp_gpu *g, const double *var) {
 
 int cfdp_gpu_set_grad(cfdp_gpu *g, const double *grad) {
   NEED_UPLOAD(g);
-  std::vector<double> tmp((size_t)g->nall * 21);
-  for (int i = 0; i < g->nall; i++)
-    memcpy(&tmp[(size_t)i * 21], grad + (size_t)g->new2old[i] * 21, 21 * sizeof(double));
+  std::vector<double> tmp;
+  g->rows_to_device(grad, tmp);
   HIP_TRY(hipMemcpy(g->d_grad, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
@@ -246,8 +274,7 @@ int cfdp_gpu_get_grad(cfdp_gpu *g, double *grad) {
   HIP_TRY(hipDeviceSynchronize());
   std::vector<double> tmp((size_t)g->nall * 21);
   HIP_TRY(hipMemcpy(tmp.data(), g->d_grad, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
-  for (int i = 0; i < g->nall; i++)
-    memcpy(grad + (size_t)g->new2old[i] * 21, &tmp[(size_t)i * 21], 21 * sizeof(double));
+  g->device_to_rows(tmp, grad);
   return 0;
 }
 
@@ -324,15 +351,15 @@ int cfdp_gpu_flux(cfdp_gpu *g, int mode, void *stream) {
 
 int cfdp_gpu_pack(cfdp_gpu *g, void *stream) {
   NEED_UPLOAD(g);
-  HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), g->d_grad, g->d_sendbuf,
+  HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), g->grad_view(), g->d_sendbuf,
                          stream ? (hipStream_t)stream : g->s_main));
   return 0;
 }
 
 int cfdp_gpu_unpack(cfdp_gpu *g, const void *dev_recvbuf, void *stream) {
   NEED_UPLOAD(g);
-  HIP_TRY(gg_launch_unpack(static_cast<const double *>(dev_recvbuf), g->recv_off.back(), g->nown,
-                           g->d_grad, stream ? (hipStream_t)stream : g->s_main));
+  HIP_TRY(gg_launch_unpack(static_cast<const double *>(dev_recvbuf), g->recv_off.back(), g->grad_view(),
+                           stream ? (hipStream_t)stream : g->s_main));
   return 0;
 }
 
@@ -359,7 +386,7 @@ void *cfdp_gpu_send_ptr(cfdp_gpu *g, int s, size_t *bytes) {
 void *cfdp_gpu_recv_ptr(cfdp_gpu *g, int s, size_t *bytes) {
   if (s < 0 || s >= (int)g->partner.size()) return nullptr;
   if (bytes) *bytes = (size_t)(g->recv_off[s + 1] - g->recv_off[s]) * 21 * sizeof(double);
-  return g->d_grad + ((size_t)g->nown + g->recv_off[s]) * 21;
+  return g->grad_view().ghost + (size_t)g->recv_off[s] * 21;  // whole rows, message order
 }
 void *cfdp_gpu_grad_ptr(cfdp_gpu *g) { return g->d_grad; }
 void *cfdp_gpu_var_ptr(cfdp_gpu *g) { return g->d_var; }
@@ -386,7 +413,7 @@ int cfdp_gpu_step_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   g->pending_exchange = comm;
   if (!comm) return launch_grad(g, CFDP_TILES_ALL, g->s_main);
   if (launch_grad(g, overlap ? CFDP_TILES_BOUNDARY : CFDP_TILES_ALL, g->s_main)) return 1;
-  HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), g->d_grad, g->d_sendbuf, g->s_main));
+  HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), g->grad_view(), g->d_sendbuf, g->s_main));
   HIP_TRY(hipEventRecord(g->ev_pack, g->s_main));
   HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_pack, 0));
   HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fluxdone, 0));
@@ -418,7 +445,7 @@ int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, i
   // the send arena is free again once last iteration's peer copies have drained
   HIP_TRY(hipStreamWaitEvent(ga->s_main, ga->ev_senddone, 0));
   if (launch_grad(ga, overlap ? CFDP_TILES_BOUNDARY : CFDP_TILES_ALL, ga->s_main)) return 1;
-  HIP_TRY(gg_launch_pack(ga->d_sendidx, ga->send_off.back(), ga->d_grad, ga->d_sendbuf, ga->s_main));
+  HIP_TRY(gg_launch_pack(ga->d_sendidx, ga->send_off.back(), ga->grad_view(), ga->d_sendbuf, ga->s_main));
   HIP_TRY(hipEventRecord(ga->ev_pack, ga->s_main));
   if (overlap && launch_grad(ga, CFDP_TILES_INTERIOR, ga->s_main)) return 1;
   HIP_TRY(hipStreamWaitEvent(ga->s_comm, ga->ev_pack, 0));

@@ -112,7 +112,7 @@ class RankSolver:
         c = self.gpu.counts()
         self.nown, self.nall, self.nsend, self.nrecv = c["nown"], c["nall"], c["nsend"], c["nrecv"]
         self.partners = self.gpu.partners()
-        # torch owns the buffers RCCL touches: grad (ghost rows = receive side) and the send arena
+        # torch owns the buffers RCCL touches: grad (its ghost block = receive side) and the send arena
         self.grad_t = torch.empty(self.nall * ROWLEN, dtype=torch.float64, device=self.device)
         self.send_t = torch.empty(max(self.nsend, 1) * ROWLEN, dtype=torch.float64, device=self.device)
         self.gpu.bind_grad(self.grad_t.data_ptr())
@@ -122,15 +122,12 @@ class RankSolver:
         self.s_main = torch.cuda.ExternalStream(self.gpu.stream(0), device=self.device)
         self.s_comm = torch.cuda.ExternalStream(self.gpu.stream(1), device=self.device)
         self.send_views, self.recv_views = [], []
-        so = ro = 0
         for s in range(len(self.partners)):
-            _, sb = self.gpu.send_slice(s)
-            _, rb = self.gpu.recv_slice(s)
-            ns, nr = sb // 8, rb // 8
-            self.send_views.append(self.send_t[so:so + ns])
-            self.recv_views.append(self.grad_t[self.nown * ROWLEN + ro: self.nown * ROWLEN + ro + nr])
-            so += ns
-            ro += nr
+            sp, sb = self.gpu.send_slice(s)
+            rp, rb = self.gpu.recv_slice(s)
+            so, ro = (sp - self.send_t.data_ptr()) // 8, (rp - self.grad_t.data_ptr()) // 8
+            self.send_views.append(self.send_t[so:so + sb // 8])
+            self.recv_views.append(self.grad_t[ro:ro + rb // 8])  # whole rows inside the ghost block
         if transport == "staged":
             self.h_send = [torch.empty(v.numel(), dtype=torch.float64).pin_memory() for v in self.send_views]
             self.h_recv = [torch.empty(v.numel(), dtype=torch.float64).pin_memory() for v in self.recv_views]

@@ -56,8 +56,13 @@ void cfdp_gpu_destroy(cfdp_gpu *g);
 /* copy the tiled mesh to the device and allocate the fields (var, grad, psd_flux, send
  * arena).  The plan may be freed afterwards.                                             */
 int  cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *plan);
-/* optional: use caller-owned device memory for grad [nall*21 doubles] / the send arena
- * [nsend*21 doubles] (e.g. buffers registered with a communication library)              */
+/* optional: use caller-owned device memory (16-byte aligned) for grad [nall*21 doubles] / the
+ * send arena [nsend*21 doubles] (e.g. buffers registered with a communication library).
+ * Device layout of grad: an owned row's 21 doubles are split into part A (doubles 0..9, read
+ * by the flux loop) and part B (doubles 10..20); ghost rows stay whole, in message order:
+ *   [A: nown x 10][ghost rows: (nall-nown) x 21][B: nown x 11]
+ * cfdp_gpu_recv_ptr() points into the ghost block; cfdp_gpu_get_grad/_set_grad convert from
+ * and to the reference's grad[nall][7][3] in file numbering.                               */
 int  cfdp_gpu_bind_grad(cfdp_gpu *g, void *dev_grad);
 int  cfdp_gpu_bind_sendbuf(cfdp_gpu *g, void *dev_sendbuf);
 
