@@ -62,6 +62,8 @@ def main() -> None:
     ap.add_argument("--tile-points", type=int, default=0)
     ap.add_argument("--grad-lanes", type=int, default=0)
     ap.add_argument("--flux-lanes", type=int, default=0)
+    ap.add_argument("--no-fusion", action="store_true",
+                    help="one kernel per face loop instead of the fused flux(i)+gradients(i+1) pass")
     ap.add_argument("--no-files", action="store_true", help="generate domains in memory (skip the loader)")
     ap.add_argument("--no-finest", action="store_true", help="skip the finest-level single-GPU roofline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
@@ -100,7 +102,8 @@ def main() -> None:
     mg.exchange_requests(part, rank, world, dist)
     nfaces_part, nown, nadd = part.nfaces, part.nown, part.nall - part.nown
     solver = mg.RankSolver(part, rank, world, device, dist, transport=args.transport,
-                           tile_points=args.tile_points, grad_lanes=args.grad_lanes, flux_lanes=args.flux_lanes)
+                           tile_points=args.tile_points, grad_lanes=args.grad_lanes, flux_lanes=args.flux_lanes,
+                           fusion=not args.no_fusion)
     t_setup = time.time() - t0
 
     def barrier():
@@ -150,6 +153,7 @@ def main() -> None:
                 world, f"{dims[0]}x{dims[1]}x{dims[2]} lattice, {ndom} domains, {ndom // world} per GPU, RCCL halo exchange"),
             "mesh_points": dims[0] * dims[1] * dims[2], "points_per_gpu": nown, "faces_per_gpu": nfaces_part,
             "ghost_points_per_gpu": nadd, "iteration": "gradients + halo exchange + pseudo flux",
+            "fused_iterations": not args.no_fusion,
             "mesh_iterations_per_s": its, "via_dualgrid_files": not args.no_files,
             "tiles": solver.gpu.stats["ntiles"], "tile_points": solver.gpu.stats["tile_points"],
             "setup_s": round(t_setup, 2),
@@ -179,11 +183,31 @@ def main() -> None:
                     traffic = v["traffic_bytes"]
         except Exception:
             traffic = None
-    out["roofline"] = {"bound": "hbm", "kernel": "gg_gradient_kernel", "achieved": bg / (ms_g * 1e-3) / 1e9,
-                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bg / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                       "traffic": traffic, "algorithmic_bytes_per_launch": bg, "us_per_launch": ms_g * 1e3,
-                       "flux_kernel": {"achieved": bf / (ms_f * 1e-3) / 1e9, "us_per_launch": ms_f * 1e3,
-                                       "algorithmic_bytes_per_launch": bf}}
+    grad_k = {"kernel": "gg_gradient_dma_kernel", "achieved": bg / (ms_g * 1e-3) / 1e9,
+              "frac": bg / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+              "algorithmic_bytes_per_launch": bg, "us_per_launch": ms_g * 1e3}
+    flux_k = {"kernel": "gg_flux_dma_kernel", "achieved": bf / (ms_f * 1e-3) / 1e9, "us_per_launch": ms_f * 1e3,
+              "algorithmic_bytes_per_launch": bf}
+    if args.no_fusion:
+        out["roofline"] = {"bound": "hbm", "kernel": grad_k["kernel"], "achieved": grad_k["achieved"],
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": grad_k["frac"], "traffic": traffic,
+                           "algorithmic_bytes_per_launch": bg, "us_per_launch": ms_g * 1e3, "flux_kernel": flux_k}
+    else:
+        # the timed loop runs the fused pass (flux(i) + gradients(i+1), tile data streamed once):
+        # one launch does the work of one gradient launch and one flux launch
+        ms_fu = solver.gpu.time_fused(200)
+        ftraffic = None
+        if world == 1:
+            try:
+                for k, v in tr["dualgrid.12 lvl 2 stand-in (64^3)"].items():
+                    if "gg_fused" in k:
+                        ftraffic = v["traffic_bytes"]
+            except Exception:
+                ftraffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "gg_fused_dma_kernel", "achieved": (bg + bf) / (ms_fu * 1e-3) / 1e9,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (bg + bf) / (ms_fu * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "traffic": ftraffic, "algorithmic_bytes_per_launch": bg + bf, "us_per_launch": ms_fu * 1e3,
+                           "gradient_kernel": grad_k, "flux_kernel": flux_k}
 
     if rank == 0 and world == 1:
         # ---- the truly HBM-bound single-GPU case: finest level (2.1 M points, 0.95 GB per pass) ----
@@ -195,14 +219,23 @@ def main() -> None:
                                   flux_lanes=args.flux_lanes)
             p1.time_kernels(10)  # first touches of 1.7 GB of device memory
             g1, f1 = p1.time_kernels(50)
+            fu1 = None
+            if not args.no_fusion:
+                p1.set_fusion(True)
+                p1.time_fused(10)
+                fu1 = p1.time_fused(50)
             b1 = pkg.algo_bytes_grad(d1.nfaces, d1.nown, 0)
             b1f = pkg.algo_bytes_flux(d1.nfaces, d1.nown, 0)
             out["finest_level"] = {"workload": "dualgrid.384 finest-level stand-in merged on 1 GPU (128^3)",
                                    "points": d1.nown, "faces": d1.nfaces, "algorithmic_bytes_per_launch": b1,
                                    "us_per_launch": g1 * 1e3, "achieved": b1 / (g1 * 1e-3) / 1e9,
                                    "frac": b1 / (g1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "iterations_per_s": 1e3 / (g1 + f1), "flux_us_per_launch": f1 * 1e3,
+                                   "iterations_per_s": 1e3 / (fu1 if fu1 else g1 + f1), "flux_us_per_launch": f1 * 1e3,
                                    "flux_achieved": b1f / (f1 * 1e-3) / 1e9}
+            if fu1:
+                out["finest_level"]["fused"] = {"us_per_launch": fu1 * 1e3, "algorithmic_bytes_per_launch": b1 + b1f,
+                                                "achieved": (b1 + b1f) / (fu1 * 1e-3) / 1e9,
+                                                "frac": (b1 + b1f) / (fu1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
             p1.close()
             d1.free()
         # ---- CPU baseline: the oracle (a port of the reference's algorithm class) on the host cores ----

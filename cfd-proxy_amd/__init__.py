@@ -201,6 +201,9 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_upload_plan.argtypes = [vp, P(PlanStruct)]
     lib.cfdp_gpu_bind_grad.argtypes = [vp, vp]
     lib.cfdp_gpu_bind_sendbuf.argtypes = [vp, vp]
+    lib.cfdp_gpu_set_fusion.argtypes = [vp, C.c_int]
+    lib.cfdp_gpu_bind_grad_alt.argtypes = [vp, vp]
+    lib.cfdp_gpu_time_fused.argtypes = [vp, C.c_int, C.c_int, P(C.c_float)]
     for n in ("set_var", "set_grad", "set_flux", "get_grad", "get_flux"):
         getattr(lib, "cfdp_gpu_" + n).argtypes = [vp, P(C.c_double)]
     lib.cfdp_gpu_set_variant.argtypes = [vp, C.c_int, C.c_int]
@@ -633,6 +636,21 @@ class GpuPartition:
 
     def bind_sendbuf(self, dev_ptr: int) -> None:
         self._ck(self.lib.cfdp_gpu_bind_sendbuf(self.h, C.c_void_p(dev_ptr)))
+
+    def set_fusion(self, on: bool) -> None:
+        """defer each iteration's flux into the pass that computes the next gradients"""
+        self._ck(self.lib.cfdp_gpu_set_fusion(self.h, int(on)))
+
+    def bind_grad_alt(self, dev_ptr: int) -> None:
+        self._ck(self.lib.cfdp_gpu_bind_grad_alt(self.h, C.c_void_p(dev_ptr)))
+
+    def grad_ptr(self) -> int:
+        return self.lib.cfdp_gpu_grad_ptr(self.h) or 0
+
+    def time_fused(self, iters: int, flux_mode: int = FLUX_CONSISTENT) -> float:
+        ms = C.c_float()
+        self._ck(self.lib.cfdp_gpu_time_fused(self.h, iters, flux_mode, C.byref(ms)))
+        return ms.value
 
     def time_kernels(self, iters: int, flux_mode: int = FLUX_CONSISTENT):
         g, f = C.c_float(), C.c_float()

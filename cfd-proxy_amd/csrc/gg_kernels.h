@@ -38,6 +38,11 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
 hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_begin, int ntiles,
                           int tile_points, size_t lds, int max_halo, int max_blob_qw, bool nt,
                           hipStream_t stream);
+// flux(i) read from a.grad + gradients(i+1) written to `gnew` in one pass over the tile blobs;
+// hipErrorNotSupported when the tile sizes fit no instantiated capacity
+hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refmode, int tile_begin,
+                           int ntiles, int tile_points, int max_halo, int max_blob_qw, bool nt,
+                           hipStream_t stream);
 hipError_t gg_launch_pack(const int *send_idx, int nsend, const gg_grad_view &grad, double *sendbuf,
                           hipStream_t stream);
 hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view &grad,

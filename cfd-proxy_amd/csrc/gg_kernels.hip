@@ -131,7 +131,7 @@ __device__ __forceinline__ void grad_batch(const uint32_t *__restrict__ inc, int
   }
 }
 
-template <int LPP, bool NT>
+template <int LPP, bool NT, bool SYNC = false>
 __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, const cfdp_tile_desc &td,
                                                   int tid, double *__restrict__ gradA,
                                                   double *__restrict__ gradB,
@@ -175,6 +175,8 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     if (k < ke) grad_batch<1, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
     tmp = 1.0 / var_l[li * 8 + 7];  // 1/pvolume, src/gradients.c:138
   }
+  // SYNC: `stage` aliases a region of the tile image other waves may still be reading
+  if constexpr (SYNC) __syncthreads();
   // ---- write the finished rows.  A lane holds NE*3 doubles of a 168-byte row; storing them
   // directly is 8 bytes per lane at a 24..168-byte stride (measured: the stores alone then
   // take longer than streaming the whole tile in).  Instead each wave transposes its PPW rows
@@ -604,6 +606,89 @@ __global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
   flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<const double *>(gbuf), td, hid, tid, flux, nown);
 }
 
+// ------------------------------------------------------------------- fused iteration kernel
+// flux(i) and gradients(i+1) of a tile in ONE pass: both face loops read the same tile blob
+// (normals + incidence lists = more than half of either kernel's HBM traffic), so a run of
+// iterations streams it once per iteration instead of twice.  grad is double-buffered: the flux
+// phase reads part A / the ghost block of the buffer iteration i wrote (its halo exchange has
+// completed), the gradient phase writes the other buffer.  The results are those of the two
+// separate kernels, bit for bit (same per-tile arithmetic, flux_tile_compute /
+// grad_tile_compute).  4 lanes per point in both phases; fixed-count LDS-DMA staging as above:
+// LDS image [blob: CB][var rows: KV][gradient rows (80 bytes each): KG] x nthr x 16 bytes; the
+// store slab of the gradient phase reuses the gradient-row region once the flux phase is done.
+template <bool REFMODE, bool NT, int CB, int KV, int KG>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
+void gg_fused_dma_kernel(
+    const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
+    const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
+    const double *__restrict__ gradA_old /*[nown][10]*/, const double *__restrict__ ghost_old /*[nghost][21]*/,
+    double *__restrict__ flux /*[nown][3]*/, int nown,
+    double *__restrict__ gradA_new /*[nown][10]*/, double *__restrict__ gradB_new /*[nown][11]*/, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int LPP = 4;
+  const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
+  const cfdp_tile_desc td = tiles[t];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, w0 = tid & ~63;
+  const int *hid = halo_idx + td.halo_off;
+  const int hmax = td.nhalo > 0 ? td.nhalo - 1 : 0;
+  // (1) halo row numbers of this thread's var pieces (4 per row) and gradient pieces (5 per row)
+  int hv[KV], hg[KG], part[KG], rloc[KG];
+#pragma unroll
+  for (int k = 0; k < KV; k++) {
+    int h = ((tid + k * nthr) >> 2) - td.npts;
+    h = h < 0 ? 0 : (h > hmax ? hmax : h);
+    hv[k] = ld_i32_nowait(hid + h);
+  }
+#pragma unroll
+  for (int k = 0; k < KG; k++) {
+    const int q = tid + k * nthr;
+    rloc[k] = q / 5;
+    part[k] = q - 5 * rloc[k];
+    int h = rloc[k] - td.npts;
+    h = h < 0 ? 0 : (h > hmax ? hmax : h);
+    hg[k] = ld_i32_nowait(hid + h);
+  }
+  // (2) the blob, once for both face loops
+  const uint4 *b4 = blob + td.blob_off;
+  const int qmax = td.blob_qw - 1;
+#pragma unroll
+  for (int i = 0; i < CB; i++) {
+    const int q0 = w0 + i * nthr;
+    const int q = q0 + lane < qmax ? q0 + lane : qmax;
+    if constexpr (NT) glds16_nt(b4 + q, smem + (size_t)q0 * 16);
+    else glds16(b4 + q, smem + (size_t)q0 * 16);
+  }
+  // (3) only the index loads are awaited; the CB blob pieces stay in flight
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CB) : "memory");
+#pragma unroll
+  for (int k = 0; k < KV; k++) asm volatile("" : "+v"(hv[k]));
+#pragma unroll
+  for (int k = 0; k < KG; k++) asm volatile("" : "+v"(hg[k]));
+  // (4) var rows and gradient rows
+  unsigned char *vbuf = smem + (size_t)CB * nthr * 16;
+  unsigned char *gbuf = vbuf + (size_t)KV * nthr * 16;
+  const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
+#pragma unroll
+  for (int k = 0; k < KV; k++) {
+    const int q = tid + k * nthr, r = q >> 2;
+    const int row = r < td.npts ? td.pstart + r : hv[k];
+    glds16(gv4 + (size_t)row * 4 + (q & 3), vbuf + (size_t)(w0 + k * nthr) * 16);
+  }
+  const unsigned char *abytes = reinterpret_cast<const unsigned char *>(gradA_old);
+  const unsigned char *hbytes = reinterpret_cast<const unsigned char *>(ghost_old);
+#pragma unroll
+  for (int k = 0; k < KG; k++) {
+    const int row = rloc[k] < td.npts ? td.pstart + rloc[k] : hg[k];
+    const unsigned char *src = row < nown ? abytes + (size_t)row * 80 : hbytes + (size_t)(row - nown) * 168;
+    glds16(reinterpret_cast<const uint4 *>(src + part[k] * 16), gbuf + (size_t)(w0 + k * nthr) * 16);
+  }
+  __syncthreads();
+  flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<const double *>(gbuf), td, hid, tid, flux, nown);
+  grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(gbuf), dbg,
+                                   CB * nthr * 16);
+}
+
 // --------------------------------------------------------------------------- pack/unpack
 __global__ __launch_bounds__(256) void gg_pack_kernel(const int *__restrict__ send_idx, int nsend,
                                                       const double *__restrict__ gradA,
@@ -782,6 +867,39 @@ hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_be
   return hipGetLastError();
 }
 
+// flux(i) from `a.grad`, gradients(i+1) into `gnew`.  hipErrorNotSupported: no instantiated
+// capacity fits this launch -- the caller runs the two separate kernels instead.
+hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refmode, int tile_begin,
+                           int ntiles, int tile_points, int max_halo, int max_blob_qw, bool nt,
+                           hipStream_t stream) {
+  if (ntiles <= 0) return hipSuccess;
+  const int block = ((tile_points * 4 + 63) / 64) * 64;
+  if (block > 1024 || (gg_debug_flags & 16)) return hipErrorNotSupported;
+  const int cb = (max_blob_qw + block - 1) / block;
+  const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;
+  const int kg = ((tile_points + max_halo) * 5 + block - 1) / block;
+  if (cb < 1 || kv < 1 || kg < 1) return hipErrorNotSupported;
+#define LAUNCH_FUSED_RN(R, N, CB, KV, KG)                                                         \
+  hipLaunchKernelGGL((gg_fused_dma_kernel<R, N, CB, KV, KG>), dim3(ntiles), dim3(block), fused_lds, \
+                     stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, \
+                     a.flux, a.nown, gnew.a, gnew.b, gg_debug_flags)
+#define LAUNCH_FUSED(CB, KV, KG)                                                                  \
+  do {                                                                                            \
+    const size_t fused_lds = (size_t)((CB) + (KV) + (KG)) * block * 16;                           \
+    if (fused_lds > 160 * 1024 || (size_t)(block / 64) * 8 * 21 * 8 > (size_t)(KG) * block * 16) break; \
+    if (refmode) { if (nt) LAUNCH_FUSED_RN(true, true, CB, KV, KG); else LAUNCH_FUSED_RN(true, false, CB, KV, KG); } \
+    else { if (nt) LAUNCH_FUSED_RN(false, true, CB, KV, KG); else LAUNCH_FUSED_RN(false, false, CB, KV, KG); } \
+    return hipGetLastError();                                                                     \
+  } while (0)
+  if (cb <= 5 && kv <= 3 && kg <= 4) LAUNCH_FUSED(5, 3, 4);
+  if (cb <= 5 && kv <= 4 && kg <= 5) LAUNCH_FUSED(5, 4, 5);
+  if (cb <= 6 && kv <= 5 && kg <= 6) LAUNCH_FUSED(6, 5, 6);
+  if (cb <= 8 && kv <= 6 && kg <= 8) LAUNCH_FUSED(8, 6, 8);
+#undef LAUNCH_FUSED
+#undef LAUNCH_FUSED_RN
+  return hipErrorNotSupported;
+}
+
 hipError_t gg_launch_pack(const int *send_idx, int nsend, const gg_grad_view &grad, double *sendbuf,
                           hipStream_t stream) {
   if (nsend <= 0) return hipSuccess;
@@ -854,6 +972,16 @@ hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
   SET_LDS((gg_gradient_dma_kernel<4, true, 6, 5>), all)
   SET_LDS((gg_gradient_dma_kernel<4, false, 8, 6>), all)
   SET_LDS((gg_gradient_dma_kernel<4, true, 8, 6>), all)
+#define SET_LDS_FUSED(CB, KV, KG)                                \
+  SET_LDS((gg_fused_dma_kernel<false, false, CB, KV, KG>), all)  \
+  SET_LDS((gg_fused_dma_kernel<false, true, CB, KV, KG>), all)   \
+  SET_LDS((gg_fused_dma_kernel<true, false, CB, KV, KG>), all)   \
+  SET_LDS((gg_fused_dma_kernel<true, true, CB, KV, KG>), all)
+  SET_LDS_FUSED(5, 3, 4)
+  SET_LDS_FUSED(5, 4, 5)
+  SET_LDS_FUSED(6, 5, 6)
+  SET_LDS_FUSED(8, 6, 8)
+#undef SET_LDS_FUSED
   SET_LDS((gg_gradient_pipe_kernel<1, false>), all)
   SET_LDS((gg_gradient_pipe_kernel<1, true>), all)
   SET_LDS((gg_gradient_pipe_kernel<2, false>), all)

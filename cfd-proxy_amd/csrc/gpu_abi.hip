@@ -48,6 +48,13 @@ struct cfdp_gpu {
   double *d_var = nullptr, *d_grad = nullptr, *d_flux = nullptr,
          *d_sendbuf = nullptr;
   bool own_grad = true, own_sendbuf = true;
+  // fused iterations (flux(i) + gradients(i+1) in one pass): grad is double-buffered; d_grad
+  // always is the buffer holding the latest gradients, d_grad_alt the one the next fused pass
+  // writes.  flux_pending: flux mode of an iteration whose flux has been deferred, or -1.
+  double *d_grad_alt = nullptr;
+  bool own_grad_alt = true;
+  int fusion = 0, flux_pending = -1;
+  long iter = 0;               // phase-1 calls so far (in-process rank groups run in lockstep)
   std::vector<int> new2old, partner, send_off, recv_off;
   std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
   int max_halo[2] = {0, 0}, max_blob[2] = {0, 0};  // per tile class: halo rows, blob 16-byte units
@@ -57,10 +64,13 @@ struct cfdp_gpu {
   bool pending_exchange = false;
   bool streams_exported = false;  // handed to the caller: not destroyed with the context
   hipGraphExec_t graph = nullptr;
-  int graph_iters = 0, graph_flux = -1, graph_mode = -1, graph_gl = 0, graph_fl = 0;
+  int graph_iters = 0, graph_flux = -1, graph_mode = -1, graph_gl = 0, graph_fl = 0, graph_fuse = -1;
+  const double *graph_cur = nullptr;  // d_grad at capture: the graph's pointers are baked in
 
   // d_grad: nall*21 doubles laid out [A: nown x 10][ghost rows: nghost x 21][B: nown x 11]
   gg_grad_view grad_view() const { return gg_grad_view::of(d_grad, nown, nall); }
+  gg_grad_view alt_view() const { return gg_grad_view::of(d_grad_alt, nown, nall); }
+  bool will_fuse() const { return fusion && flux_pending >= 0 && d_grad_alt; }
   // device image <-> rows in FILE numbering
   void rows_to_device(const double *rows, std::vector<double> &img) const {
     img.resize((size_t)nall * 21);
@@ -132,7 +142,9 @@ static void free_device(cfdp_gpu *g) {
   (void)hipFree(g->d_tiles); (void)hipFree(g->d_blob); (void)hipFree(g->d_halo); (void)hipFree(g->d_sendidx);
   (void)hipFree(g->d_var); (void)hipFree(g->d_flux);
   if (g->own_grad) (void)hipFree(g->d_grad);
+  if (g->own_grad_alt) (void)hipFree(g->d_grad_alt);
   if (g->own_sendbuf) (void)hipFree(g->d_sendbuf);
+  g->d_grad_alt = nullptr; g->own_grad_alt = true; g->flux_pending = -1; g->iter = 0;
   g->d_tiles = nullptr; g->d_blob = nullptr; g->d_halo = g->d_sendidx = nullptr;
   g->d_var = g->d_grad = g->d_flux = g->d_sendbuf = nullptr;
   g->own_grad = g->own_sendbuf = true;
@@ -210,6 +222,7 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   HIP_TRY(hipMemset(g->d_flux, 0, sizeof(double) * 3 * (size_t)p->nown));
   HIP_TRY(gg_set_max_lds((size_t)p->lds_grad, (size_t)p->lds_flux));
   g->uploaded = true;
+  if (g->fusion) return cfdp_gpu_set_fusion(g, 1);
   return 0;
 }
 
@@ -242,6 +255,52 @@ int cfdp_gpu_bind_sendbuf(cfdp_gpu *g, void *dev_sendbuf) {
   return 0;
 }
 
+static int launch_flux(cfdp_gpu *g, int mode, hipStream_t st);
+
+// run the deferred flux of the last fused-mode iteration, if any
+static int flush_flux(cfdp_gpu *g, bool record = true) {
+  if (g->flux_pending < 0) return 0;
+  const int mode = g->flux_pending;
+  g->flux_pending = -1;
+  if (launch_flux(g, mode, g->s_main)) return 1;
+  if (record) HIP_TRY(hipEventRecord(g->ev_fluxdone, g->s_main));
+  return 0;
+}
+
+int cfdp_gpu_set_fusion(cfdp_gpu *g, int on) {
+  if (!g) return fail("null context");
+  if (!g->uploaded) { g->fusion = on != 0; return 0; }  // takes effect at upload
+  HIP_TRY(hipSetDevice(g->device));
+  if (!on) {
+    if (flush_flux(g)) return 1;
+    g->fusion = 0;
+    return 0;
+  }
+  if (!g->d_grad_alt) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMalloc(&g->d_grad_alt, sizeof(double) * 21 * (size_t)g->nall));
+    HIP_TRY(hipMemcpy(g->d_grad_alt, g->d_grad, sizeof(double) * 21 * (size_t)g->nall, hipMemcpyDeviceToDevice));
+    g->own_grad_alt = true;
+  }
+  g->fusion = 1;
+  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  return 0;
+}
+
+int cfdp_gpu_bind_grad_alt(cfdp_gpu *g, void *dev_grad) {
+  NEED_UPLOAD(g);
+  if (!dev_grad) return fail("null device pointer");
+  if ((uintptr_t)dev_grad & 15) return fail("grad buffer must be 16-byte aligned");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(dev_grad, g->d_grad_alt ? g->d_grad_alt : g->d_grad, sizeof(double) * 21 * (size_t)g->nall,
+                    hipMemcpyDeviceToDevice));
+  if (g->d_grad_alt && g->own_grad_alt) (void)hipFree(g->d_grad_alt);
+  g->d_grad_alt = static_cast<double *>(dev_grad);
+  g->own_grad_alt = false;
+  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  return 0;
+}
+
 int cfdp_gpu_set_var(cfdp_gpu *g, const double *var) {
   NEED_UPLOAD(g);
   std::vector<double> tmp((size_t)g->nall * 8, 0.0);
@@ -254,14 +313,20 @@ int cfdp_gpu_set_var(cfdp_gpu *g, const double *var) {
 
 int cfdp_gpu_set_grad(cfdp_gpu *g, const double *grad) {
   NEED_UPLOAD(g);
+  if (flush_flux(g)) return 1;
   std::vector<double> tmp;
   g->rows_to_device(grad, tmp);
+  HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(g->d_grad, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (g->d_grad_alt)  // rows no kernel writes (ghosts without an exchange, faceless points) read the same from either buffer
+    HIP_TRY(hipMemcpy(g->d_grad_alt, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
 
 int cfdp_gpu_set_flux(cfdp_gpu *g, const double *flux) {
   NEED_UPLOAD(g);
+  if (flush_flux(g)) return 1;
+  HIP_TRY(hipDeviceSynchronize());
   std::vector<double> tmp((size_t)g->nown * 3);
   for (int i = 0; i < g->nown; i++)
     memcpy(&tmp[(size_t)i * 3], flux + (size_t)g->new2old[i] * 3, 3 * sizeof(double));
@@ -271,6 +336,7 @@ int cfdp_gpu_set_flux(cfdp_gpu *g, const double *flux) {
 
 int cfdp_gpu_get_grad(cfdp_gpu *g, double *grad) {
   NEED_UPLOAD(g);
+  if (flush_flux(g)) return 1;
   HIP_TRY(hipDeviceSynchronize());
   std::vector<double> tmp((size_t)g->nall * 21);
   HIP_TRY(hipMemcpy(tmp.data(), g->d_grad, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -280,6 +346,7 @@ int cfdp_gpu_get_grad(cfdp_gpu *g, double *grad) {
 
 int cfdp_gpu_get_flux(cfdp_gpu *g, double *flux) {
   NEED_UPLOAD(g);
+  if (flush_flux(g)) return 1;
   HIP_TRY(hipDeviceSynchronize());
   std::vector<double> tmp((size_t)g->nown * 3);
   HIP_TRY(hipMemcpy(tmp.data(), g->d_flux, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -315,8 +382,9 @@ static int pipe_for(const cfdp_gpu *g, int ntiles) {
   return g->pipeline >= 0 ? g->pipeline : 0;
 }
 
-static int launch_grad(cfdp_gpu *g, int which, hipStream_t st) {
-  const gg_args a = g->args();
+static int launch_grad(cfdp_gpu *g, int which, hipStream_t st, const gg_grad_view *into = nullptr) {
+  gg_args a = g->args();
+  if (into) a.grad = *into;
   if (which == CFDP_TILES_ALL || which == CFDP_TILES_BOUNDARY)
     HIP_TRY(gg_launch_gradient(a, g->grad_lanes, 0, g->nbtiles, g->tp[0], g->lds_grad[0], g->max_halo[0],
                                g->max_blob[0], pipe_for(g, g->nbtiles), g->streaming, st));
@@ -327,25 +395,57 @@ static int launch_grad(cfdp_gpu *g, int which, hipStream_t st) {
   return 0;
 }
 
-static int launch_flux(cfdp_gpu *g, int mode, hipStream_t st) {
+static int launch_flux_range(cfdp_gpu *g, int mode, int c, hipStream_t st) {
   const gg_args a = g->args();
-  const bool ref = mode == CFDP_FLUX_REFERENCE;
-  HIP_TRY(gg_launch_flux(a, g->flux_lanes, ref, 0, g->nbtiles, g->tp[0], g->lds_flux[0], g->max_halo[0],
-                         g->max_blob[0], g->streaming, st));
-  HIP_TRY(gg_launch_flux(a, g->flux_lanes, ref, g->nbtiles, g->ntiles - g->nbtiles, g->tp[1],
-                         g->lds_flux[1], g->max_halo[1], g->max_blob[1], g->streaming, st));
+  const int begin = c ? g->nbtiles : 0, n = c ? g->ntiles - g->nbtiles : g->nbtiles;
+  HIP_TRY(gg_launch_flux(a, g->flux_lanes, mode == CFDP_FLUX_REFERENCE, begin, n, g->tp[c], g->lds_flux[c],
+                         g->max_halo[c], g->max_blob[c], g->streaming, st));
   return 0;
+}
+
+static int launch_flux(cfdp_gpu *g, int mode, hipStream_t st) {
+  return launch_flux_range(g, mode, 0, st) || launch_flux_range(g, mode, 1, st);
+}
+
+// the deferred flux (from d_grad) + the next gradients (into d_grad_alt) over the selected tiles
+// in one pass; falls back to the two separate kernels when no fused capacity fits the tiles.
+// The caller swaps the buffers (fused_done) once every tile range of the iteration is enqueued.
+static int launch_fused(cfdp_gpu *g, int which, hipStream_t st) {
+  const gg_args a = g->args();
+  const gg_grad_view gnew = g->alt_view();
+  const int mode = g->flux_pending;
+  for (int c = 0; c < 2; c++) {
+    if (which == (c ? CFDP_TILES_BOUNDARY : CFDP_TILES_INTERIOR)) continue;
+    const int begin = c ? g->nbtiles : 0, n = c ? g->ntiles - g->nbtiles : g->nbtiles;
+    const hipError_t e = gg_launch_fused(a, gnew, mode == CFDP_FLUX_REFERENCE, begin, n, g->tp[c], g->max_halo[c],
+                                         g->max_blob[c], g->streaming, st);
+    if (e == hipErrorNotSupported) {
+      if (launch_flux_range(g, mode, c, st)) return 1;
+      if (launch_grad(g, c ? CFDP_TILES_INTERIOR : CFDP_TILES_BOUNDARY, st, &gnew)) return 1;
+    } else {
+      HIP_TRY(e);
+    }
+  }
+  return 0;
+}
+
+static void fused_done(cfdp_gpu *g) {
+  std::swap(g->d_grad, g->d_grad_alt);
+  std::swap(g->own_grad, g->own_grad_alt);
+  g->flux_pending = -1;
 }
 
 int cfdp_gpu_gradients(cfdp_gpu *g, int which_tiles, void *stream) {
   NEED_UPLOAD(g);
   if (which_tiles < 0 || which_tiles > 2) return fail("bad tile selector %d", which_tiles);
+  if (flush_flux(g)) return 1;
   return launch_grad(g, which_tiles, stream ? (hipStream_t)stream : g->s_main);
 }
 
 int cfdp_gpu_flux(cfdp_gpu *g, int mode, void *stream) {
   NEED_UPLOAD(g);
   if (mode != CFDP_FLUX_CONSISTENT && mode != CFDP_FLUX_REFERENCE) return fail("bad flux mode %d", mode);
+  if (flush_flux(g)) return 1;
   return launch_flux(g, mode, stream ? (hipStream_t)stream : g->s_main);
 }
 
@@ -366,6 +466,7 @@ int cfdp_gpu_unpack(cfdp_gpu *g, const void *dev_recvbuf, void *stream) {
 int cfdp_gpu_sync(cfdp_gpu *g) {
   if (!g) return fail("null context");
   HIP_TRY(hipSetDevice(g->device));
+  if (g->uploaded && flush_flux(g)) return 1;
   HIP_TRY(hipDeviceSynchronize());
   return 0;
 }
@@ -411,13 +512,26 @@ int cfdp_gpu_step_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   NEED_UPLOAD(g);
   const bool comm = with_exchange && !g->partner.empty();
   g->pending_exchange = comm;
-  if (!comm) return launch_grad(g, CFDP_TILES_ALL, g->s_main);
-  if (launch_grad(g, overlap ? CFDP_TILES_BOUNDARY : CFDP_TILES_ALL, g->s_main)) return 1;
-  HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), g->grad_view(), g->d_sendbuf, g->s_main));
+  g->iter++;
+  // fused mode: this iteration's gradients ride with the previous iteration's deferred flux and
+  // go to the other grad buffer, which then becomes the current one (its ghost block is where
+  // the exchange between pre() and post() delivers)
+  const bool fused = g->will_fuse();
+  if (!fused && flush_flux(g)) return 1;
+  auto grad_tiles = [&](int which) { return fused ? launch_fused(g, which, g->s_main) : launch_grad(g, which, g->s_main); };
+  if (!comm) {
+    if (grad_tiles(CFDP_TILES_ALL)) return 1;
+    if (fused) fused_done(g);
+    return 0;
+  }
+  if (grad_tiles(overlap ? CFDP_TILES_BOUNDARY : CFDP_TILES_ALL)) return 1;
+  HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), fused ? g->alt_view() : g->grad_view(), g->d_sendbuf,
+                         g->s_main));
   HIP_TRY(hipEventRecord(g->ev_pack, g->s_main));
   HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_pack, 0));
   HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fluxdone, 0));
-  if (overlap && launch_grad(g, CFDP_TILES_INTERIOR, g->s_main)) return 1;
+  if (overlap && grad_tiles(CFDP_TILES_INTERIOR)) return 1;
+  if (fused) fused_done(g);
   return 0;
 }
 
@@ -428,7 +542,11 @@ int cfdp_gpu_step_post(cfdp_gpu *g, int with_flux, int flux_mode) {
     HIP_TRY(hipStreamWaitEvent(g->s_main, g->ev_senddone, 0));
   }
   g->pending_exchange = false;
-  if (with_flux && launch_flux(g, flux_mode, g->s_main)) return 1;
+  if (with_flux) {
+    if (flux_mode != CFDP_FLUX_CONSISTENT && flux_mode != CFDP_FLUX_REFERENCE) return fail("bad flux mode %d", flux_mode);
+    if (g->fusion && g->d_grad_alt) g->flux_pending = flux_mode;  // rides with the next gradients (or the next sync)
+    else if (launch_flux(g, flux_mode, g->s_main)) return 1;
+  }
   HIP_TRY(hipEventRecord(g->ev_fluxdone, g->s_main));
   return 0;
 }
@@ -441,13 +559,23 @@ int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, i
   NEED_UPLOAD(ga);
   const bool comm = with_exchange && !ga->partner.empty();
   ga->pending_exchange = comm;
-  if (!comm) return launch_grad(ga, CFDP_TILES_ALL, ga->s_main);
+  ga->iter++;
+  const bool fused = ga->will_fuse();  // see cfdp_gpu_step_pre
+  if (!fused && flush_flux(ga)) return 1;
+  auto grad_tiles = [&](int which) { return fused ? launch_fused(ga, which, ga->s_main) : launch_grad(ga, which, ga->s_main); };
+  if (!comm) {
+    if (grad_tiles(CFDP_TILES_ALL)) return 1;
+    if (fused) fused_done(ga);
+    return 0;
+  }
   // the send arena is free again once last iteration's peer copies have drained
   HIP_TRY(hipStreamWaitEvent(ga->s_main, ga->ev_senddone, 0));
-  if (launch_grad(ga, overlap ? CFDP_TILES_BOUNDARY : CFDP_TILES_ALL, ga->s_main)) return 1;
-  HIP_TRY(gg_launch_pack(ga->d_sendidx, ga->send_off.back(), ga->grad_view(), ga->d_sendbuf, ga->s_main));
+  if (grad_tiles(overlap ? CFDP_TILES_BOUNDARY : CFDP_TILES_ALL)) return 1;
+  HIP_TRY(gg_launch_pack(ga->d_sendidx, ga->send_off.back(), fused ? ga->alt_view() : ga->grad_view(),
+                         ga->d_sendbuf, ga->s_main));
   HIP_TRY(hipEventRecord(ga->ev_pack, ga->s_main));
-  if (overlap && launch_grad(ga, CFDP_TILES_INTERIOR, ga->s_main)) return 1;
+  if (overlap && grad_tiles(CFDP_TILES_INTERIOR)) return 1;
+  if (fused) fused_done(ga);
   HIP_TRY(hipStreamWaitEvent(ga->s_comm, ga->ev_pack, 0));
   for (size_t s = 0; s < ga->partner.size(); s++) {
     const int b = ga->partner[s];
@@ -460,6 +588,11 @@ int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, i
     size_t sbytes = 0, rbytes = 0;
     void *src = cfdp_gpu_send_ptr(ga, (int)s, &sbytes);
     void *dst = cfdp_gpu_recv_ptr(gb, slot, &rbytes);
+    // b's ghost block of THIS iteration: ranks of a group run their phases in lockstep, so b
+    // has either done its phase 1 already (iter equal: its buffers are swapped) or will fuse
+    // -- and swap -- when it gets there
+    if (gb->iter != ga->iter && gb->will_fuse())
+      dst = gb->alt_view().ghost + (size_t)gb->recv_off[slot] * 21;
     if (sbytes != rbytes) return fail("halo size mismatch %d->%d: %zu vs %zu bytes", a, b, sbytes, rbytes);
     if (!sbytes) continue;
     // b's ghost rows may still be read by b's previous flux (write-after-read)
@@ -478,7 +611,11 @@ int cfdp_gpu_rank_flux(cfdp_gpu **ranks, int G, int b, int with_flux, int flux_m
   if (gb->pending_exchange)
     for (int a : gb->partner) HIP_TRY(hipStreamWaitEvent(gb->s_main, ranks[a]->ev_senddone, 0));
   gb->pending_exchange = false;
-  if (with_flux && launch_flux(gb, flux_mode, gb->s_main)) return 1;
+  if (with_flux) {
+    if (flux_mode != CFDP_FLUX_CONSISTENT && flux_mode != CFDP_FLUX_REFERENCE) return fail("bad flux mode %d", flux_mode);
+    if (gb->fusion && gb->d_grad_alt) gb->flux_pending = flux_mode;
+    else if (launch_flux(gb, flux_mode, gb->s_main)) return 1;
+  }
   HIP_TRY(hipEventRecord(gb->ev_fluxdone, gb->s_main));
   return 0;
 }
@@ -502,6 +639,7 @@ int cfdp_gpu_sync_group(cfdp_gpu **ranks, int G) {
 int cfdp_gpu_time_kernels(cfdp_gpu *g, int iters, int flux_mode, float *ms_grad, float *ms_flux) {
   NEED_UPLOAD(g);
   if (iters < 1) return fail("iters must be >= 1");
+  if (flush_flux(g)) return 1;
   hipStream_t st = g->s_main;
   for (int w = 0; w < 2; w++) {
     if (launch_grad(g, CFDP_TILES_ALL, st)) return 1;
@@ -525,31 +663,92 @@ int cfdp_gpu_time_kernels(cfdp_gpu *g, int iters, int flux_mode, float *ms_grad,
   return 0;
 }
 
+int cfdp_gpu_time_fused(cfdp_gpu *g, int iters, int flux_mode, float *ms_fused) {
+  NEED_UPLOAD(g);
+  if (iters < 1) return fail("iters must be >= 1");
+  if (!g->fusion || !g->d_grad_alt) return fail("fusion is off");
+  if (flux_mode != CFDP_FLUX_CONSISTENT && flux_mode != CFDP_FLUX_REFERENCE) return fail("bad flux mode %d", flux_mode);
+  if (flush_flux(g)) return 1;
+  hipStream_t st = g->s_main;
+  if (launch_grad(g, CFDP_TILES_ALL, st)) return 1;
+  auto pass = [&]() -> int {
+    g->flux_pending = flux_mode;
+    if (launch_fused(g, CFDP_TILES_ALL, st)) return 1;
+    fused_done(g);
+    return 0;
+  };
+  for (int w = 0; w < 2; w++) if (pass()) return 1;
+  // timed as the iteration loop runs it: an even number of passes replayed from one hipGraph
+  // (stream launches add ~4 us of dependent-launch gap to every kernel)
+  iters += iters & 1;
+  hipGraph_t gr = nullptr;
+  hipGraphExec_t ge = nullptr;
+  HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  for (int i = 0; i < iters && !rc; i++) rc = pass();
+  hipError_t ec = hipStreamEndCapture(st, &gr);
+  if (rc) { if (gr) (void)hipGraphDestroy(gr); return 1; }
+  HIP_TRY(ec);
+  HIP_TRY(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+  HIP_TRY(hipGraphDestroy(gr));
+  HIP_TRY(hipGraphLaunch(ge, st));
+  HIP_TRY(hipEventRecord(g->ev_a, st));
+  HIP_TRY(hipGraphLaunch(ge, st));
+  HIP_TRY(hipEventRecord(g->ev_b, st));
+  HIP_TRY(hipEventSynchronize(g->ev_b));
+  HIP_TRY(hipGraphExecDestroy(ge));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, g->ev_a, g->ev_b));
+  if (ms_fused) *ms_fused = ms / (float)iters;
+  g->flux_pending = flux_mode;  // the last pass's gradients still owe their flux
+  return flush_flux(g);
+}
+
 int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode, int use_graph,
                             float *ms_total) {
   NEED_UPLOAD(g);
   if (iters < 1) return fail("iters must be >= 1");
+  if (with_flux && flux_mode != CFDP_FLUX_CONSISTENT && flux_mode != CFDP_FLUX_REFERENCE)
+    return fail("bad flux mode %d", flux_mode);
+  if (flush_flux(g)) return 1;
   hipStream_t st = g->s_main;
   const int chunk = 25;  // NITER of the reference harness (src/hybrid.f6.c:72)
+  const bool fuse = g->fusion && g->d_grad_alt && with_flux;
+  // n iterations, no exchange.  Fused mode: gradients(1), then n-1 passes of flux(i) +
+  // gradients(i+1), then flux(n) -- the same values as n x (gradients, flux), with the tile
+  // blobs streamed once per iteration.  An odd n leaves the two grad buffers where they were.
+  auto enqueue = [&](int n) -> int {
+    for (int i = 0; i < n; i++) {
+      if (fuse && g->flux_pending >= 0) {
+        if (launch_fused(g, CFDP_TILES_ALL, st)) return 1;
+        fused_done(g);
+      } else if (launch_grad(g, CFDP_TILES_ALL, st)) {
+        return 1;
+      }
+      if (fuse) g->flux_pending = flux_mode;
+      else if (with_flux && launch_flux(g, flux_mode, st)) return 1;
+    }
+    return flush_flux(g, false);
+  };
   if (use_graph) {
     const bool stale = !g->graph || g->graph_flux != with_flux || g->graph_mode != flux_mode ||
-                       g->graph_gl != g->grad_lanes || g->graph_fl != g->flux_lanes;
+                       g->graph_gl != g->grad_lanes || g->graph_fl != g->flux_lanes ||
+                       g->graph_fuse != (int)fuse || g->graph_cur != g->d_grad;
     if (stale) {
       if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
       hipGraph_t gr = nullptr;
+      const double *cur0 = g->d_grad;
       HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      int rc = 0;
-      for (int i = 0; i < chunk && !rc; i++) {
-        rc = launch_grad(g, CFDP_TILES_ALL, st);
-        if (!rc && with_flux) rc = launch_flux(g, flux_mode, st);
-      }
+      const int rc = enqueue(chunk);
       hipError_t ec = hipStreamEndCapture(st, &gr);
       if (rc) { if (gr) (void)hipGraphDestroy(gr); return 1; }
       HIP_TRY(ec);
+      if (g->d_grad != cur0) { (void)hipGraphDestroy(gr); return fail("graph chunk must leave the grad buffers in place"); }
       HIP_TRY(hipGraphInstantiate(&g->graph, gr, nullptr, nullptr, 0));
       HIP_TRY(hipGraphDestroy(gr));
       g->graph_iters = chunk; g->graph_flux = with_flux; g->graph_mode = flux_mode;
       g->graph_gl = g->grad_lanes; g->graph_fl = g->flux_lanes;
+      g->graph_fuse = (int)fuse; g->graph_cur = g->d_grad;
     }
   }
   HIP_TRY(hipEventRecord(g->ev_a, st));
@@ -559,9 +758,9 @@ int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode
       HIP_TRY(hipGraphLaunch(g->graph, st));
       done += chunk;
     } else {
-      if (launch_grad(g, CFDP_TILES_ALL, st)) return 1;
-      if (with_flux && launch_flux(g, flux_mode, st)) return 1;
-      done++;
+      const int n = use_graph ? iters - done : (iters - done < chunk ? iters - done : chunk);
+      if (enqueue(n)) return 1;
+      done += n;
     }
   }
   HIP_TRY(hipEventRecord(g->ev_b, st));

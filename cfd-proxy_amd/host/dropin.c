@@ -121,6 +121,11 @@ void init_threads(comm_data *cd, solver_data *sd, int NTHREADS) {
   GPU_OK(cfdp_gpu_create(rank % ndev, &gpu));
   GPU_OK(cfdp_gpu_upload_plan(gpu, plan));
   cfdp_plan_free(plan);
+  /* fused iterations: compute_psd_flux() defers the flux loop into the pass of the next
+   * compute_gradients_gg_*() over the same tiles (same values; any read-back or sync flushes
+   * it).  CFDP_FUSION=0 keeps one kernel per entry point.                                 */
+  const char *fus = getenv("CFDP_FUSION");
+  GPU_OK(cfdp_gpu_set_fusion(gpu, !(fus && atoi(fus) == 0)));
   grp->gpus[rank] = gpu;
   cfdp_solver *sv = cfdp_calloc(1, sizeof(*sv));
   sv->gpu = gpu; sv->group = grp; sv->rank = rank;

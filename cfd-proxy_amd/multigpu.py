@@ -98,7 +98,8 @@ class RankSolver:
     """The per-rank iteration: gradients (+ halo exchange) + pseudo flux on one GPU."""
 
     def __init__(self, part: Domain, rank: int, world: int, device: int, dist=None,
-                 transport: str = "rccl", tile_points: int = 0, grad_lanes: int = 0, flux_lanes: int = 0):
+                 transport: str = "rccl", tile_points: int = 0, grad_lanes: int = 0, flux_lanes: int = 0,
+                 fusion: bool = True):
         import torch
 
         self.torch = torch
@@ -117,6 +118,13 @@ class RankSolver:
         self.send_t = torch.empty(max(self.nsend, 1) * ROWLEN, dtype=torch.float64, device=self.device)
         self.gpu.bind_grad(self.grad_t.data_ptr())
         self.gpu.bind_sendbuf(self.send_t.data_ptr())
+        # fused iterations (flux(i) rides with gradients(i+1)): grad is double-buffered and the two
+        # buffers swap roles every iteration; the exchange delivers into the current one
+        self.grad_bufs = [self.grad_t]
+        if fusion:
+            self.grad_bufs.append(torch.empty_like(self.grad_t))
+            self.gpu.bind_grad_alt(self.grad_bufs[1].data_ptr())
+            self.gpu.set_fusion(True)
         # the context's own HIP streams, seen from torch (the transport enqueues on the comm stream;
         # all stream ordering of an iteration lives in cfdp_gpu_step_pre/_post)
         self.s_main = torch.cuda.ExternalStream(self.gpu.stream(0), device=self.device)
@@ -127,24 +135,28 @@ class RankSolver:
             rp, rb = self.gpu.recv_slice(s)
             so, ro = (sp - self.send_t.data_ptr()) // 8, (rp - self.grad_t.data_ptr()) // 8
             self.send_views.append(self.send_t[so:so + sb // 8])
-            self.recv_views.append(self.grad_t[ro:ro + rb // 8])  # whole rows inside the ghost block
+            # whole rows inside the ghost block, one view per grad buffer
+            self.recv_views.append([b[ro:ro + rb // 8] for b in self.grad_bufs])
         if transport == "staged":
             self.h_send = [torch.empty(v.numel(), dtype=torch.float64).pin_memory() for v in self.send_views]
-            self.h_recv = [torch.empty(v.numel(), dtype=torch.float64).pin_memory() for v in self.recv_views]
+            self.h_recv = [torch.empty(v[0].numel(), dtype=torch.float64).pin_memory() for v in self.recv_views]
 
     # ------------------------------------------------------------------------------ pieces
     def _exchange(self) -> None:
         """halo exchange, enqueued on the context's comm stream (step_pre has made that stream wait
         for the pack and for the previous flux, step_post makes the flux wait for it)"""
         torch, dist = self.torch, self.dist
+        cur = 0
+        if len(self.grad_bufs) > 1 and self.gpu.grad_ptr() == self.grad_bufs[1].data_ptr():
+            cur = 1  # the buffer this iteration's gradients went to
         with torch.cuda.stream(self.s_comm):
             if self.transport == "rccl":
                 ops = []
                 for s, peer in enumerate(self.partners):
                     if self.send_views[s].numel():
                         ops.append(dist.P2POp(dist.isend, self.send_views[s], peer))
-                    if self.recv_views[s].numel():
-                        ops.append(dist.P2POp(dist.irecv, self.recv_views[s], peer))
+                    if self.recv_views[s][cur].numel():
+                        ops.append(dist.P2POp(dist.irecv, self.recv_views[s][cur], peer))
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()  # orders s_comm after the RCCL stream; does not block the host
             else:  # staged through the host (tests only)
@@ -160,7 +172,7 @@ class RankSolver:
                 for r in reqs:
                     r.wait()
                 for s in range(len(self.partners)):
-                    self.recv_views[s].copy_(self.h_recv[s], non_blocking=True)
+                    self.recv_views[s][cur].copy_(self.h_recv[s], non_blocking=True)
 
     def step(self, with_exchange: bool = True, overlap: bool = True, with_flux: bool = True,
              flux_mode: int = FLUX_CONSISTENT) -> None:
@@ -173,6 +185,7 @@ class RankSolver:
         self.gpu.step_post(with_flux, flux_mode)
 
     def synchronize(self) -> None:
+        self.gpu.sync()  # also runs a flux deferred by the fused mode
         self.torch.cuda.synchronize(self.device)
 
     def grad_host(self) -> np.ndarray:

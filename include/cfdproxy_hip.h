@@ -66,6 +66,19 @@ int  cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *plan);
 int  cfdp_gpu_bind_grad(cfdp_gpu *g, void *dev_grad);
 int  cfdp_gpu_bind_sendbuf(cfdp_gpu *g, void *dev_sendbuf);
 
+/* Fused iterations.  Both face loops read the same tile data (normals + incidence lists, more
+ * than half of either kernel's HBM traffic).  With fusion on, the iteration-level entry points
+ * (cfdp_gpu_step_pre/_post, cfdp_gpu_rank_gradients/_rank_flux, cfdp_gpu_iteration_group,
+ * cfdp_gpu_run_iterations) DEFER the flux of iteration i and compute it in the same pass over
+ * the tiles as the gradients of iteration i+1 (grad is double-buffered; a deferred flux is
+ * flushed by cfdp_gpu_sync, the get/set calls and the eager launch calls).  Values are
+ * bit-identical to the separate kernels.  Default: off.  cfdp_gpu_bind_grad_alt: caller-owned
+ * memory for the second grad buffer (same size and layout as cfdp_gpu_bind_grad's); the two
+ * buffers swap roles every fused iteration -- cfdp_gpu_grad_ptr/_recv_ptr always refer to the
+ * one holding (receiving) the latest gradients.                                            */
+int  cfdp_gpu_set_fusion(cfdp_gpu *g, int on);
+int  cfdp_gpu_bind_grad_alt(cfdp_gpu *g, void *dev_grad);
+
 /* host <-> device fields, FILE numbering on the host side: var [nall][7], grad
  * [nall][7][3], psd_flux [nall][3] (ghost rows of psd_flux are not computed)             */
 int  cfdp_gpu_set_var(cfdp_gpu *g, const double *var);
@@ -117,6 +130,8 @@ int  cfdp_gpu_step_post(cfdp_gpu *g, int with_flux, int flux_mode);
 /* measurement: `iters` back-to-back launches bracketed by HIP events on the context's
  * main stream; average milliseconds per launch (gradient over all tiles; flux)           */
 int  cfdp_gpu_time_kernels(cfdp_gpu *g, int iters, int flux_mode, float *ms_grad, float *ms_flux);
+/* average milliseconds of the fused pass (flux(i) + gradients(i+1), all tiles); fusion on  */
+int  cfdp_gpu_time_fused(cfdp_gpu *g, int iters, int flux_mode, float *ms_fused);
 /* K full iterations (gradients [+flux]) captured in one hipGraph and replayed            */
 int  cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode,
                              int use_graph, float *ms_total);

@@ -55,16 +55,22 @@ def main():
     assert np.array_equal(part.var, whole.var[gid])
 
     if args.gpu:
-        solver = mg.RankSolver(part, rank, world, 0, dist, transport="staged", tile_points=32)
-        for overlap in (True, False):
-            part.grad[:] = 1.0
-            solver.gpu.push_fields()
-            solver.step(with_exchange=True, overlap=overlap, with_flux=True)
-            solver.step(with_exchange=True, overlap=overlap, with_flux=True)  # twice: buffer reuse hazards
-            g = solver.grad_host().copy()
-            err = np.abs(g - truth[gid]).max() / np.abs(truth).max()
-            assert err <= 1e-12, (rank, overlap, err)
-        solver.close()
+        ftruth = orc.np_flux(whole.fpoint, whole.fnormal, truth, whole.nown, mode=0)
+        for fusion in (False, True):
+            solver = mg.RankSolver(part, rank, world, 0, dist, transport="staged", tile_points=32, fusion=fusion)
+            for overlap in (True, False):
+                part.grad[:] = 1.0
+                part.psd_flux[:] = 2.0
+                solver.gpu.push_fields()
+                for _ in range(3):  # repeated: buffer reuse hazards, both grad buffers of the fused mode
+                    solver.step(with_exchange=True, overlap=overlap, with_flux=True)
+                g = solver.grad_host().copy()
+                err = np.abs(g - truth[gid]).max() / np.abs(truth).max()
+                assert err <= 1e-12, (rank, fusion, overlap, err)
+                f = part.psd_flux[: part.nown]
+                ferr = np.abs(f - ftruth[gid[: part.nown]]).max() / np.abs(ftruth[: whole.nown]).max()
+                assert ferr <= 1e-12, (rank, fusion, overlap, ferr)
+            solver.close()
     else:
         ref = orc.CpuRef(part.fpoint, part.fnormal, part.pvolume, part.nown, nthreads=2, sendpoints=part.send_points())
         g = ref.gradients(part.var)

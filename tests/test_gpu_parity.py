@@ -383,3 +383,85 @@ def test_driver_binary_with_reference_cli(gpu, tmp_path):
     assert "*** SUCCESS" in r.stdout and "comm_free:" in r.stdout and "exchange_dbl_xgmi_async:" in r.stdout
     r = subprocess.run([exe, "-bad"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "Usage" in r.stdout
+
+
+# ------------------------------------------------------------------ fused iterations
+@pytest.mark.parametrize("flux_mode", [0, 1])
+@pytest.mark.parametrize("tile_points", [16, 64])
+def test_fused_iterations_are_bit_identical_to_separate_kernels(gpu, orc, flux_mode, tile_points):
+    """flux(i) + gradients(i+1) in one pass over the tiles == the two kernels, bit for bit; the
+    deferred flux is flushed by sync / get; graph replay and stream launches agree"""
+    pkg = gpu
+    gp = pkg.gen_params(24, 20, 18, ndomains=1)
+    dom = pkg.gen_domain(gp, 0)
+    pkg.fill_var(dom, None, pkg.VAR_HASH)
+    # the reference-mode flux is the reference's ONE-thread result (it depends on the thread count)
+    ref = orc.CpuRef(dom.fpoint, dom.fnormal, dom.pvolume, dom.nown, nthreads=1 if flux_mode else 4)
+    g_ref = ref.gradients(dom.var.copy())
+    f_ref = ref.flux(g_ref, mode=flux_mode)
+    ref.close()
+    part = pkg.GpuPartition(dom, tile_points=tile_points)
+    part.run_iterations(3, True, flux_mode, use_graph=False)
+    part.pull_fields()
+    g0, f0 = dom.grad.copy(), dom.psd_flux.copy()
+    assert np.abs(g0 - g_ref).max() <= TOL * np.abs(g_ref).max()
+    assert np.abs(f0[: dom.nown] - f_ref[: dom.nown]).max() <= TOL * np.abs(f_ref).max()
+    part.set_fusion(True)
+    for iters, graph in ((1, False), (2, False), (4, False), (25, True), (27, True), (50, True)):
+        dom.grad[:] = -3.0
+        dom.psd_flux[:] = 5.0
+        part.push_fields()
+        part.run_iterations(iters, True, flux_mode, use_graph=graph)
+        part.pull_fields()
+        assert np.array_equal(dom.grad[: dom.nown], g0[: dom.nown]), (iters, graph)
+        assert np.array_equal(dom.psd_flux[: dom.nown], f0[: dom.nown]), (iters, graph)
+        assert np.all(dom.grad[dom.nown:] == -3.0)          # ghost rows untouched without an exchange
+    # the iteration brackets defer the flux; the eager calls and the getters flush it
+    dom.psd_flux[:] = 5.0
+    part.push_fields()
+    for _ in range(3):
+        part.step_pre(False, False)
+        part.step_post(True, flux_mode)
+    part.pull_fields()
+    assert np.array_equal(dom.grad[: dom.nown], g0[: dom.nown]) and np.array_equal(dom.psd_flux[: dom.nown], f0[: dom.nown])
+    ms = part.time_fused(3, flux_mode)
+    assert ms > 0
+    part.pull_fields()
+    assert np.array_equal(dom.grad[: dom.nown], g0[: dom.nown]) and np.array_equal(dom.psd_flux[: dom.nown], f0[: dom.nown])
+    part.set_fusion(False)
+    part.run_iterations(2, True, flux_mode, use_graph=False)
+    part.pull_fields()
+    assert np.array_equal(dom.grad[: dom.nown], g0[: dom.nown]) and np.array_equal(dom.psd_flux[: dom.nown], f0[: dom.nown])
+    part.close()
+    dom.free()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_fused_iterations_with_halo_exchange_between_in_process_ranks(gpu, orc, overlap):
+    """4 domains on 2 and 4 in-process ranks: with fusion the ghost rows land in the buffer the
+    next fused pass reads; grad (ghost rows included) and flux equal the unfused run bitwise"""
+    pkg = gpu
+    from cfd_proxy_amd import multigpu as mg
+    nd = 4
+    gp = pkg.gen_params(14, 12, 10, ndomains=nd)
+    for G in (2, 4):
+        results = []
+        for fusion in (False, True):
+            parts = [mg.build_rank_partition(gp, nd, G, r, via_files=False)[0] for r in range(G)]
+            pkg.merge_link_group(parts)
+            gparts = [pkg.GpuPartition(p, tile_points=32) for p in parts]
+            for gpart in gparts:
+                gpart.set_fusion(fusion)
+            for _ in range(4):
+                pkg.group_iteration(gparts, with_exchange=True, overlap=overlap, with_flux=True)
+            pkg.group_sync(gparts)
+            out = []
+            for p, gpart in zip(parts, gparts):
+                gpart.pull_fields()
+                out.append((p.grad.copy(), p.psd_flux[: p.nown].copy()))
+                gpart.close()
+            results.append(out)
+        for (g_a, f_a), (g_b, f_b) in zip(*results):
+            assert np.array_equal(g_a, g_b)
+            assert np.array_equal(f_a, f_b)
+            assert np.abs(g_a).max() > 0

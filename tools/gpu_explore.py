@@ -44,5 +44,15 @@ for n in sizes:
                     err = "relerr grad %.2e flux %.2e" % (e1, e2)
                 log("n", n, "tp", tp, "L", L, "pipe", pipe, "grad %.1f us %.0f GB/s (%.1f%% of 8TB/s)" % (mg * 1e3, bg / mg / 1e6, bg / mg / 1e6 / 80),
                     "flux %.1f us %.0f GB/s" % (mf * 1e3, bf / mf / 1e6), "lds", part.stats["lds_grad"], err)
+            if L == 4 and not os.environ.get("NO_FUSED"):
+                part.set_pipeline(0)
+                part.set_fusion(True)
+                mfu = part.time_fused(iters); mfu = part.time_fused(iters)
+                it = 100
+                part.run_iterations(it); t_f = part.run_iterations(it) / it
+                part.set_fusion(False)
+                part.run_iterations(it); t_s = part.run_iterations(it) / it
+                log("n", n, "tp", tp, "fused pass %.1f us (%.0f GB/s algorithmic = %.1f%% of 8TB/s)" % (mfu * 1e3, (bg + bf) / mfu / 1e6, (bg + bf) / mfu / 1e6 / 80),
+                    "iteration fused %.1f us, separate %.1f us" % (t_f * 1e3, t_s * 1e3))
             part.close()
     dom.free()
