@@ -74,6 +74,9 @@ template <bool NT> __device__ __forceinline__ void st_row(double v, double *p) {
 #ifndef GG_DEEP_BATCH
 #define GG_DEEP_BATCH 7
 #endif
+#ifndef GG_FLUX_BATCH
+#define GG_FLUX_BATCH 1
+#endif
 #ifndef GG_WAVES_EU
 #define GG_WAVES_EU 4
 #endif
@@ -227,6 +230,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     const size_t p0 = (size_t)(td.pstart + wp + h * SPP);
     double *ga = gradA + p0 * 10, *gb = gradB + p0 * 11;
     const int na = nvh * 10, nd = nvh * 21;
+    if (dbg & 256) continue;  // timing experiment: no row stores
     for (int c = lane; c < nd; c += 64) {
       if (c < na) st_row<NT>(slab[c], &ga[c]);
       else st_row<NT>(slab[SPP * 10 + c - na], &gb[c - na]);
@@ -456,11 +460,37 @@ __global__ __launch_bounds__(1024) void gg_gradient_pipe_kernel(
 // wave shuffles in a fixed order (deterministic).
 // The per-tile flux arithmetic.  `smem` holds the tile blob, `g_l` the 3x3 velocity-gradient
 // blocks of own + halo points, 10 doubles (80 bytes) per row.
+//
+// The viscous stress is linear in the velocity gradient, and the face value is the mean of the
+// two ends (src/flux.c:139-173): flux = -stress(0.5*(g0+g1)).n = (P(g0) + P(g1)).n with
+// P(g) = -0.5*stress(g).  P (6 doubles) is computed ONCE per staged row, in place, instead of
+// once per incidence: 6 adds + 9 FMAs per incidence instead of ~48 fp64 operations -- the fp64
+// vector rate, not LDS or HBM, bounded this loop (measured: the flux phase cost 64 us of the
+// 331-us fused pass on the 128^3 mesh).  Differs from the reference's association by round-off.
 template <int LPP, bool REFMODE>
-__device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, const double *g_l,
+__device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, double *g_l,
                                                   const cfdp_tile_desc &td, const int *__restrict__ hid,
-                                                  int tid, double *__restrict__ flux, int nown) {
+                                                  int tid, int nthr, double *__restrict__ flux, int nown) {
   const int npts = td.npts;
+  {
+    const double mue_eff = 1.0, lambda = -2.0 / 3.0 * mue_eff;  // src/flux.c:125,163
+    const int nrows = npts + td.nhalo;
+    for (int r = tid; r < nrows; r += nthr) {
+      double *g = g_l + r * 10;
+      const double dvx_dx = g[0], dvx_dy = g[1], dvx_dz = g[2];
+      const double dvy_dx = g[3], dvy_dy = g[4], dvy_dz = g[5];
+      const double dvz_dx = g[6], dvz_dy = g[7], dvz_dz = g[8];
+      const double sts_xx = lambda * (dvy_dy + dvz_dz - 2.0 * dvx_dx);
+      const double sts_yy = lambda * (dvx_dx + dvz_dz - 2.0 * dvy_dy);
+      const double sts_zz = lambda * (dvx_dx + dvy_dy - 2.0 * dvz_dz);
+      const double sts_xy = mue_eff * (dvx_dy + dvy_dx);
+      const double sts_xz = mue_eff * (dvx_dz + dvz_dx);
+      const double sts_yz = mue_eff * (dvy_dz + dvz_dy);
+      g[0] = -0.5 * sts_xx; g[1] = -0.5 * sts_xy; g[2] = -0.5 * sts_xz;
+      g[3] = -0.5 * sts_yy; g[4] = -0.5 * sts_yz; g[5] = -0.5 * sts_zz;
+    }
+    __syncthreads();
+  }
   const int li = tid / LPP, sub = tid % LPP;
   const bool active = li < npts;
   const int plane = (td.nfaces * 8 + 15) & ~15;
@@ -476,39 +506,50 @@ __device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, con
   if (active) {
     ks = (int)ioff[li];
     ke = (int)ioff[li + 1];
-    double gs[9];
+    double ps[6];
 #pragma unroll
-    for (int c = 0; c < 9; c++) gs[c] = g_l[li * 10 + c];
-    for (int k = ks + sub; k < ke; k += LPP) {
-      const uint32_t w = inc[k];
-      const int nbr = (int)(w & 0xFFFFu), f = (int)((w >> 16) & 0x7FFFu);
-      const bool is_p1 = (w >> 31) != 0;
-      if (REFMODE && !is_p1) {
-        // reference 1-thread semantics (src/flux.c:177-182 with the class numbering of
-        // src/rangelist.c:719-736): the p0 end only receives +flux when p1 is a ghost
-        const bool nbr_ghost = nbr >= npts && hid[nbr - npts] >= nown;
-        if (!nbr_ghost) continue;
+    for (int c = 0; c < 6; c++) ps[c] = g_l[li * 10 + c];
+    // U of this lane's incidences per batch: all incidence words, then all operands, then the
+    // FMAs, so the lane pays the LDS round trips once per batch (as in grad_batch).  With few
+    // lanes per point a lane has ~4 incidences and runs in a workgroup of few waves: U = 4.
+    constexpr int U = LPP <= 4 ? GG_FLUX_BATCH : 1;
+    for (int k = ks + sub; k < ke; k += U * LPP) {
+      uint32_t w[U];
+      bool on[U];
+#pragma unroll
+      for (int i = 0; i < U; i++) {
+        on[i] = k + i * LPP < ke;
+        w[i] = inc[on[i] ? k + i * LPP : k];
       }
-      const double nx = fnx[f], ny = fny[f], nz = fnz[f];
-      const double *gn = g_l + nbr * 10;
-      const double dvx_dx = 0.5 * (gs[0] + gn[0]), dvx_dy = 0.5 * (gs[1] + gn[1]),
-                   dvx_dz = 0.5 * (gs[2] + gn[2]);
-      const double dvy_dx = 0.5 * (gs[3] + gn[3]), dvy_dy = 0.5 * (gs[4] + gn[4]),
-                   dvy_dz = 0.5 * (gs[5] + gn[5]);
-      const double dvz_dx = 0.5 * (gs[6] + gn[6]), dvz_dy = 0.5 * (gs[7] + gn[7]),
-                   dvz_dz = 0.5 * (gs[8] + gn[8]);
-      const double mue_eff = 1.0, lambda = -2.0 / 3.0 * mue_eff;  // src/flux.c:125,163
-      const double sts_xx = lambda * (dvy_dy + dvz_dz - 2.0 * dvx_dx);
-      const double sts_yy = lambda * (dvx_dx + dvz_dz - 2.0 * dvy_dy);
-      const double sts_zz = lambda * (dvx_dx + dvy_dy - 2.0 * dvz_dz);
-      const double sts_xy = mue_eff * (dvx_dy + dvy_dx);
-      const double sts_xz = mue_eff * (dvx_dz + dvz_dx);
-      const double sts_yz = mue_eff * (dvy_dz + dvz_dy);
-      const double fl0 = -(sts_xx * nx + sts_xy * ny + sts_xz * nz);
-      const double fl1 = -(sts_xy * nx + sts_yy * ny + sts_yz * nz);
-      const double fl2 = -(sts_xz * nx + sts_yz * ny + sts_zz * nz);
-      if (is_p1) { f0 -= fl0; f1 -= fl1; f2 -= fl2; }
-      else       { f0 += fl0; f1 += fl1; f2 += fl2; }
+      double sx[U], sy[U], sz[U], pn[U][6];
+#pragma unroll
+      for (int i = 0; i < U; i++) {
+        const int nbr = (int)(w[i] & 0xFFFFu), f = (int)((w[i] >> 16) & 0x7FFFu);
+        if (REFMODE && !(w[i] >> 31)) {
+          // reference 1-thread semantics (src/flux.c:177-182 with the class numbering of
+          // src/rangelist.c:719-736): the p0 end only receives +flux when p1 is a ghost
+          const bool nbr_ghost = nbr >= npts && hid[nbr - npts] >= nown;
+          on[i] = on[i] && nbr_ghost;
+        }
+        sx[i] = fnx[f]; sy[i] = fny[f]; sz[i] = fnz[f];
+        const double *p = g_l + nbr * 10;
+#pragma unroll
+        for (int c = 0; c < 6; c++) pn[i][c] = p[c];
+      }
+#pragma unroll
+      for (int i = 0; i < U; i++) {
+        if (!on[i]) continue;
+        // the p1 end subtracts (src/flux.c:184-188): flip the normal (bit 31 of w = sign bit)
+        const int sgn = (int)(w[i] & 0x80000000u);
+        const double nx = __hiloint2double(__double2hiint(sx[i]) ^ sgn, __double2loint(sx[i]));
+        const double ny = __hiloint2double(__double2hiint(sy[i]) ^ sgn, __double2loint(sy[i]));
+        const double nz = __hiloint2double(__double2hiint(sz[i]) ^ sgn, __double2loint(sz[i]));
+        const double txx = ps[0] + pn[i][0], txy = ps[1] + pn[i][1], txz = ps[2] + pn[i][2];
+        const double tyy = ps[3] + pn[i][3], tyz = ps[4] + pn[i][4], tzz = ps[5] + pn[i][5];
+        f0 = fma(txx, nx, fma(txy, ny, fma(txz, nz, f0)));
+        f1 = fma(txy, nx, fma(tyy, ny, fma(tyz, nz, f1)));
+        f2 = fma(txz, nx, fma(tyz, ny, fma(tzz, nz, f2)));
+      }
     }
   }
   // combine the LPP partial sums (lanes of one point are adjacent, LPP divides 64)
@@ -548,7 +589,7 @@ __global__ __launch_bounds__(1024) void gg_flux_kernel(
   }
   __syncthreads();
 
-  flux_tile_compute<LPP, REFMODE>(smem, g_l, td, hid, tid, flux, nown);
+  flux_tile_compute<LPP, REFMODE>(smem, g_l, td, hid, tid, nthr, flux, nown);
 }
 
 // one workgroup per tile, fixed-count LDS-DMA staging (see gg_gradient_dma_kernel): the blob as CB
@@ -603,7 +644,7 @@ __global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
     glds16(reinterpret_cast<const uint4 *>(src + part[k] * 16), gbuf + (size_t)(w0 + k * nthr) * 16);
   }
   __syncthreads();
-  flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<const double *>(gbuf), td, hid, tid, flux, nown);
+  flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
 }
 
 // ------------------------------------------------------------------- fused iteration kernel
@@ -684,7 +725,9 @@ void gg_fused_dma_kernel(
     glds16(reinterpret_cast<const uint4 *>(src + part[k] * 16), gbuf + (size_t)(w0 + k * nthr) * 16);
   }
   __syncthreads();
-  flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<const double *>(gbuf), td, hid, tid, flux, nown);
+  if (!(dbg & 128))  // timing experiment: no flux phase
+    flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
+  if (dbg & 512) return;  // timing experiment: no gradient phase
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(gbuf), dbg,
                                    CB * nthr * 16);
 }

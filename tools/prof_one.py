@@ -9,4 +9,7 @@ gp = m.gen_params(n, ndomains=1); dom = m.gen_domain(gp, 0); m.fill_var(dom, Non
 part = m.GpuPartition(dom, tile_points=tp, grad_lanes=L, flux_lanes=8); part.set_pipeline(pipe)
 g, f = part.time_kernels(iters)
 print("n", n, "tp", tp, "L", L, "pipe", pipe, "grad us", g * 1e3, "flux us", f * 1e3, flush=True)
+if os.environ.get("FUSED", "1") != "0":
+    part.set_fusion(True)
+    print("fused pass us", part.time_fused(iters) * 1e3, flush=True)
 part.close()
