@@ -233,6 +233,7 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_step_post.argtypes = [vp, C.c_int, C.c_int]
     lib.cfdp_gpu_time_kernels.argtypes = [vp, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]
     lib.cfdp_gpu_run_iterations.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]
+    lib.cfdp_gpu_vcycle.argtypes = [P(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]
     lib.cfdp_gpu_counts.argtypes = [vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
 
 
@@ -678,6 +679,18 @@ def group_iteration(parts: Sequence[GpuPartition], with_exchange=True, overlap=T
     rc = lib.cfdp_gpu_iteration_group(arr, len(parts), int(with_exchange), int(overlap), int(with_flux), flux_mode)
     if rc:
         raise GpuError(lib.cfdp_gpu_last_error().decode())
+
+
+def vcycle(levels: Sequence[GpuPartition], sweeps: int = 3, cycles: int = 1, flux_mode: int = FLUX_CONSISTENT,
+           use_graph: bool = True) -> float:
+    """`cycles` multigrid V cycles over `levels` (finest first; one partition per level, one
+    device): `sweeps` iterations per level down and up.  Milliseconds per cycle."""
+    lib = hip_lib()
+    arr = (C.c_void_p * len(levels))(*[p.h for p in levels])
+    ms = C.c_float()
+    if lib.cfdp_gpu_vcycle(arr, len(levels), sweeps, cycles, flux_mode, int(use_graph), C.byref(ms)):
+        raise GpuError(lib.cfdp_gpu_last_error().decode())
+    return ms.value
 
 
 def group_sync(parts: Sequence[GpuPartition]) -> None:

@@ -258,12 +258,12 @@ int cfdp_gpu_bind_sendbuf(cfdp_gpu *g, void *dev_sendbuf) {
 static int launch_flux(cfdp_gpu *g, int mode, hipStream_t st);
 
 // run the deferred flux of the last fused-mode iteration, if any
-static int flush_flux(cfdp_gpu *g, bool record = true) {
+static int flush_flux(cfdp_gpu *g, bool record = true, hipStream_t st = nullptr) {
   if (g->flux_pending < 0) return 0;
   const int mode = g->flux_pending;
   g->flux_pending = -1;
-  if (launch_flux(g, mode, g->s_main)) return 1;
-  if (record) HIP_TRY(hipEventRecord(g->ev_fluxdone, g->s_main));
+  if (launch_flux(g, mode, st ? st : g->s_main)) return 1;
+  if (record) HIP_TRY(hipEventRecord(g->ev_fluxdone, st ? st : g->s_main));
   return 0;
 }
 
@@ -663,6 +663,25 @@ int cfdp_gpu_time_kernels(cfdp_gpu *g, int iters, int flux_mode, float *ms_grad,
   return 0;
 }
 
+// n iterations of one partition on stream `st`, no exchange.  Fused mode: gradients(1), then n-1
+// passes of flux(i) + gradients(i+1), then flux(n) -- the same values as n x (gradients, flux),
+// with the tile blobs streamed once per iteration.  An odd n leaves the two grad buffers where
+// they were.
+static int enqueue_iterations(cfdp_gpu *g, int n, int with_flux, int flux_mode, hipStream_t st) {
+  const bool fuse = g->fusion && g->d_grad_alt && with_flux;
+  for (int i = 0; i < n; i++) {
+    if (fuse && g->flux_pending >= 0) {
+      if (launch_fused(g, CFDP_TILES_ALL, st)) return 1;
+      fused_done(g);
+    } else if (launch_grad(g, CFDP_TILES_ALL, st)) {
+      return 1;
+    }
+    if (fuse) g->flux_pending = flux_mode;
+    else if (with_flux && launch_flux(g, flux_mode, st)) return 1;
+  }
+  return flush_flux(g, false, st);
+}
+
 int cfdp_gpu_time_fused(cfdp_gpu *g, int iters, int flux_mode, float *ms_fused) {
   NEED_UPLOAD(g);
   if (iters < 1) return fail("iters must be >= 1");
@@ -714,22 +733,7 @@ int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode
   hipStream_t st = g->s_main;
   const int chunk = 25;  // NITER of the reference harness (src/hybrid.f6.c:72)
   const bool fuse = g->fusion && g->d_grad_alt && with_flux;
-  // n iterations, no exchange.  Fused mode: gradients(1), then n-1 passes of flux(i) +
-  // gradients(i+1), then flux(n) -- the same values as n x (gradients, flux), with the tile
-  // blobs streamed once per iteration.  An odd n leaves the two grad buffers where they were.
-  auto enqueue = [&](int n) -> int {
-    for (int i = 0; i < n; i++) {
-      if (fuse && g->flux_pending >= 0) {
-        if (launch_fused(g, CFDP_TILES_ALL, st)) return 1;
-        fused_done(g);
-      } else if (launch_grad(g, CFDP_TILES_ALL, st)) {
-        return 1;
-      }
-      if (fuse) g->flux_pending = flux_mode;
-      else if (with_flux && launch_flux(g, flux_mode, st)) return 1;
-    }
-    return flush_flux(g, false);
-  };
+  auto enqueue = [&](int n) -> int { return enqueue_iterations(g, n, with_flux, flux_mode, st); };
   if (use_graph) {
     const bool stale = !g->graph || g->graph_flux != with_flux || g->graph_mode != flux_mode ||
                        g->graph_gl != g->grad_lanes || g->graph_fl != g->flux_lanes ||
@@ -768,6 +772,71 @@ int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, g->ev_a, g->ev_b));
   if (ms_total) *ms_total = ms;
+  return 0;
+}
+
+// ------------------------------------------------------------------------ multigrid V cycle
+// The published experiment is a "3V multigrid cycle" (documentation/CFD-Proxy.pdf p.3): `sweeps`
+// iterations on every level going down, and again going up; the reference has no transfer
+// operators -- a level is just another set of dualgrid files (src/hybrid.f6.c:38-47, -lvl).  The
+// coarse levels are a few tiles each and pure launch latency, so one whole cycle over all levels
+// (one partition per level, all on one device) is captured in ONE hipGraph and replayed.
+int cfdp_gpu_vcycle(cfdp_gpu **levels, int nlevels, int sweeps, int cycles, int flux_mode,
+                    int use_graph, float *ms_per_cycle) {
+  if (!levels || nlevels < 1 || sweeps < 1 || cycles < 1) return fail("bad V-cycle arguments");
+  if (flux_mode != CFDP_FLUX_CONSISTENT && flux_mode != CFDP_FLUX_REFERENCE) return fail("bad flux mode %d", flux_mode);
+  for (int l = 0; l < nlevels; l++) {
+    NEED_UPLOAD(levels[l]);
+    if (levels[l]->device != levels[0]->device) return fail("all levels of a V cycle must live on one device");
+    if (flush_flux(levels[l])) return 1;
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  cfdp_gpu *g0 = levels[0];
+  hipStream_t st = g0->s_main;
+  auto one_cycle = [&]() -> int {
+    for (int l = 0; l < nlevels; l++)
+      if (enqueue_iterations(levels[l], sweeps, 1, flux_mode, st)) return 1;
+    for (int l = nlevels - 2; l >= 0; l--)
+      if (enqueue_iterations(levels[l], sweeps, 1, flux_mode, st)) return 1;
+    return 0;
+  };
+  hipGraphExec_t ge = nullptr;
+  if (use_graph) {
+    std::vector<const double *> cur0;
+    for (int l = 0; l < nlevels; l++) cur0.push_back(levels[l]->d_grad);
+    hipGraph_t gr = nullptr;
+    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = one_cycle();
+    hipError_t ec = hipStreamEndCapture(st, &gr);
+    if (rc) { if (gr) (void)hipGraphDestroy(gr); return 1; }
+    HIP_TRY(ec);
+    bool in_place = true;
+    for (int l = 0; l < nlevels; l++) in_place = in_place && levels[l]->d_grad == cur0[l];
+    if (in_place) HIP_TRY(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+    // else (even `sweeps` with fusion: a cycle swaps the coarsest level's buffers): the capture
+    // only served as cycle number one's dry run; launch from the stream instead
+    HIP_TRY(hipGraphDestroy(gr));
+    if (!in_place)
+      for (int l = 0; l < nlevels; l++)
+        if (levels[l]->d_grad != cur0[l]) {
+          std::swap(levels[l]->d_grad, levels[l]->d_grad_alt);
+          std::swap(levels[l]->own_grad, levels[l]->own_grad_alt);
+        }
+  }
+  auto run = [&]() -> int {
+    if (ge) { HIP_TRY(hipGraphLaunch(ge, st)); return 0; }
+    return one_cycle();
+  };
+  if (run()) return 1;  // warm
+  HIP_TRY(hipEventRecord(g0->ev_a, st));
+  for (int c = 0; c < cycles; c++)
+    if (run()) return 1;
+  HIP_TRY(hipEventRecord(g0->ev_b, st));
+  HIP_TRY(hipEventSynchronize(g0->ev_b));
+  if (ge) HIP_TRY(hipGraphExecDestroy(ge));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, g0->ev_a, g0->ev_b));
+  if (ms_per_cycle) *ms_per_cycle = ms / (float)cycles;
   return 0;
 }
 

@@ -195,6 +195,59 @@ void compute_psd_flux(solver_data *sd) {
 
 /* -------------------------------------------------------------------------- test_solver */
 #define N_MEDIAN 25
+
+static int cmp_double(const void *a, const void *b);
+
+/* ------------------------------------------------------------------------ cfdp_test_vcycle
+ * The published experiment (documentation/CFD-Proxy.pdf p.3) is a "3V multigrid cycle": SWEEPS
+ * iterations on every level, finest to coarsest and back.  The reference itself only runs one
+ * level per process start (-lvl, src/hybrid.f6.c:38-47) and has no transfer operators, so a
+ * cycle here is the same iteration (gradients + halo exchange + flux) looped over the levels'
+ * rank groups.  One rank per level: the whole cycle is one hipGraph (cfdp_gpu_vcycle); several
+ * ranks: stream launches with the overlapped ("async") exchange.  Prints the median seconds
+ * per cycle over N_MEDIAN samples of NCYCLES cycles, in the style of the TIMINGS block.      */
+void cfdp_test_vcycle(int nlevels, cfdp_group **levels, int sweeps, int ncycles) {
+  CFDP_ASSERT(nlevels >= 1 && levels != NULL && sweeps >= 1 && ncycles >= 1);
+  int single = 1;
+  for (int l = 0; l < nlevels; l++) single = single && levels[l]->G == 1;
+  double median[N_MEDIAN];
+  cfdp_gpu **lv = cfdp_calloc((size_t)nlevels, sizeof(*lv));
+  for (int l = 0; l < nlevels; l++) lv[l] = levels[l]->gpus[0];
+  for (int k = 0; k < N_MEDIAN; k++) {
+    if (single) {
+      float ms = 0.f;
+      GPU_OK(cfdp_gpu_vcycle(lv, nlevels, sweeps, ncycles, levels[0]->flux_mode, 1, &ms));
+      median[k] = (double)ms * 1e-3;
+    } else {
+      for (int l = 0; l < nlevels; l++) GPU_OK(cfdp_gpu_sync_group(levels[l]->gpus, levels[l]->G));
+      double t = -cfdp_now();
+      for (int c = 0; c < ncycles; c++)
+        for (int v = 0; v < 2 * nlevels - 1; v++) {
+          cfdp_group *g = levels[v < nlevels ? v : 2 * nlevels - 2 - v];
+          for (int i = 0; i < sweeps; i++) {
+            for (int r = 0; r < g->G; r++) GPU_OK(cfdp_gpu_rank_gradients(g->gpus, g->G, r, 1, 1));
+            for (int r = 0; r < g->G; r++) GPU_OK(cfdp_gpu_rank_flux(g->gpus, g->G, r, 1, g->flux_mode));
+          }
+        }
+      for (int l = 0; l < nlevels; l++) GPU_OK(cfdp_gpu_sync_group(levels[l]->gpus, levels[l]->G));
+      t += cfdp_now();
+      median[k] = t / ncycles;
+    }
+    printf(".");
+    fflush(stdout);
+  }
+  free(lv);
+  qsort(median, N_MEDIAN, sizeof(double), cmp_double);
+  printf("\n\n*** SETUP\n");
+  printf("                                 nProc: %d\n", levels[0]->G);
+  printf("                                levels: %d\n", nlevels);
+  printf("                      sweeps per level: %d\n", sweeps);
+  printf("                      cycles per sample: %d\n", ncycles);
+  printf("                              N_MEDIAN: %d\n", N_MEDIAN);
+  printf("\n*** TIMINGS\n");
+  printf("%38s: %10.6f\n", single ? "v_cycle_hipgraph" : "v_cycle_xgmi_async", median[(N_MEDIAN - 1) / 2]);
+}
+
 #define N_SOLVER 3
 
 static int cmp_double(const void *a, const void *b) {

@@ -185,6 +185,11 @@ cfdp_group *cfdp_group_create(int G, solver_data **sds, comm_data **cds);
 void cfdp_group_link_raw(int G, comm_data **cds);
 void cfdp_group_set_flux_mode(cfdp_group *grp, int mode);
 void cfdp_group_destroy(cfdp_group *grp);
+/* extension: the published "3V multigrid cycle" (documentation/CFD-Proxy.pdf p.3) over the
+ * rank groups of several -lvl levels (finest first), `sweeps` iterations per level down and
+ * up; prints median seconds per cycle in the style of test_solver's TIMINGS block
+ * (src/solver.c:296-311).  Every level must have been through init_threads().              */
+void cfdp_test_vcycle(int nlevels, cfdp_group **levels, int sweeps, int ncycles);
 
 #ifdef __cplusplus
 }

@@ -136,6 +136,14 @@ int  cfdp_gpu_time_fused(cfdp_gpu *g, int iters, int flux_mode, float *ms_fused)
 int  cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode,
                              int use_graph, float *ms_total);
 
+/* multigrid "3V cycle" (documentation/CFD-Proxy.pdf p.3; levels = the -lvl files of
+ * src/hybrid.f6.c:38-47, no transfer operators in the reference): `sweeps` iterations
+ * (gradients + flux) on levels[0] (finest) .. levels[nlevels-1], then back up to levels[0];
+ * one partition per level, all on one device, no exchange.  The whole cycle is ONE hipGraph
+ * (use_graph) replayed `cycles` times; average milliseconds per cycle.                     */
+int  cfdp_gpu_vcycle(cfdp_gpu **levels, int nlevels, int sweeps, int cycles, int flux_mode,
+                     int use_graph, float *ms_per_cycle);
+
 /* sizes for callers that allocate */
 int  cfdp_gpu_counts(const cfdp_gpu *g, int *nown, int *nall, int *nsend, int *nrecv);
 

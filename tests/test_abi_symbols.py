@@ -41,12 +41,14 @@ def test_every_declared_symbol_is_exported(pkg, header, lib):
 def test_expected_entry_points_are_declared():
     hip = declared_functions("cfdproxy_hip.h")
     for n in ("cfdp_gpu_create", "cfdp_gpu_upload_plan", "cfdp_gpu_gradients", "cfdp_gpu_flux", "cfdp_gpu_pack",
-              "cfdp_gpu_unpack", "cfdp_gpu_rank_gradients", "cfdp_gpu_rank_flux", "cfdp_gpu_time_kernels"):
+              "cfdp_gpu_unpack", "cfdp_gpu_rank_gradients", "cfdp_gpu_rank_flux", "cfdp_gpu_time_kernels",
+              "cfdp_gpu_step_pre", "cfdp_gpu_step_post", "cfdp_gpu_set_fusion", "cfdp_gpu_bind_grad_alt",
+              "cfdp_gpu_time_fused", "cfdp_gpu_vcycle"):
         assert n in hip
     drop = declared_functions("cfdproxy_dropin.h")
     for n in ("init_communication", "read_communication_data", "compute_communication_tables",
               "free_communication_ressources", "read_solver_data", "init_solver_data", "init_threads", "test_solver",
-              "compute_psd_flux", "get_nc_int", "get_nc_double", "get_nc_val") + tuple(
+              "compute_psd_flux", "get_nc_int", "get_nc_double", "get_nc_val", "cfdp_test_vcycle") + tuple(
             "compute_gradients_gg_" + v for v in ("comm_free", "mpi_bulk_sync", "mpi_early_recv", "mpi_async",
                                                   "gaspi_bulk_sync", "gaspi_async", "mpifence_bulk_sync",
                                                   "mpifence_async", "mpipscw_bulk_sync", "mpipscw_async")):

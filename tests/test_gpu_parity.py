@@ -465,3 +465,53 @@ def test_fused_iterations_with_halo_exchange_between_in_process_ranks(gpu, orc, 
             assert np.array_equal(g_a, g_b)
             assert np.array_equal(f_a, f_b)
             assert np.abs(g_a).max() > 0
+
+
+# ------------------------------------------------------------------ multigrid V cycle
+@pytest.mark.parametrize("fusion", [False, True])
+def test_vcycle_over_three_levels_matches_single_level_runs(gpu, fusion):
+    """the "3V cycle" loop: every level ends with the gradients / flux of its own
+    mesh, whether the cycle is replayed from one hipGraph or launched from the stream"""
+    pkg = gpu
+    dims = [(16, 12, 8), (8, 6, 4), (4, 3, 2)]
+    doms, parts, want = [], [], []
+    for d in dims:
+        dom = pkg.gen_domain(pkg.gen_params(*d, ndomains=1), 0)
+        pkg.fill_var(dom, None, pkg.VAR_HASH)
+        part = pkg.GpuPartition(dom, tile_points=64)
+        part.run_iterations(1, True, 0, use_graph=False)
+        part.pull_fields()
+        want.append((dom.grad.copy(), dom.psd_flux.copy()))
+        part.set_fusion(fusion)
+        doms.append(dom)
+        parts.append(part)
+    for sweeps, graph in ((3, True), (3, False), (2, True), (1, True)):
+        for dom, part in zip(doms, parts):
+            dom.grad[:] = 9.0
+            dom.psd_flux[:] = -9.0
+            part.push_fields()
+        ms = pkg.vcycle(parts, sweeps=sweeps, cycles=2, use_graph=graph)
+        assert ms > 0
+        for dom, part, (g, f) in zip(doms, parts, want):
+            part.pull_fields()
+            assert np.array_equal(dom.grad[: dom.nown], g[: dom.nown]), (sweeps, graph)
+            assert np.array_equal(dom.psd_flux[: dom.nown], f[: dom.nown]), (sweeps, graph)
+    for part, dom in zip(parts, doms):
+        part.close()
+        dom.free()
+
+
+def test_driver_binary_vcycle(gpu, tmp_path):
+    """bin/hybrid.f6.hip -vcycle 3 PREFIX: three levels of 4 domain files; one rank (hipGraph) and
+    two in-process ranks (peer-copy exchange on every level)"""
+    pkg = gpu
+    prefix = str(tmp_path / "dualgrid")
+    for lvl, d in enumerate([(16, 16, 12), (8, 8, 6), (4, 4, 4)], start=1):
+        pkg.write_mesh(pkg.gen_params(*d, ndomains=4), prefix, lvl)
+    exe = os.path.join(ROOT, "cfd-proxy_amd", "bin", "hybrid.f6.hip")
+    r = subprocess.run([exe, "-vcycle", "3", prefix, "--gpus", "1", "--cycles", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "*** SUCCESS" in r.stdout and "v_cycle_hipgraph:" in r.stdout and "levels: 3" in r.stdout
+    r = subprocess.run([exe, "-vcycle", "3", prefix, "--gpus", "2", "--cycles", "3", "--sweeps", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "*** SUCCESS" in r.stdout and "v_cycle_xgmi_async:" in r.stdout
