@@ -68,7 +68,9 @@ def main() -> None:
     ap.add_argument("--no-finest", action="store_true", help="skip the finest-level single-GPU roofline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--cpu-samples", type=int, default=7)
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "staged"])
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "staged"],
+                    help="rccl: ncclSend/ncclRecv issued by the C library; torch: torch.distributed P2P ops; "
+                         "staged: through the host (tests)")
     args = ap.parse_args()
 
     import numpy as np
@@ -91,7 +93,7 @@ def main() -> None:
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = "nccl" if args.transport == "rccl" else "gloo"
+        backend = "gloo" if args.transport == "staged" else "nccl"
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 device_id=torch.device("cuda", device) if backend == "nccl" else None)
 
@@ -119,13 +121,12 @@ def main() -> None:
         if world == 1:
             solver.gpu.run_iterations(steps, with_flux=True, use_graph=True)  # hipGraph replay of 25-step chunks
         else:
-            for _ in range(steps):
-                solver.step(**kw)
+            solver.run_steps(steps, **kw)
         solver.synchronize()
         barrier()
         dt = time.perf_counter() - t
         if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device=solver.device if args.transport == "rccl" else "cpu")
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.transport == "staged" else solver.device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt
@@ -134,8 +135,7 @@ def main() -> None:
     if world == 1:
         solver.gpu.run_iterations(max(args.warmup, 1), with_flux=True, use_graph=True)
     else:
-        for _ in range(args.warmup):
-            solver.step(with_exchange=True, overlap=True)
+        solver.run_steps(max(args.warmup, 1), with_exchange=True, overlap=True)
     dt = timed(args.steps, with_exchange=True, overlap=True)
     ms_per_step = dt / args.steps * 1e3
     its = args.steps / dt  # iterations/s of the whole mesh
@@ -154,11 +154,25 @@ def main() -> None:
             "mesh_points": dims[0] * dims[1] * dims[2], "points_per_gpu": nown, "faces_per_gpu": nfaces_part,
             "ghost_points_per_gpu": nadd, "iteration": "gradients + halo exchange + pseudo flux",
             "fused_iterations": not args.no_fusion,
+            "transport": solver.transport if world > 1 else "none (one partition)",
             "mesh_iterations_per_s": its, "via_dualgrid_files": not args.no_files,
             "tiles": solver.gpu.stats["ntiles"], "tile_points": solver.gpu.stats["tile_points"],
             "setup_s": round(t_setup, 2),
         },
     }
+
+    # ---- every row that was sent must have arrived: sum over ranks of the ghost rows == sum over
+    # ranks of the packed send rows (same doubles, so equal up to the order of the additions)
+    if world > 1:
+        solver.synchronize()
+        g = solver.grad_host()
+        sidx = [part.sendindex(k) for k in part.partners]  # a point sent to two partners counts twice
+        sent = float(np.abs(g[np.concatenate(sidx)]).sum()) if sidx else 0.0
+        got = float(np.abs(g[part.nown:]).sum())
+        tt = torch.tensor([sent, got], dtype=torch.float64, device="cpu" if args.transport == "staged" else solver.device)
+        dist.all_reduce(tt)
+        out["exchange_check"] = {"sum_abs_sent_rows": float(tt[0]), "sum_abs_ghost_rows": float(tt[1]),
+                                 "ok": bool(abs(float(tt[0]) - float(tt[1])) <= 1e-9 * max(float(tt[0]), 1e-300))}
 
     # ---- overlap efficiency (reference's own normalisation: comm_free / with exchange) ----
     if world > 1:

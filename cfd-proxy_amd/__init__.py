@@ -233,6 +233,12 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_step_post.argtypes = [vp, C.c_int, C.c_int]
     lib.cfdp_gpu_time_kernels.argtypes = [vp, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]
     lib.cfdp_gpu_run_iterations.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]
+    lib.cfdp_rccl_load.argtypes = [C.c_char_p]
+    lib.cfdp_rccl_unique_id.argtypes = [vp]
+    lib.cfdp_gpu_rccl_init.argtypes = [vp, vp, C.c_int, C.c_int, P(C.c_int)]
+    lib.cfdp_gpu_rccl_finalize.argtypes = [vp]
+    lib.cfdp_gpu_step_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.cfdp_gpu_run_steps_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_vcycle.argtypes = [P(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]
     lib.cfdp_gpu_counts.argtypes = [vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
 
@@ -637,6 +643,32 @@ class GpuPartition:
 
     def bind_sendbuf(self, dev_ptr: int) -> None:
         self._ck(self.lib.cfdp_gpu_bind_sendbuf(self.h, C.c_void_p(dev_ptr)))
+
+    # ---- the exchange issued from the C library (RCCL resolved at run time)
+    @staticmethod
+    def rccl_unique_id(libpath: str = "") -> bytes:
+        lib = hip_lib()
+        if lib.cfdp_rccl_load(libpath.encode()):
+            raise GpuError(lib.cfdp_gpu_last_error().decode())
+        buf = C.create_string_buffer(128)
+        if lib.cfdp_rccl_unique_id(buf):
+            raise GpuError(lib.cfdp_gpu_last_error().decode())
+        return buf.raw
+
+    def rccl_init(self, unique_id: bytes, nranks: int, rank: int, rank_of_partner=None, libpath: str = "") -> None:
+        self._ck(self.lib.cfdp_rccl_load(libpath.encode()))
+        rp = None
+        if rank_of_partner is not None:
+            rp = (C.c_int * len(rank_of_partner))(*rank_of_partner)
+        self._ck(self.lib.cfdp_gpu_rccl_init(self.h, C.create_string_buffer(unique_id, 128), nranks, rank, rp))
+
+    def step_rccl(self, with_exchange=True, overlap=True, with_flux=True, flux_mode: int = FLUX_CONSISTENT) -> None:
+        self._ck(self.lib.cfdp_gpu_step_rccl(self.h, int(with_exchange), int(overlap), int(with_flux), flux_mode))
+
+    def run_steps_rccl(self, steps: int, with_exchange=True, overlap=True, with_flux=True,
+                       flux_mode: int = FLUX_CONSISTENT) -> None:
+        self._ck(self.lib.cfdp_gpu_run_steps_rccl(self.h, steps, int(with_exchange), int(overlap), int(with_flux),
+                                                  flux_mode))
 
     def set_fusion(self, on: bool) -> None:
         """defer each iteration's flux into the pass that computes the next gradients"""

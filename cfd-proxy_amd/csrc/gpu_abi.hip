@@ -9,6 +9,9 @@
 #include <cstring>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is resolved at run time (cfdp_rccl_load)
+
 #include "cfdproxy_hip.h"
 #include "gg_kernels.h"
 
@@ -54,6 +57,9 @@ struct cfdp_gpu {
   double *d_grad_alt = nullptr;
   bool own_grad_alt = true;
   int fusion = 0, flux_pending = -1;
+  // one process per GPU: this rank's RCCL communicator and the communicator rank of every partner
+  ncclComm_t comm = nullptr;
+  std::vector<int> peer;
   long iter = 0;               // phase-1 calls so far (in-process rank groups run in lockstep)
   std::vector<int> new2old, partner, send_off, recv_off;
   std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
@@ -155,6 +161,7 @@ void cfdp_gpu_destroy(cfdp_gpu *g) {
   if (!g) return;
   (void)hipSetDevice(g->device);
   (void)hipDeviceSynchronize();
+  (void)cfdp_gpu_rccl_finalize(g);
   free_device(g);
   if (!g->streams_exported) {  // exported streams may still be referenced by the caller's runtime
     if (g->s_main) (void)hipStreamDestroy(g->s_main);
@@ -772,6 +779,136 @@ int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, g->ev_a, g->ev_b));
   if (ms_total) *ms_total = ms;
+  return 0;
+}
+
+// ------------------------------------------------------- one process per GPU: RCCL from C
+// The halo exchange of a step issued straight from this library: one ncclGroup of
+// ncclSend/ncclRecv per iteration on the context's comm stream, between the two step brackets
+// -- the analogue of exchange_dbl_mpi_send / _post_recv (src/exchange_data_mpi.c:96-166) with
+// the receive side being the ghost block itself.  A host pays ONE call per iteration (or one
+// per hipGraph replay of several).  RCCL is resolved at run time from the library the process
+// already uses (PyTorch ships its own librccl.so; a C host names the system one), so this
+// library has no link-time dependency on it.
+namespace {
+struct rccl_api {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+} rccl;
+
+#define RCCL_TRY(expr)                                                                              \
+  do {                                                                                              \
+    ncclResult_t r_ = (expr);                                                                       \
+    if (r_ != ncclSuccess)                                                                          \
+      return fail("%s failed: %s [%s:%d]", #expr, rccl.GetErrorString ? rccl.GetErrorString(r_) : "?", \
+                  __FILE__, __LINE__);                                                              \
+  } while (0)
+
+// this iteration's messages: sends from the packed arena, receives into the current ghost block
+int enqueue_exchange(cfdp_gpu *g) {
+  RCCL_TRY(rccl.GroupStart());
+  for (size_t s = 0; s < g->partner.size(); s++) {
+    size_t sb = 0, rb = 0;
+    void *sp = cfdp_gpu_send_ptr(g, (int)s, &sb), *rp = cfdp_gpu_recv_ptr(g, (int)s, &rb);
+    if (sb) RCCL_TRY(rccl.Send(sp, sb / sizeof(double), ncclDouble, g->peer[s], g->comm, g->s_comm));
+    if (rb) RCCL_TRY(rccl.Recv(rp, rb / sizeof(double), ncclDouble, g->peer[s], g->comm, g->s_comm));
+  }
+  RCCL_TRY(rccl.GroupEnd());
+  return 0;
+}
+
+int one_step(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {
+  if (cfdp_gpu_step_pre(g, with_exchange, overlap)) return 1;
+  if (g->pending_exchange && enqueue_exchange(g)) return 1;
+  return cfdp_gpu_step_post(g, with_flux, flux_mode);
+}
+}  // namespace
+
+int cfdp_rccl_load(const char *libpath) {
+  if (rccl.lib) return 0;
+  const char *names[] = {libpath, "librccl.so.1", "librccl.so"};
+  for (const char *n : names) {
+    if (!n || !*n) continue;
+    rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (rccl.lib) break;
+  }
+  if (!rccl.lib) return fail("cannot load RCCL (%s): %s", libpath ? libpath : "librccl.so.1", dlerror());
+#define RCCL_SYM(field, name)                                                      \
+  do {                                                                             \
+    *(void **)(&rccl.field) = dlsym(rccl.lib, name);                               \
+    if (!rccl.field) { rccl.lib = nullptr; return fail("RCCL symbol %s not found", name); } \
+  } while (0)
+  RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+  RCCL_SYM(CommInitRank, "ncclCommInitRank");
+  RCCL_SYM(CommDestroy, "ncclCommDestroy");
+  RCCL_SYM(GroupStart, "ncclGroupStart");
+  RCCL_SYM(GroupEnd, "ncclGroupEnd");
+  RCCL_SYM(Send, "ncclSend");
+  RCCL_SYM(Recv, "ncclRecv");
+  RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+  return 0;
+}
+
+int cfdp_rccl_unique_id(void *id128) {
+  if (!rccl.lib) return fail("cfdp_rccl_load() has not been called");
+  if (!id128) return fail("null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  RCCL_TRY(rccl.GetUniqueId(static_cast<ncclUniqueId *>(id128)));
+  return 0;
+}
+
+int cfdp_gpu_rccl_init(cfdp_gpu *g, const void *id128, int nranks, int rank, const int *rank_of_partner) {
+  NEED_UPLOAD(g);
+  if (!rccl.lib) return fail("cfdp_rccl_load() has not been called");
+  if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail("bad communicator arguments");
+  if (g->comm) return fail("this context already has a communicator");
+  g->peer.resize(g->partner.size());
+  for (size_t s = 0; s < g->partner.size(); s++) {
+    g->peer[s] = rank_of_partner ? rank_of_partner[s] : g->partner[s];
+    if (g->peer[s] < 0 || g->peer[s] >= nranks)
+      return fail("partner %d maps to communicator rank %d outside [0,%d)", g->partner[s], g->peer[s], nranks);
+  }
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  RCCL_TRY(rccl.CommInitRank(&g->comm, nranks, id, rank));
+  return 0;
+}
+
+int cfdp_gpu_rccl_finalize(cfdp_gpu *g) {
+  if (!g) return fail("null context");
+  if (g->comm) {
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipDeviceSynchronize());
+    RCCL_TRY(rccl.CommDestroy(g->comm));
+    g->comm = nullptr;
+  }
+  return 0;
+}
+
+int cfdp_gpu_step_rccl(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {
+  NEED_UPLOAD(g);
+  if (with_exchange && !g->partner.empty() && !g->comm) return fail("no communicator: call cfdp_gpu_rccl_init()");
+  return one_step(g, with_exchange, overlap, with_flux, flux_mode);
+}
+
+// `steps` iterations enqueued by one call.  (Capturing the step -- RCCL group included -- in a
+// hipGraph was tried: with RCCL 2.26.6 / ROCm 7.0 hipStreamEndCapture crashes once ncclSend/
+// ncclRecv have been captured, so the steps are stream launches: ~54 us of host time each.)
+int cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
+                            int flux_mode) {
+  NEED_UPLOAD(g);
+  if (steps < 1) return fail("steps must be >= 1");
+  if (with_exchange && !g->partner.empty() && !g->comm) return fail("no communicator: call cfdp_gpu_rccl_init()");
+  for (int i = 0; i < steps; i++)
+    if (one_step(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
   return 0;
 }
 

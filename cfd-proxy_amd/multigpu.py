@@ -5,10 +5,15 @@ MPI/GASPI point-to-point messages (reference src/exchange_data_mpi.c:96-166,199-
 src/exchange_data_gaspi.c:105-151).  Here each GPU rank owns N/G whole domains
 (host/domain_merge.c) and exchanges 168-byte gradient rows with its neighbour ranks:
 
-  * transport "rccl": grouped ncclSend/ncclRecv (torch.distributed batch_isend_irecv on the
-    "nccl" backend = RCCL over xGMI).  The send side is the packed send arena, the receive
-    side is the ghost-row block of `grad` itself (ghost rows are numbered in message order),
-    so there is no unpack pass and no staging copy.
+  * transport "rccl" (default): grouped ncclSend/ncclRecv over xGMI issued by the C library itself
+    (cfdp_gpu_step_rccl / cfdp_gpu_run_steps_rccl: one host call per iteration or per batch of
+    iterations), on a communicator it creates from a ncclUniqueId broadcast over the process
+    group; RCCL is the library PyTorch already loaded.  The send side is the packed send arena,
+    the receive side is the ghost block of `grad` itself (ghost rows are numbered in message
+    order), so there is no unpack pass and no staging copy.
+  * transport "torch": the same messages as torch.distributed batch_isend_irecv ("nccl" backend)
+    on the context's comm stream -- the fallback when the library cannot set up its own
+    communicator (several Python-level calls per iteration).
   * transport "staged": device -> host -> gloo -> host -> device.  Only for tests on
     machines without one GPU per rank (several ranks may share cuda:0).
 
@@ -137,9 +142,50 @@ class RankSolver:
             self.send_views.append(self.send_t[so:so + sb // 8])
             # whole rows inside the ghost block, one view per grad buffer
             self.recv_views.append([b[ro:ro + rb // 8] for b in self.grad_bufs])
+        if transport == "rccl" and world > 1:
+            try:
+                self._init_own_communicator()
+            except Exception as e:  # keep going on the torch.distributed transport
+                import sys
+                print(f"[rank {rank}] own RCCL communicator failed ({e}); using torch.distributed P2P", file=sys.stderr)
+                self.transport = transport = "torch"
         if transport == "staged":
             self.h_send = [torch.empty(v.numel(), dtype=torch.float64).pin_memory() for v in self.send_views]
             self.h_recv = [torch.empty(v[0].numel(), dtype=torch.float64).pin_memory() for v in self.recv_views]
+
+    @staticmethod
+    def torch_rccl_path() -> str:
+        import torch
+        p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        return p if os.path.exists(p) else ""
+
+    def _init_own_communicator(self) -> None:
+        """collective over the process group; raises on every rank alike when a step fails"""
+        torch, dist = self.torch, self.dist
+        lib = self.torch_rccl_path()
+
+        def all_ok(ok: bool) -> bool:
+            t = torch.tensor([1 if ok else 0], device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+
+        ok = True
+        try:
+            self.gpu._ck(self.gpu.lib.cfdp_rccl_load(lib.encode()))
+        except Exception:
+            ok = False
+        if not all_ok(ok):
+            raise RuntimeError("RCCL could not be resolved on every rank")
+        box = [None]
+        if self.rank == 0:
+            try:
+                box[0] = GpuPartition.rccl_unique_id(lib)
+            except Exception:
+                box[0] = None
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            raise RuntimeError("ncclGetUniqueId failed on rank 0")
+        self.gpu.rccl_init(box[0], self.world, self.rank, None, lib)
 
     # ------------------------------------------------------------------------------ pieces
     def _exchange(self) -> None:
@@ -150,7 +196,7 @@ class RankSolver:
         if len(self.grad_bufs) > 1 and self.gpu.grad_ptr() == self.grad_bufs[1].data_ptr():
             cur = 1  # the buffer this iteration's gradients went to
         with torch.cuda.stream(self.s_comm):
-            if self.transport == "rccl":
+            if self.transport == "torch":
                 ops = []
                 for s, peer in enumerate(self.partners):
                     if self.send_views[s].numel():
@@ -179,10 +225,23 @@ class RankSolver:
         """one iteration = what test_solver times (reference src/solver.c:48-54): two ABI calls
         around one communication call"""
         comm = with_exchange and self.world > 1 and bool(self.partners)
+        if self.transport == "rccl":
+            self.gpu.step_rccl(comm, overlap, with_flux, flux_mode)  # one call: brackets + ncclGroup
+            return
         self.gpu.step_pre(comm, overlap)
         if comm:
             self._exchange()
         self.gpu.step_post(with_flux, flux_mode)
+
+    def run_steps(self, steps: int, with_exchange: bool = True, overlap: bool = True, with_flux: bool = True,
+                  flux_mode: int = FLUX_CONSISTENT) -> None:
+        """`steps` iterations (one library call with the library's own communicator)"""
+        comm = with_exchange and self.world > 1 and bool(self.partners)
+        if self.transport == "rccl":
+            self.gpu.run_steps_rccl(steps, comm, overlap, with_flux, flux_mode)
+            return
+        for _ in range(steps):
+            self.step(with_exchange, overlap, with_flux, flux_mode)
 
     def synchronize(self) -> None:
         self.gpu.sync()  # also runs a flux deferred by the fused mode

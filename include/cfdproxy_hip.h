@@ -127,6 +127,24 @@ int  cfdp_gpu_sync_group(cfdp_gpu **ranks, int G);
 int  cfdp_gpu_step_pre(cfdp_gpu *g, int with_exchange, int overlap);
 int  cfdp_gpu_step_post(cfdp_gpu *g, int with_flux, int flux_mode);
 
+/* one rank per process with the exchange issued from this library: grouped ncclSend/ncclRecv
+ * (RCCL over xGMI) on the context's comm stream between the two brackets -- one call per
+ * iteration (cfdp_gpu_step_rccl) or per batch of iterations (cfdp_gpu_run_steps_rccl).
+ * Replaces exchange_dbl_mpi_send/_post_recv and the MPI_Waitany loop
+ * (src/exchange_data_mpi.c:96-166,199-543).
+ *   cfdp_rccl_load       resolve RCCL at run time: `libpath` = the librccl.so the process
+ *                        already uses (PyTorch ships one), NULL/"" = the system library
+ *   cfdp_rccl_unique_id  128-byte ncclUniqueId (rank 0; the caller broadcasts it)
+ *   cfdp_gpu_rccl_init   ncclCommInitRank; rank_of_partner[s] = communicator rank of partner
+ *                        slot s (NULL: the partition's partner ranks are communicator ranks) */
+int  cfdp_rccl_load(const char *libpath);
+int  cfdp_rccl_unique_id(void *id128);
+int  cfdp_gpu_rccl_init(cfdp_gpu *g, const void *id128, int nranks, int rank, const int *rank_of_partner);
+int  cfdp_gpu_rccl_finalize(cfdp_gpu *g);
+int  cfdp_gpu_step_rccl(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode);
+int  cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
+                             int flux_mode);
+
 /* measurement: `iters` back-to-back launches bracketed by HIP events on the context's
  * main stream; average milliseconds per launch (gradient over all tiles; flux)           */
 int  cfdp_gpu_time_kernels(cfdp_gpu *g, int iters, int flux_mode, float *ms_grad, float *ms_flux);

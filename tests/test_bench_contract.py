@@ -51,4 +51,6 @@ def test_bench_two_ranks_staged_transport(gpu):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["points_per_gpu"] == 262144
     assert out["config"]["ghost_points_per_gpu"] > 0 and "overlap" in out
     assert 0 < out["overlap"]["efficiency_async"] <= 1.5
+    assert out["exchange_check"]["ok"], out["exchange_check"]
+    assert out["config"]["transport"] == "staged" and out["config"]["fused_iterations"]
     assert "cpu_baseline" not in out

@@ -515,3 +515,41 @@ def test_driver_binary_vcycle(gpu, tmp_path):
     r = subprocess.run([exe, "-vcycle", "3", prefix, "--gpus", "2", "--cycles", "3", "--sweeps", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "*** SUCCESS" in r.stdout and "v_cycle_xgmi_async:" in r.stdout
+
+
+# ------------------------------------------------------------------ RCCL issued from the C library
+@pytest.mark.parametrize("fusion", [False, True])
+def test_rccl_exchange_from_c_library_self_sendrecv(gpu, fusion):
+    """plumbing of cfdp_gpu_step_rccl / cfdp_gpu_run_steps_rccl on ONE GPU: rank 0 of a 2-rank
+    decomposition exchanges with ITSELF (communicator of one rank, partner mapped to rank 0; the
+    cut is symmetric, so its send and receive counts match): its ghost rows must become its own
+    packed send rows -- through the run-time resolved RCCL, the comm stream and both grad buffers
+    of the fused mode"""
+    import torch
+    pkg = gpu
+    from cfd_proxy_amd import multigpu as mg
+    gp = pkg.gen_params(12, 10, 8, ndomains=2)
+    parts = [mg.build_rank_partition(gp, 2, 2, r, via_files=False)[0] for r in range(2)]
+    reqs = [{int(k): (v[0], v[1]) for k, v in pkg.merge_requests(p).items()} for p in parts]
+    for r, p in enumerate(parts):
+        mg.exchange_requests(p, r, 2, None, all_requests=reqs)
+    part = parts[0]
+    assert part.partners == [1] and len(part.sendindex(1)) == len(part.recvindex(1)) > 0
+    g = pkg.GpuPartition(part, tile_points=32)
+    g.set_fusion(fusion)
+    lib = mg.RankSolver.torch_rccl_path()
+    g.rccl_init(pkg.GpuPartition.rccl_unique_id(lib), 1, 0, rank_of_partner=[0], libpath=lib)
+    for steps, overlap in ((1, True), (3, False), (14, True), (25, True)):
+        part.grad[:] = -1.0
+        g.push_fields()
+        if steps <= 3:
+            for _ in range(steps):
+                g.step_rccl(True, overlap, True)
+        else:
+            g.run_steps_rccl(steps, True, overlap, True)
+        g.pull_fields()
+        sent = part.grad[part.sendindex(1)]
+        got = part.grad[part.recvindex(1)]
+        assert np.abs(sent).max() > 0 and not np.any(sent == -1.0)
+        assert np.array_equal(got, sent), (steps, overlap)
+    g.close()
