@@ -26,6 +26,7 @@
 #include "cfdproxy_host.h"
 #include "host_util.h"
 
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -111,19 +112,30 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
   }
 }
 
-typedef struct { unsigned char *p; size_t len, cap; } bytebuf;
-static void *bb_reserve(bytebuf *b, size_t n) {
-  if (b->len + n > b->cap) {
-    size_t nc = b->cap ? b->cap : (1u << 20);
-    while (nc < b->len + n) nc *= 2;
-    b->p = realloc(b->p, nc);
-    CFDP_ASSERT(b->p != NULL);
-    b->cap = nc;
+/* small open-addressing map key -> first-touch index, cleared in O(1) by a generation count */
+typedef struct { int *key, *val; unsigned *gen; unsigned cur; int mask; } lmap;
+static void lmap_init(lmap *m, int max_keys) {
+  int cap = 64;
+  while (cap < 4 * max_keys) cap *= 2;
+  m->key = cfdp_malloc((size_t)cap * sizeof(int));
+  m->val = cfdp_malloc((size_t)cap * sizeof(int));
+  m->gen = cfdp_calloc((size_t)cap, sizeof(unsigned));
+  m->cur = 0;
+  m->mask = cap - 1;
+}
+static void lmap_free(lmap *m) { free(m->key); free(m->val); free(m->gen); }
+static inline void lmap_reset(lmap *m) {
+  if (++m->cur == 0) { memset(m->gen, 0, (size_t)(m->mask + 1) * sizeof(unsigned)); m->cur = 1; }
+}
+/* index of k; a new key gets (*next)++ */
+static inline int lmap_index(lmap *m, int k, int *next) {
+  unsigned h = ((unsigned)k * 2654435761u) >> 7;
+  for (;;) {
+    h &= (unsigned)m->mask;
+    if (m->gen[h] != m->cur) { m->gen[h] = m->cur; m->key[h] = k; m->val[h] = (*next)++; return m->val[h]; }
+    if (m->key[h] == k) return m->val[h];
+    h++;
   }
-  void *r = b->p + b->len;
-  memset(r, 0, n);
-  b->len += n;
-  return r;
 }
 
 cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *opts) {
@@ -134,17 +146,31 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
   CFDP_ASSERT(nown > 0 && nall >= nown);
   const int has_comm = cd && cd->ndomains > 1 && cd->ncommdomains > 0;
 
+  const int trace = getenv("CFDP_PLAN_TRACE") != NULL;
+  double t_prev = cfdp_now();
+#define PLAN_STAGE(name)                                                              \
+  do {                                                                                \
+    if (trace) { double t_ = cfdp_now(); fprintf(stderr, "[plan] %-28s %.3f s\n", name, t_ - t_prev); t_prev = t_; } \
+  } while (0)
   cfdp_plan *P = cfdp_calloc(1, sizeof(*P));
   P->nown = nown; P->nall = nall; P->tile_points = o.tile_points;
 
-  /* ---- 1. point -> incident faces (CSR over owned points, file face order) ---- */
+  /* ---- 1. point -> incident faces (CSR over owned points, file face order) ----
+   * Every thread streams the whole face list but only keeps the ends that fall into its own
+   * range of points: the scattered writes stay inside a cache-sized slice, and a point's list
+   * is in file order whatever the thread count (the order the kernels add a point's faces in). */
   int *xadj = cfdp_calloc((size_t)nown + 2, sizeof(int));
   long used = 0;
-  for (int f = 0; f < nf; f++) {
-    int a = sd->fpoint[f][0], b = sd->fpoint[f][1];
-    if (a < nown) xadj[a + 1]++;
-    if (b < nown) xadj[b + 1]++;
-    if (a < nown || b < nown) used++;
+#pragma omp parallel reduction(+ : used)
+  {
+    const int nth = omp_get_num_threads(), th = omp_get_thread_num();
+    const int lo = (int)((long)nown * th / nth), hi = (int)((long)nown * (th + 1) / nth);
+    for (int f = 0; f < nf; f++) {
+      int a = sd->fpoint[f][0], b = sd->fpoint[f][1];
+      if (a >= lo && a < hi) xadj[a + 1]++;
+      if (b >= lo && b < hi) xadj[b + 1]++;
+      if (th == 0 && (a < nown || b < nown)) used++;
+    }
   }
   P->nfaces_used = used;
   for (int p = 0; p < nown; p++) xadj[p + 1] += xadj[p];
@@ -153,13 +179,19 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
   int *adj_other = cfdp_malloc((size_t)(nadj ? nadj : 1) * sizeof(int));
   int *fill = cfdp_malloc((size_t)nown * sizeof(int));
   memcpy(fill, xadj, (size_t)nown * sizeof(int));
-  for (int f = 0; f < nf; f++) {
-    int a = sd->fpoint[f][0], b = sd->fpoint[f][1];
-    if (a < nown) { adj_face[fill[a]] = f; adj_other[fill[a]++] = b; }
-    if (b < nown) { adj_face[fill[b]] = (int)((unsigned)f | 0x80000000u); adj_other[fill[b]++] = a; }
+#pragma omp parallel
+  {
+    const int nth = omp_get_num_threads(), th = omp_get_thread_num();
+    const int lo = (int)((long)nown * th / nth), hi = (int)((long)nown * (th + 1) / nth);
+    for (int f = 0; f < nf; f++) {
+      int a = sd->fpoint[f][0], b = sd->fpoint[f][1];
+      if (a >= lo && a < hi) { adj_face[fill[a]] = f; adj_other[fill[a]++] = b; }
+      if (b >= lo && b < hi) { adj_face[fill[b]] = (int)((unsigned)f | 0x80000000u); adj_other[fill[b]++] = a; }
+    }
   }
   free(fill);
 
+  PLAN_STAGE("point->face CSR");
   /* ---- 2. which owned points are sent (reference htype 2, src/rangelist.c:129-141) ---- */
   unsigned char *is_send = cfdp_calloc((size_t)nown, 1);
   int any_send = 0;
@@ -208,6 +240,7 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
   T.tile_first[T.ntiles] = nown;
   P->ntiles = T.ntiles;
 
+  PLAN_STAGE("grow tiles");
   /* ---- 3b. order the tiles for L2 reuse.  Growth order sweeps the mesh in layers, so a
    * tile's neighbours (whose var rows it gathers as halo rows) can be a whole layer --
    * hundreds of tiles, several MB of stream -- apart.  Cluster the TILE graph the same way
@@ -285,6 +318,7 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
     free(txadj); free(tstamp);
   }
 
+  PLAN_STAGE("supertile order");
   /* ---- 4. renumber: owned points tile-major; ghosts grouped by partner, message order ---- */
   P->new2old = cfdp_malloc((size_t)nall * sizeof(int));
   P->old2new = cfdp_malloc((size_t)nall * sizeof(int));
@@ -335,91 +369,147 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
     P->degree[i] = xadj[old + 1] - xadj[old];
   }
 
-  /* ---- 5. per-tile face copies, halo lists, incidence lists ---- */
+  PLAN_STAGE("renumber");
+  /* ---- 5. per-tile face copies, halo lists, incidence lists ----
+   * Tiles are independent: pass A sizes every tile, a prefix sum places its blob and its halo
+   * list, pass B fills them -- both passes in parallel over tiles.  The tile-local numbering
+   * of faces and halo points (first touch, walking the tile's points and their faces in file
+   * order) lives in small per-thread hash maps instead of mesh-sized stamp arrays.           */
   P->tiles = cfdp_calloc((size_t)P->ntiles, sizeof(cfdp_tile_desc));
-  int *fstamp = cfdp_calloc((size_t)(nf ? nf : 1), sizeof(int));
-  int *fval = cfdp_malloc((size_t)(nf ? nf : 1) * sizeof(int));
-  int *hstamp = cfdp_calloc((size_t)nall, sizeof(int));
-  int *hval = cfdp_malloc((size_t)nall * sizeof(int));
-  bytebuf blob = {0, 0, 0}, halo = {0, 0, 0};
-  long lds_g[2] = {0, 0}, lds_f[2] = {0, 0};
+  int max_inc = 1;
   for (int t = 0; t < P->ntiles; t++) {
-    const int ts = T.tile_first[t], te = T.tile_first[t + 1], np = te - ts;
-    cfdp_tile_desc *td = &P->tiles[t];
-    td->pstart = ts;
-    td->npts = np;
-    /* count */
-    int E = 0, H = 0, I = 0;
-    for (int li = 0; li < np; li++) {
-      int p = T.order[ts + li];
-      for (int e = xadj[p]; e < xadj[p + 1]; e++) {
-        int q = adj_other[e];
-        int f = adj_face[e] & 0x7FFFFFFF, sgn = (unsigned)adj_face[e] >> 31;
-        int in_tile = q < nown && T.tile_of[q] == t;
-        I++;
-        if (!in_tile || sgn == 0) {
-          if (fstamp[f] != t + 1) { fstamp[f] = t + 1; fval[f] = E++; }
-        }
-        if (!in_tile && hstamp[q] != t + 1) { hstamp[q] = t + 1; hval[q] = H++; }
-      }
-    }
-    CFDP_ASSERT(np + H <= 65535);
-    CFDP_ASSERT(E <= 32767);
-    td->nhalo = H; td->nfaces = E; td->ninc = I;
-    const long b_fn = cfdp_blob_fn_bytes(E), b_inc = cfdp_blob_inc_bytes(I),
-               b_off = cfdp_blob_off_bytes(np);
-    CFDP_ASSERT(blob.len % 16 == 0 && blob.len / 16 < 0x7FFFFFFF);
-    td->blob_off = (int)(blob.len / 16);
-    td->blob_qw = (int)((b_fn + b_inc + b_off) / 16);
-    td->halo_off = (int)(halo.len / 4);
-    unsigned char *bp = bb_reserve(&blob, (size_t)(b_fn + b_inc + b_off));
-    int *hp = bb_reserve(&halo, (size_t)H * 4);
-    double *fn = (double *)bp;
-    const long plane = cfdp_blob_plane_bytes(E) / 8; /* doubles per normal-component plane */
-    uint32_t *inc = (uint32_t *)(bp + b_fn);
-    uint32_t *ioff = (uint32_t *)(bp + b_fn + b_inc);
-    /* fill: faces were numbered in first-touch order above; re-walk identically */
-    int Ic = 0;
-    for (int li = 0; li < np; li++) {
-      int p = T.order[ts + li];
-      ioff[li] = (uint32_t)Ic;
-      for (int e = xadj[p]; e < xadj[p + 1]; e++) {
-        int q = adj_other[e];
-        int f = adj_face[e] & 0x7FFFFFFF;
-        unsigned sgn = (unsigned)adj_face[e] >> 31;
-        int in_tile = q < nown && T.tile_of[q] == t;
-        int lf = fval[f];
-        /* an internal face is listed by both ends; the normal is stored once */
-        fn[lf] = sd->fnormal[f][0];
-        fn[plane + lf] = sd->fnormal[f][1];
-        fn[2 * plane + lf] = sd->fnormal[f][2];
-        unsigned nbr;
-        if (in_tile) nbr = (unsigned)(P->old2new[q] - ts);
-        else { nbr = (unsigned)(np + hval[q]); hp[hval[q]] = P->old2new[q]; }
-        inc[Ic++] = nbr | ((unsigned)lf << 16) | (sgn << 31);
-      }
-    }
-    ioff[np] = (uint32_t)Ic;
-    CFDP_ASSERT(Ic == I);
-    P->nfaces_dup += E;
-    P->ninc_total += I;
-    const int cls = t < P->nbtiles ? 0 : 1;
-    long lg = (long)td->blob_qw * 16 + (long)(np + H) * 64;
-    long lf = (long)td->blob_qw * 16 + (long)(np + H) * 80;
-    if (lg > lds_g[cls]) lds_g[cls] = lg;
-    if (lf > lds_f[cls]) lds_f[cls] = lf;
+    int n = 0;
+    for (int i = T.tile_first[t]; i < T.tile_first[t + 1]; i++) n += xadj[T.order[i] + 1] - xadj[T.order[i]];
+    if (n > max_inc) max_inc = n;
   }
-  /* (an internal face is numbered at its p0 end's visit in the count loop, which has
-   * finished for the whole tile before the fill loop reads fval[])                       */
+  long lds_g[2] = {0, 0}, lds_f[2] = {0, 0};
+  long *boff = cfdp_calloc((size_t)P->ntiles + 1, sizeof(long)); /* blob offsets, bytes */
+  long *hoff = cfdp_calloc((size_t)P->ntiles + 1, sizeof(long)); /* halo offsets, entries */
+  long dup_total = 0, inc_total = 0;
+  int bad = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) {
+      for (int t = 0; t < P->ntiles; t++) {
+        boff[t + 1] += boff[t];
+        hoff[t + 1] += hoff[t];
+      }
+      P->blob_bytes = boff[P->ntiles];
+      P->nhalo_total = hoff[P->ntiles];
+      CFDP_ASSERT(P->blob_bytes % 16 == 0 && P->blob_bytes / 16 < 0x7FFFFFFF);
+      P->blob = cfdp_malloc((size_t)(P->blob_bytes ? P->blob_bytes : 16));
+      P->halo_idx = cfdp_malloc((size_t)(P->nhalo_total ? P->nhalo_total : 1) * sizeof(int));
+    }
+#pragma omp parallel reduction(+ : dup_total, inc_total) reduction(| : bad)
+    {
+      lmap fmap, hmap;
+      lmap_init(&fmap, max_inc);
+      lmap_init(&hmap, max_inc);
+      long tg[2] = {0, 0}, tf[2] = {0, 0};
+#pragma omp for schedule(dynamic, 64)
+      for (int t = 0; t < P->ntiles; t++) {
+        const int ts = T.tile_first[t], te = T.tile_first[t + 1], np = te - ts;
+        cfdp_tile_desc *td = &P->tiles[t];
+        lmap_reset(&fmap);
+        lmap_reset(&hmap);
+        int E = 0, H = 0, I = 0;
+        if (pass == 0) {
+          for (int li = 0; li < np; li++) {
+            int p = T.order[ts + li];
+            for (int e = xadj[p]; e < xadj[p + 1]; e++) {
+              int q = adj_other[e];
+              int f = adj_face[e] & 0x7FFFFFFF, sgn = (unsigned)adj_face[e] >> 31;
+              int in_tile = q < nown && T.tile_of[q] == t;
+              I++;
+              /* an internal face is listed by both ends and numbered at its p0 end */
+              if (!in_tile || sgn == 0) lmap_index(&fmap, f, &E);
+              if (!in_tile) lmap_index(&hmap, q, &H);
+            }
+          }
+          if (np + H > 65535 || E > 32767) bad = 1;
+          td->pstart = ts; td->npts = np;
+          td->nhalo = H; td->nfaces = E; td->ninc = I;
+          const long b_fn = cfdp_blob_fn_bytes(E), b_inc = cfdp_blob_inc_bytes(I), b_off = cfdp_blob_off_bytes(np);
+          td->blob_qw = (int)((b_fn + b_inc + b_off) / 16);
+          boff[t + 1] = b_fn + b_inc + b_off;
+          hoff[t + 1] = H;
+          dup_total += E;
+          inc_total += I;
+          const int cls = t < P->nbtiles ? 0 : 1;
+          long lg = (long)td->blob_qw * 16 + (long)(np + H) * 64;
+          long lf = (long)td->blob_qw * 16 + (long)(np + H) * 80;
+          if (lg > tg[cls]) tg[cls] = lg;
+          if (lf > tf[cls]) tf[cls] = lf;
+        } else {
+          td->blob_off = (int)(boff[t] / 16);
+          td->halo_off = (int)hoff[t];
+          E = td->nfaces;
+          const long b_fn = cfdp_blob_fn_bytes(E), b_inc = cfdp_blob_inc_bytes(td->ninc);
+          unsigned char *bp = P->blob + boff[t];
+          memset(bp, 0, (size_t)(boff[t + 1] - boff[t])); /* alignment padding is defined */
+          int *hp = P->halo_idx + hoff[t];
+          double *fn = (double *)bp;
+          const long plane = cfdp_blob_plane_bytes(E) / 8; /* doubles per normal-component plane */
+          uint32_t *inc = (uint32_t *)(bp + b_fn);
+          uint32_t *ioff = (uint32_t *)(bp + b_fn + b_inc);
+          /* numbering pass first (an internal face may be met at its p1 end before its p0 end) */
+          int En = 0, Hn = 0;
+          for (int li = 0; li < np; li++) {
+            int p = T.order[ts + li];
+            for (int e = xadj[p]; e < xadj[p + 1]; e++) {
+              int q = adj_other[e];
+              int f = adj_face[e] & 0x7FFFFFFF, sgn = (unsigned)adj_face[e] >> 31;
+              int in_tile = q < nown && T.tile_of[q] == t;
+              if (!in_tile || sgn == 0) lmap_index(&fmap, f, &En);
+              if (!in_tile) lmap_index(&hmap, q, &Hn);
+            }
+          }
+          int Ic = 0;
+          for (int li = 0; li < np; li++) {
+            int p = T.order[ts + li];
+            ioff[li] = (uint32_t)Ic;
+            for (int e = xadj[p]; e < xadj[p + 1]; e++) {
+              int q = adj_other[e];
+              int f = adj_face[e] & 0x7FFFFFFF;
+              unsigned sgn = (unsigned)adj_face[e] >> 31;
+              int in_tile = q < nown && T.tile_of[q] == t;
+              int dummy = 0;
+              int lf = lmap_index(&fmap, f, &dummy);
+              /* an internal face is listed by both ends; the normal is stored once */
+              fn[lf] = sd->fnormal[f][0];
+              fn[plane + lf] = sd->fnormal[f][1];
+              fn[2 * plane + lf] = sd->fnormal[f][2];
+              unsigned nbr;
+              if (in_tile) nbr = (unsigned)(P->old2new[q] - ts);
+              else {
+                int hv = lmap_index(&hmap, q, &dummy);
+                nbr = (unsigned)(np + hv);
+                hp[hv] = P->old2new[q];
+              }
+              inc[Ic++] = nbr | ((unsigned)lf << 16) | (sgn << 31);
+            }
+          }
+          ioff[np] = (uint32_t)Ic;
+          if (Ic != td->ninc || En != E || Hn != td->nhalo) bad = 1;
+        }
+      }
+#pragma omp critical
+      for (int c = 0; c < 2; c++) {
+        if (tg[c] > lds_g[c]) lds_g[c] = tg[c];
+        if (tf[c] > lds_f[c]) lds_f[c] = tf[c];
+      }
+      lmap_free(&fmap);
+      lmap_free(&hmap);
+    }
+    CFDP_ASSERT(!bad); /* tile too large for 16-bit neighbour / 15-bit face slots, or an internal error */
+  }
+  P->nfaces_dup = dup_total;
+  P->ninc_total = inc_total;
+  free(boff); free(hoff);
   for (int c = 0; c < 2; c++) { P->lds_grad_cls[c] = lds_g[c]; P->lds_flux_cls[c] = lds_f[c]; }
   P->lds_grad = lds_g[0] > lds_g[1] ? lds_g[0] : lds_g[1];
   P->lds_flux = lds_f[0] > lds_f[1] ? lds_f[0] : lds_f[1];
-  P->blob = blob.p; P->blob_bytes = (long)blob.len;
-  P->halo_idx = (int *)halo.p; P->nhalo_total = (long)(halo.len / 4);
-  if (!P->blob) P->blob = cfdp_calloc(16, 1);
-  if (!P->halo_idx) P->halo_idx = cfdp_calloc(4, 1);
-
-  free(fstamp); free(fval); free(hstamp); free(hval);
+  PLAN_STAGE("tile blobs");
+#undef PLAN_STAGE
   free(T.tile_of); free(T.stamp); free(T.seeded); free(T.seedq); free(T.lq);
   free(T.order); free(T.tile_first);
   free(xadj); free(adj_face); free(adj_other); free(is_send);
