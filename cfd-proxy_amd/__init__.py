@@ -150,6 +150,12 @@ def _declare_host(lib: C.CDLL) -> None:
     lib.cfdp_domain_rank.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.cfdp_rank_domains.argtypes = [C.c_int, C.c_int, C.c_int, P(C.c_int), P(C.c_int)]
     lib.cfdp_rank_domains.restype = None
+    lib.cfdp_set_domain_map.argtypes = [P(C.c_int), C.c_int, C.c_int]
+    lib.cfdp_set_domain_map.restype = None
+    lib.cfdp_rank_domain_list.argtypes = [C.c_int, C.c_int, C.c_int, P(C.c_int)]
+    lib.cfdp_cluster_domains.argtypes = [C.c_int, C.c_int, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
+    lib.cfdp_cluster_domains.restype = C.c_long
+    lib.cfdp_domain_graph.argtypes = [C.c_char_p, C.c_int, C.c_int, P(P(C.c_int)), P(P(C.c_int)), P(P(C.c_int))]
     lib.cfdp_merge_domains.argtypes = [C.c_int, P(C.c_int), P(SolverData), P(CommData), C.c_int,
                                        C.c_int, C.c_int, P(SolverData), P(CommData),
                                        P(P(MergeInfo))]
@@ -424,6 +430,47 @@ def rank_domains(r: int, N: int, G: int):
     f, c = C.c_int(), C.c_int()
     host_lib().cfdp_rank_domains(r, N, G, C.byref(f), C.byref(c))
     return f.value, c.value
+
+
+def rank_domain_list(r: int, N: int, G: int) -> List[int]:
+    """the domains of rank r under the active domain -> rank mapping (blocks, or set_domain_map)"""
+    ids = (C.c_int * N)()
+    n = host_lib().cfdp_rank_domain_list(r, N, G, ids)
+    return list(ids[:n])
+
+
+def set_domain_map(rank_of_domain, G: int = 0) -> None:
+    """install (or, with None, remove) an explicit domain -> rank map for the merger"""
+    if rank_of_domain is None:
+        host_lib().cfdp_set_domain_map(None, 0, 0)
+        return
+    m = np.ascontiguousarray(rank_of_domain, np.int32)
+    host_lib().cfdp_set_domain_map(m.ctypes.data_as(C.POINTER(C.c_int)), len(m), G or int(m.max()) + 1)
+
+
+def cluster_domains(xadj, adj, wgt, G: int):
+    """greedy graph growing on the domain graph -> (rank_of_domain, weight of the cut edges)"""
+    xa, ad = np.ascontiguousarray(xadj, np.int32), np.ascontiguousarray(adj, np.int32)
+    wg = None if wgt is None else np.ascontiguousarray(wgt, np.int32)
+    ip = C.POINTER(C.c_int)
+    out = np.empty(len(xa) - 1, np.int32)
+    cut = host_lib().cfdp_cluster_domains(len(xa) - 1, G, xa.ctypes.data_as(ip), ad.ctypes.data_as(ip),
+                                          None if wg is None else wg.ctypes.data_as(ip), out.ctypes.data_as(ip))
+    return out, int(cut)
+
+
+def domain_graph(prefix: str, lvl: int, N: int):
+    """(xadj, adj, wgt) of the commpartner graph of N dualgrid files"""
+    ip = C.POINTER(C.c_int)
+    xa, ad, wg = ip(), ip(), ip()
+    host_lib().cfdp_domain_graph(prefix.encode(), lvl, N, C.byref(xa), C.byref(ad), C.byref(wg))
+    xadj = np.ctypeslib.as_array(xa, shape=(N + 1,)).copy()
+    n = int(xadj[N])
+    adj = np.ctypeslib.as_array(ad, shape=(max(n, 1),))[:n].copy()
+    wgt = np.ctypeslib.as_array(wg, shape=(max(n, 1),))[:n].copy()
+    for q in (xa, ad, wg):
+        _libc.free(q)
+    return xadj, adj, wgt
 
 
 def merge_domains(doms: Sequence[Domain], domain_ids: Sequence[int], N: int, G: int, r: int) -> Domain:

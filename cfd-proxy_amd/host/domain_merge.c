@@ -17,7 +17,30 @@
 
 #include <string.h>
 
+/* Optional explicit domain -> rank map (cfdp_set_domain_map).  Default: contiguous blocks of
+ * domain ids, which is right when the ids are spatially coherent (our generator numbers RCB
+ * leaves in order); for files whose numbering is not, cfdp_cluster_domains() builds a map from
+ * the commpartner graph.  Set once during setup, before any merge.                          */
+static int *g_domain_map = NULL;
+static int g_domain_map_n = 0, g_domain_map_g = 0;
+
+void cfdp_set_domain_map(const int *rank_of_domain, int N, int G) {
+  free(g_domain_map);
+  g_domain_map = NULL;
+  g_domain_map_n = g_domain_map_g = 0;
+  if (!rank_of_domain) return;
+  CFDP_ASSERT(N >= 1 && G >= 1);
+  g_domain_map = cfdp_malloc((size_t)N * sizeof(int));
+  for (int d = 0; d < N; d++) {
+    CFDP_ASSERT(rank_of_domain[d] >= 0 && rank_of_domain[d] < G);
+    g_domain_map[d] = rank_of_domain[d];
+  }
+  g_domain_map_n = N;
+  g_domain_map_g = G;
+}
+
 int cfdp_domain_rank(int domain, int N, int G) {
+  if (g_domain_map && g_domain_map_n == N && g_domain_map_g == G) return g_domain_map[domain];
   int base = N / G, rem = N % G;
   int cut = rem * (base + 1);
   if (domain < cut) return domain / (base + 1);
@@ -28,6 +51,88 @@ void cfdp_rank_domains(int r, int N, int G, int *first, int *count) {
   int base = N / G, rem = N % G;
   *first = r * base + (r < rem ? r : rem);
   *count = base + (r < rem ? 1 : 0);
+}
+
+int cfdp_rank_domain_list(int r, int N, int G, int *ids) {
+  int n = 0;
+  for (int d = 0; d < N; d++)
+    if (cfdp_domain_rank(d, N, G) == r) ids[n++] = d; /* ascending, as cfdp_merge_domains wants */
+  return n;
+}
+
+/* Greedy graph growing on the domain graph (CSR xadj/adj, edge weight = halo points exchanged):
+ * G clusters of N/G (+1) domains.  A cluster starts from the unassigned domain with the fewest
+ * unassigned neighbours (a corner of what is left) and repeatedly takes the unassigned domain
+ * with the heaviest connection to it, so clusters are compact and the halo between ranks small.
+ * Returns the total weight of the edges cut between ranks.                                  */
+long cfdp_cluster_domains(int N, int G, const int *xadj, const int *adj, const int *wgt, int *rank_of_domain) {
+  CFDP_ASSERT(N >= 1 && G >= 1 && G <= N);
+  long *gain = cfdp_calloc((size_t)N, sizeof(long));
+  for (int d = 0; d < N; d++) rank_of_domain[d] = -1;
+  int assigned = 0;
+  for (int r = 0; r < G; r++) {
+    const int target = N / G + (r < N % G ? 1 : 0);
+    for (int d = 0; d < N; d++) gain[d] = 0;
+    int size = 0;
+    while (size < target && assigned < N) {
+      int best = -1;
+      if (size > 0) { /* heaviest connection to the growing cluster */
+        for (int d = 0; d < N; d++)
+          if (rank_of_domain[d] < 0 && gain[d] > 0 && (best < 0 || gain[d] > gain[best])) best = d;
+      }
+      if (best < 0) { /* seed (or the cluster's component is exhausted): a corner of the rest */
+        int best_deg = 0;
+        for (int d = 0; d < N; d++) {
+          if (rank_of_domain[d] >= 0) continue;
+          int deg = 0;
+          for (int e = xadj[d]; e < xadj[d + 1]; e++) deg += rank_of_domain[adj[e]] < 0;
+          if (best < 0 || deg < best_deg) { best = d; best_deg = deg; }
+        }
+      }
+      rank_of_domain[best] = r;
+      size++;
+      assigned++;
+      for (int e = xadj[best]; e < xadj[best + 1]; e++) gain[adj[e]] += wgt ? wgt[e] : 1;
+    }
+  }
+  CFDP_ASSERT(assigned == N);
+  long cut = 0;
+  for (int d = 0; d < N; d++)
+    for (int e = xadj[d]; e < xadj[d + 1]; e++)
+      if (rank_of_domain[adj[e]] != rank_of_domain[d]) cut += wgt ? wgt[e] : 1;
+  free(gain);
+  return cut / 2;
+}
+
+/* the domain graph of a set of dualgrid files: neighbours = commpartner, weight = recvcount
+ * (src/comm_data.c:79-112).  Arrays are malloc'd; the caller frees them.                     */
+int cfdp_domain_graph(const char *prefix, int lvl, int N, int **pxadj, int **padj, int **pwgt) {
+  int *xadj = cfdp_calloc((size_t)N + 1, sizeof(int));
+  int cap = 16 * N + 16, n = 0;
+  int *adj = cfdp_malloc((size_t)cap * sizeof(int)), *wgt = cfdp_malloc((size_t)cap * sizeof(int));
+  for (int d = 0; d < N; d++) {
+    solver_data sd;
+    comm_data cd;
+    memset(&cd, 0, sizeof cd);
+    cd.nProc = N; cd.iProc = d;
+    cfdp_load_domain(prefix, d, lvl, &sd, &cd);
+    for (int i = 0; i < cd.ncommdomains; i++) {
+      const int k = cd.commpartner[i];
+      if (n == cap) {
+        cap *= 2;
+        adj = realloc(adj, (size_t)cap * sizeof(int));
+        wgt = realloc(wgt, (size_t)cap * sizeof(int));
+      }
+      adj[n] = k;
+      wgt[n] = cd.recvcount ? cd.recvcount[k] : 1;
+      n++;
+    }
+    xadj[d + 1] = n;
+    cfdp_free_solver_data(&sd);
+    cfdp_free_comm_data(&cd);
+  }
+  *pxadj = xadj; *padj = adj; *pwgt = wgt;
+  return 0;
 }
 
 typedef struct { int rank, domain, idx; } ext_key;

@@ -35,7 +35,7 @@ import numpy as np
 
 from . import (FLUX_CONSISTENT, TILES_ALL, TILES_BOUNDARY, TILES_INTERIOR, VAR_HASH, Domain,
                GpuPartition, fill_var, gen_domain, gen_global_ids, load_domain, merge_domains,
-               merge_requests, merge_set_send, rank_domains)
+               merge_requests, merge_set_send, rank_domain_list)
 
 ROWLEN = 21  # NGRAD * 3 doubles per halo point (reference dim2, src/gradients.c:176-177)
 
@@ -72,8 +72,8 @@ def build_rank_partition(gp, n_domains: int, world: int, rank: int, via_files: b
                          var_kind: int = VAR_HASH, workdir: Optional[str] = None) -> Tuple[Domain, dict]:
     """Generate (optionally through dualgrid files + the drop-in loader) and merge the domains
     of `rank`.  Returns the merged partition (send lists not yet linked) and setup stats."""
-    first, count = rank_domains(rank, n_domains, world)
-    ids = list(range(first, first + count))
+    ids = rank_domain_list(rank, n_domains, world)  # blocks of ids, or the installed domain map
+    count = len(ids)
     tmp = None
     doms = []
     if via_files:

@@ -68,9 +68,19 @@ typedef struct {
   long nfaces_in, nfaces_dropped;
 } cfdp_merge_info;
 
-/* rank that owns `domain` under the block distribution used everywhere */
+/* rank that owns `domain`: contiguous blocks of domain ids by default (cfdp_rank_domains gives
+ * a rank's block), or the explicit map installed with cfdp_set_domain_map (NULL removes it) --
+ * for dualgrid files whose domain numbering is not spatially coherent, built by
+ * cfdp_cluster_domains() from the commpartner graph of the files (cfdp_domain_graph; reference
+ * fields commpartner / recvcount, src/comm_data.c:79-112).  cfdp_rank_domain_list: a rank's
+ * domains under whichever mapping is active, ascending; returns their number.               */
 int  cfdp_domain_rank(int domain, int ndomains_total, int G);
 void cfdp_rank_domains(int r, int ndomains_total, int G, int *first, int *count);
+void cfdp_set_domain_map(const int *rank_of_domain, int ndomains_total, int G);
+int  cfdp_rank_domain_list(int r, int ndomains_total, int G, int *ids);
+long cfdp_cluster_domains(int ndomains_total, int G, const int *xadj, const int *adj, const int *wgt,
+                          int *rank_of_domain);
+int  cfdp_domain_graph(const char *prefix, int lvl, int ndomains_total, int **xadj, int **adj, int **wgt);
 
 /* merge `ndom_local` loaded domains into one partition.  out_cd gets nProc=G, iProc=r,
  * ndomains=G, commpartner/recvcount/recvindex filled; sendcount/sendindex are filled by

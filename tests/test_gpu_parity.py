@@ -381,6 +381,10 @@ def test_driver_binary_with_reference_cli(gpu, tmp_path):
     r = subprocess.run([exe, "-lvl", "2", prefix, "--gpus", "2", "--var", "hash"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "*** SUCCESS" in r.stdout and "comm_free:" in r.stdout and "exchange_dbl_xgmi_async:" in r.stdout
+    r = subprocess.run([exe, "-lvl", "2", prefix, "--gpus", "2", "--var", "hash", "--cluster"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "*** SUCCESS" in r.stdout and "clustered onto 2 ranks" in r.stdout
     r = subprocess.run([exe, "-bad"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "Usage" in r.stdout
 

@@ -214,3 +214,82 @@ def test_plan_handles_isolated_points_and_ghost_ghost_faces(pkg, orc):
     assert np.allclose(back[[0, 1, 2]], ref[[0, 1, 2]], rtol=1e-14)
     plan.free()
     dom.free()
+
+
+def test_domain_clustering_from_commpartner_graph(pkg, tmp_path):
+    """real dualgrid files need not number their domains coherently: ranks are then formed along
+    the commpartner graph of the files.  On a relabelled graph the clustered map cuts
+    far fewer halo points than blocks of ids, and about as few as blocks of the coherent ids."""
+    nd, G = 24, 4
+    gp = pkg.gen_params(24, 20, 16, ndomains=nd)
+    prefix = str(tmp_path / "dualgrid")
+    pkg.write_mesh(gp, prefix, 2)
+    xadj, adj, wgt = pkg.domain_graph(prefix, 2, nd)
+    assert xadj[0] == 0 and xadj[-1] == len(adj) == len(wgt) and (wgt > 0).all()
+    for d in range(nd):                                           # symmetric graph, symmetric weights
+        for e in range(xadj[d], xadj[d + 1]):
+            k = adj[e]
+            back = [i for i in range(xadj[k], xadj[k + 1]) if adj[i] == d]
+            assert len(back) == 1
+
+    def cut_of(mapping):
+        return sum(int(wgt[e]) for d in range(nd) for e in range(xadj[d], xadj[d + 1]) if mapping[adj[e]] != mapping[d]) // 2
+
+    blocks = np.array([pkg.host_lib().cfdp_domain_rank(d, nd, G) for d in range(nd)])
+    m, cut = pkg.cluster_domains(xadj, adj, wgt, G)
+    assert cut == cut_of(m) and sorted(np.bincount(m, minlength=G)) == [nd // G] * G
+    assert cut <= 1.3 * cut_of(blocks)
+    # relabel the domains at random: blocks of ids become scattered, the clustering does not care
+    rng = np.random.default_rng(7)
+    perm = rng.permutation(nd)                                    # new id of old domain d
+    inv = np.argsort(perm)
+    pxadj, padj, pwgt = [0], [], []
+    for new in range(nd):
+        old = inv[new]
+        for e in range(xadj[old], xadj[old + 1]):
+            padj.append(perm[adj[e]])
+            pwgt.append(wgt[e])
+        pxadj.append(len(padj))
+    pm, pcut = pkg.cluster_domains(pxadj, padj, pwgt, G)
+    scattered = sum(int(pwgt[e]) for d in range(nd) for e in range(pxadj[d], pxadj[d + 1]) if blocks[padj[e]] != blocks[d]) // 2
+    assert pcut <= 1.3 * cut_of(blocks) and pcut < 0.7 * scattered
+
+
+def test_merge_under_an_explicit_domain_map(pkg, orc):
+    """any domain -> rank map works for the merger (here the worst one: round robin)"""
+    dims, nd, G = (14, 12, 10), 8, 3
+    gp = pkg.gen_params(*dims, ndomains=nd, ghost_faces=1)
+    truth, _, _ = global_truth(pkg, orc, gp, pkg.VAR_HASH)
+    doms = [pkg.gen_domain(gp, d) for d in range(nd)]
+    gids = [pkg.gen_global_ids(gp, d, doms[d].nall) for d in range(nd)]
+    for d in range(nd):
+        pkg.fill_var(doms[d], gids[d], pkg.VAR_HASH, *dims)
+    pkg.set_domain_map([d % G for d in range(nd)], G)
+    try:
+        parts, mgids = [], []
+        for r in range(G):
+            ids = pkg.rank_domain_list(r, nd, G)
+            assert ids == [d for d in range(nd) if d % G == r]
+            part = pkg.merge_domains([doms[d] for d in ids], ids, nd, G, r)
+            mi = part.merge_info.contents
+            gid = np.full(part.nall, -1, np.int64)
+            for dl, d in enumerate(ids):
+                l2m = np.ctypeslib.as_array(mi.local2merged[dl], shape=(doms[d].nall,))
+                gid[l2m] = gids[d]
+                part.var[l2m] = doms[d].var
+            assert (gid >= 0).all() and len(np.unique(gid)) == part.nall
+            g = orc.np_gradients(part.fpoint, part.fnormal, part.pvolume, part.var, part.nown)
+            assert np.abs(g[: part.nown] - truth[gid[: part.nown]]).max() <= 1e-12 * np.abs(truth).max()
+            parts.append(part)
+            mgids.append(gid)
+        pkg.merge_link_group(parts)
+        for r, part in enumerate(parts):
+            for s in part.partners:
+                si, ri = part.sendindex(s), parts[s].recvindex(r)
+                assert len(si) == len(ri) > 0 and np.array_equal(mgids[r][si], mgids[s][ri])
+    finally:
+        pkg.set_domain_map(None)
+    for p in parts:
+        p.free()
+    for d in doms:
+        d.free()

@@ -37,6 +37,11 @@ check("3 bulk steps")
 g.run_steps_rccl(8, True, True, True); log("eager run")
 check("eager 8")
 import time
-g.sync(); t = time.perf_counter(); g.run_steps_rccl(500, True, True, True); t1 = time.perf_counter(); g.sync(); t2 = time.perf_counter()
-log("500 eager steps: host enqueue %.1f us/step, total %.1f us/step" % ((t1 - t) / 500 * 1e6, (t2 - t) / 500 * 1e6))
+def host_cost(tag, **kw):
+    g.sync(); t = time.perf_counter(); g.run_steps_rccl(500, **kw); t1 = time.perf_counter(); g.sync(); t2 = time.perf_counter()
+    log("%-34s host enqueue %.1f us/step, total %.1f us/step" % (tag, (t1 - t) / 500 * 1e6, (t2 - t) / 500 * 1e6))
+for _ in range(2):
+    host_cost("no exchange", with_exchange=False, overlap=False, with_flux=True)
+    host_cost("exchange, bulk", with_exchange=True, overlap=False, with_flux=True)
+    host_cost("exchange, overlapped", with_exchange=True, overlap=True, with_flux=True)
 g.close(); log("done")
