@@ -893,6 +893,14 @@ int cfdp_gpu_rccl_finalize(cfdp_gpu *g) {
   return 0;
 }
 
+// the RCCL group of the iteration opened by cfdp_gpu_step_pre (nothing if that step has no exchange)
+int cfdp_gpu_exchange_rccl(cfdp_gpu *g) {
+  NEED_UPLOAD(g);
+  if (!g->pending_exchange) return 0;
+  if (!g->comm) return fail("no communicator: call cfdp_gpu_rccl_init()");
+  return enqueue_exchange(g);
+}
+
 int cfdp_gpu_step_rccl(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {
   NEED_UPLOAD(g);
   if (with_exchange && !g->partner.empty() && !g->comm) return fail("no communicator: call cfdp_gpu_rccl_init()");

@@ -33,6 +33,7 @@ typedef struct cfdp_solver { /* what solver_data.gpu points to */
   cfdp_gpu *gpu;
   cfdp_group *group;
   int rank;
+  int external; /* partners live in other processes: exchange = RCCL (cfdp_attach_rccl) */
 } cfdp_solver;
 
 #define GPU_OK(call)                                                                       \
@@ -102,7 +103,8 @@ void init_threads(comm_data *cd, solver_data *sd, int NTHREADS) {
   (void)NTHREADS;
   cfdp_group *grp = (cfdp_group *)cd->group;
   int rank = cd->iProc;
-  if (!grp) { /* stand-alone partition: a private group of one */
+  int device_rank = rank;
+  if (!grp) { /* stand-alone partition (or one rank of a multi-process run): a private group of one */
     solver_data *sds[1] = {sd};
     comm_data *cds[1] = {cd};
     int np = cd->nProc, ip = cd->iProc;
@@ -118,7 +120,8 @@ void init_threads(comm_data *cd, solver_data *sd, int NTHREADS) {
     exit(EXIT_FAILURE);
   }
   cfdp_gpu *gpu = NULL;
-  GPU_OK(cfdp_gpu_create(rank % ndev, &gpu));
+  const char *devenv = getenv("CFDP_DEVICE"); /* default: ranks of a node take its devices in turn */
+  GPU_OK(cfdp_gpu_create(devenv ? atoi(devenv) : device_rank % ndev, &gpu));
   GPU_OK(cfdp_gpu_upload_plan(gpu, plan));
   cfdp_plan_free(plan);
   /* fused iterations: compute_psd_flux() defers the flux loop into the pass of the next
@@ -154,9 +157,24 @@ void cfdp_sync_fields_to_host(solver_data *sd) {
   GPU_OK(cfdp_gpu_get_flux(sv->gpu, &sd->psd_flux[0][0]));
 }
 
+/* one rank per process: give this partition's context its RCCL communicator; from then on the
+ * exchange of compute_gradients_gg_* is a group of ncclSend/ncclRecv with the other processes */
+void cfdp_attach_rccl(solver_data *sd, const void *unique_id128, int nranks, int rank) {
+  cfdp_solver *sv = solver_of(sd);
+  GPU_OK(cfdp_gpu_rccl_init(sv->gpu, unique_id128, nranks, rank, NULL));
+  sv->external = 1;
+}
+
+cfdp_gpu *cfdp_dropin_context(solver_data *sd) { return solver_of(sd)->gpu; }
+
 /* --------------------------------------------------------------- gradients (10 variants) */
 static void gradients(solver_data *sd, int with_exchange, int overlap) {
   cfdp_solver *sv = solver_of(sd);
+  if (sv->external) { /* step bracket + this iteration's RCCL group; compute_psd_flux closes the step */
+    GPU_OK(cfdp_gpu_step_pre(sv->gpu, with_exchange, overlap));
+    if (with_exchange) GPU_OK(cfdp_gpu_exchange_rccl(sv->gpu));
+    return;
+  }
   GPU_OK(cfdp_gpu_rank_gradients(sv->group->gpus, sv->group->G, sv->rank, with_exchange, overlap));
 }
 
@@ -190,6 +208,10 @@ ASYNC(compute_gradients_gg_mpipscw_async)
 
 void compute_psd_flux(solver_data *sd) {
   cfdp_solver *sv = solver_of(sd);
+  if (sv->external) {
+    GPU_OK(cfdp_gpu_step_post(sv->gpu, 1, sv->group->flux_mode));
+    return;
+  }
   GPU_OK(cfdp_gpu_rank_flux(sv->group->gpus, sv->group->G, sv->rank, 1, sv->group->flux_mode));
 }
 

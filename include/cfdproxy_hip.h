@@ -141,7 +141,14 @@ int  cfdp_rccl_load(const char *libpath);
 int  cfdp_rccl_unique_id(void *id128);
 int  cfdp_gpu_rccl_init(cfdp_gpu *g, const void *id128, int nranks, int rank, const int *rank_of_partner);
 int  cfdp_gpu_rccl_finalize(cfdp_gpu *g);
+int  cfdp_gpu_exchange_rccl(cfdp_gpu *g);   /* between cfdp_gpu_step_pre and cfdp_gpu_step_post */
 int  cfdp_gpu_step_rccl(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode);
+/* drop-in layer, one rank per process (e.g. MPI-launched, bin/hybrid.f6.hip.mpi): the context
+ * init_threads() built for `sd`, and its RCCL communicator -- afterwards compute_gradients_gg_*
+ * exchange with the other processes through it (replaces init_mpi_requests / the GASPI segment
+ * setup, src/exchange_data_mpi.c:27-76, src/exchange_data_gaspi.c:38-103)                     */
+cfdp_gpu *cfdp_dropin_context(solver_data *sd);
+void cfdp_attach_rccl(solver_data *sd, const void *unique_id128, int nranks, int rank);
 int  cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
                              int flux_mode);
 
