@@ -16,7 +16,7 @@ reqs = [{int(k): (v[0], v[1]) for k, v in pkg.merge_requests(p).items()} for p i
 for r, p in enumerate(parts):
     mg.exchange_requests(p, r, 2, None, all_requests=reqs)
 part = parts[0]
-g = pkg.GpuPartition(part, tile_points=32)
+g = pkg.GpuPartition(part, tile_points=int(os.environ.get("TP", "64")))
 g.set_fusion(os.environ.get("FUSION", "0") == "1")
 lib = mg.RankSolver.torch_rccl_path()
 log("lib", lib)
