@@ -314,6 +314,7 @@ int cfdp_gpu_set_var(cfdp_gpu *g, const double *var) {
   for (int i = 0; i < g->nall; i++)
     memcpy(&tmp[(size_t)i * 8], var + (size_t)g->new2old[i] * 7, 7 * sizeof(double));
   for (int i = 0; i < g->nown; i++) tmp[(size_t)i * 8 + 7] = g->vol[i];  // pvolume rides in the row's pad
+  HIP_TRY(hipDeviceSynchronize());  // the context's streams are non-blocking: nothing may still read var
   HIP_TRY(hipMemcpy(g->d_var, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
