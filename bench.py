@@ -68,9 +68,10 @@ def main() -> None:
     ap.add_argument("--no-finest", action="store_true", help="skip the finest-level single-GPU roofline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--cpu-samples", type=int, default=7)
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch", "staged"],
-                    help="rccl: ncclSend/ncclRecv issued by the C library; torch: torch.distributed P2P ops; "
-                         "staged: through the host (tests)")
+    ap.add_argument("--transport", default="ipc", choices=["ipc", "rccl", "torch", "staged"],
+                    help="ipc: xGMI write + notify between the processes of a node (falls back to rccl if its "
+                         "check fails); rccl: ncclSend/ncclRecv issued by the C library; torch: torch.distributed "
+                         "P2P ops; staged: through the host (tests)")
     args = ap.parse_args()
 
     import numpy as np
@@ -93,7 +94,8 @@ def main() -> None:
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = "gloo" if args.transport == "staged" else "nccl"
+        # RCCL needs one device per rank; ranks sharing a device (tests on a 1-GPU box) rendezvous over gloo
+        backend = "gloo" if args.transport == "staged" or ndev < world else "nccl"
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 device_id=torch.device("cuda", device) if backend == "nccl" else None)
 
@@ -107,6 +109,7 @@ def main() -> None:
                            tile_points=args.tile_points, grad_lanes=args.grad_lanes, flux_lanes=args.flux_lanes,
                            fusion=not args.no_fusion)
     t_setup = time.time() - t0
+    coll_device = solver.device if dist is not None and dist.get_backend() == "nccl" else "cpu"
 
     def barrier():
         solver.synchronize()
@@ -126,7 +129,7 @@ def main() -> None:
         barrier()
         dt = time.perf_counter() - t
         if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.transport == "staged" else solver.device)
+            tt = torch.tensor([dt], dtype=torch.float64, device=coll_device)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt
@@ -169,10 +172,15 @@ def main() -> None:
         sidx = [part.sendindex(k) for k in part.partners]  # a point sent to two partners counts twice
         sent = float(np.abs(g[np.concatenate(sidx)]).sum()) if sidx else 0.0
         got = float(np.abs(g[part.nown:]).sum())
-        tt = torch.tensor([sent, got], dtype=torch.float64, device="cpu" if args.transport == "staged" else solver.device)
+        tt = torch.tensor([sent, got], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tt)
         out["exchange_check"] = {"sum_abs_sent_rows": float(tt[0]), "sum_abs_ghost_rows": float(tt[1]),
                                  "ok": bool(abs(float(tt[0]) - float(tt[1])) <= 1e-9 * max(float(tt[0]), 1e-300))}
+        if solver.transport == "ipc":
+            et = torch.tensor([float(solver.gpu.ipc_error() != 0)], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(et)
+            out["exchange_check"]["wait_timeouts"] = int(et.item())
+            out["exchange_check"]["ok"] = out["exchange_check"]["ok"] and int(et.item()) == 0
 
     # ---- overlap efficiency (reference's own normalisation: comm_free / with exchange) ----
     if world > 1:

@@ -245,6 +245,13 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_rccl_finalize.argtypes = [vp]
     lib.cfdp_gpu_step_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_run_steps_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.cfdp_gpu_ipc_export.argtypes = [vp, vp, P(C.c_size_t)]
+    lib.cfdp_gpu_ipc_connect.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_size_t]
+    lib.cfdp_gpu_ipc_ready.argtypes = [vp]
+    lib.cfdp_gpu_ipc_disconnect.argtypes = [vp]
+    lib.cfdp_gpu_ipc_error.argtypes = [vp]
+    lib.cfdp_gpu_step_ipc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.cfdp_gpu_run_steps_ipc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_vcycle.argtypes = [P(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]
     lib.cfdp_gpu_counts.argtypes = [vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
 
@@ -716,6 +723,34 @@ class GpuPartition:
                        flux_mode: int = FLUX_CONSISTENT) -> None:
         self._ck(self.lib.cfdp_gpu_run_steps_rccl(self.h, steps, int(with_exchange), int(overlap), int(with_flux),
                                                   flux_mode))
+
+    # ---- xGMI write + notify between processes (HIP IPC)
+    def ipc_export(self):
+        """(64-byte IPC handle of this rank's block, bytes of one landing arena)"""
+        buf, n = C.create_string_buffer(64), C.c_size_t()
+        self._ck(self.lib.cfdp_gpu_ipc_export(self.h, buf, C.byref(n)))
+        return buf.raw, n.value
+
+    def ipc_connect(self, slot: int, handle: bytes, land_off0: int, land_off1: int, flag_off: int) -> None:
+        self._ck(self.lib.cfdp_gpu_ipc_connect(self.h, slot, C.create_string_buffer(handle, 64), land_off0, land_off1,
+                                               flag_off))
+
+    def ipc_ready(self) -> None:
+        self._ck(self.lib.cfdp_gpu_ipc_ready(self.h))
+
+    def ipc_disconnect(self) -> None:
+        self._ck(self.lib.cfdp_gpu_ipc_disconnect(self.h))
+
+    def ipc_error(self) -> int:
+        return self.lib.cfdp_gpu_ipc_error(self.h)
+
+    def step_ipc(self, with_exchange=True, overlap=True, with_flux=True, flux_mode: int = FLUX_CONSISTENT) -> None:
+        self._ck(self.lib.cfdp_gpu_step_ipc(self.h, int(with_exchange), int(overlap), int(with_flux), flux_mode))
+
+    def run_steps_ipc(self, steps: int, with_exchange=True, overlap=True, with_flux=True,
+                      flux_mode: int = FLUX_CONSISTENT, use_graph: bool = True) -> None:
+        self._ck(self.lib.cfdp_gpu_run_steps_ipc(self.h, steps, int(with_exchange), int(overlap), int(with_flux),
+                                                 flux_mode, int(use_graph)))
 
     def set_fusion(self, on: bool) -> None:
         """defer each iteration's flux into the pass that computes the next gradients"""

@@ -47,6 +47,12 @@ hipError_t gg_launch_pack(const int *send_idx, int nsend, const gg_grad_view &gr
                           hipStream_t stream);
 hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view &grad,
                             hipStream_t stream);
+// xGMI write + notify exchange (see gg_kernels.hip): header words of a rank's IPC block
+enum { GG_IPC_MAXSLOTS = 48, GG_IPC_ITER = 48, GG_IPC_ERR = 49, GG_IPC_HDR_BYTES = 256 };
+hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row, const int *send_off,
+                          const gg_grad_view &grad, double *const *dst, hipStream_t stream);
+hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, hipStream_t stream);
+hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, hipStream_t stream);
 extern int gg_debug_flags;
 hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux);
 

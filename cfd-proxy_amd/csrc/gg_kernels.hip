@@ -287,6 +287,7 @@ __device__ __forceinline__ int ld_i32_nowait(const int *p) {
 }
 __device__ __forceinline__ void glds16(const uint4 *src, unsigned char *lds_wave_base);
 __device__ __forceinline__ void glds16_nt(const uint4 *src, unsigned char *lds_wave_base);
+__device__ __forceinline__ void glds16_sys(const uint4 *src, unsigned char *lds_wave_base);
 
 template <bool NT, int CB, int KV>
 __device__ __forceinline__ void dma_stage_tile(unsigned char *buf, const cfdp_tile_desc &td,
@@ -358,6 +359,13 @@ __device__ __forceinline__ void glds16(const uint4 *src, unsigned char *lds_wave
 // the same with the non-temporal policy (aux = 2): for the tile blobs, which are read exactly
 // once per launch and would otherwise push the var rows (re-read as halo rows by the
 // neighbouring tiles) out of the XCD's L2
+// system scope (sc0 sc1): ghost rows may have been written by ANOTHER device straight into this
+// device's memory (xGMI write + notify exchange); a line of them left in this XCD's L2 from the
+// previous iteration would be stale, so these loads go past the L2
+__device__ __forceinline__ void glds16_sys(const uint4 *src, unsigned char *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 17);
+}
 __device__ __forceinline__ void glds16_nt(const uint4 *src, unsigned char *lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                    (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 2);
@@ -585,7 +593,9 @@ __global__ __launch_bounds__(1024) void gg_flux_kernel(
   for (int q = tid; q < (npts + nhalo) * 9; q += nthr) {
     const int r = q / 9, c = q - 9 * r;
     const int row = r < npts ? td.pstart + r : hid[r - npts];
-    g_l[r * 10 + c] = row < nown ? gradA[(size_t)row * 10 + c] : ghost[(size_t)(row - nown) * 21 + c];
+    g_l[r * 10 + c] = row < nown ? gradA[(size_t)row * 10 + c]
+                                 : __hip_atomic_load(&ghost[(size_t)(row - nown) * 21 + c], __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_SYSTEM);  // see glds16_sys
   }
   __syncthreads();
 
@@ -640,8 +650,11 @@ __global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
 #pragma unroll
   for (int k = 0; k < KV; k++) {
     const int row = rloc[k] < td.npts ? td.pstart + rloc[k] : hrow[k];
-    const unsigned char *src = row < nown ? abytes + (size_t)row * 80 : hbytes + (size_t)(row - nown) * 168;
-    glds16(reinterpret_cast<const uint4 *>(src + part[k] * 16), gbuf + (size_t)(w0 + k * nthr) * 16);
+    if (row < nown)
+      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * 80 + part[k] * 16), gbuf + (size_t)(w0 + k * nthr) * 16);
+    else
+      glds16_sys(reinterpret_cast<const uint4 *>(hbytes + (size_t)(row - nown) * 168 + part[k] * 16),
+                 gbuf + (size_t)(w0 + k * nthr) * 16);
   }
   __syncthreads();
   flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
@@ -721,8 +734,11 @@ void gg_fused_dma_kernel(
 #pragma unroll
   for (int k = 0; k < KG; k++) {
     const int row = rloc[k] < td.npts ? td.pstart + rloc[k] : hg[k];
-    const unsigned char *src = row < nown ? abytes + (size_t)row * 80 : hbytes + (size_t)(row - nown) * 168;
-    glds16(reinterpret_cast<const uint4 *>(src + part[k] * 16), gbuf + (size_t)(w0 + k * nthr) * 16);
+    if (row < nown)
+      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * 80 + part[k] * 16), gbuf + (size_t)(w0 + k * nthr) * 16);
+    else
+      glds16_sys(reinterpret_cast<const uint4 *>(hbytes + (size_t)(row - nown) * 168 + part[k] * 16),
+                 gbuf + (size_t)(w0 + k * nthr) * 16);
   }
   __syncthreads();
   if (!(dbg & 128))  // timing experiment: no flux phase
@@ -750,6 +766,70 @@ __global__ __launch_bounds__(256) void gg_unpack_kernel(const double *__restrict
   const int n = nrecv * 21;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     ghost[i] = recvbuf[i];  // ghost rows are in message order (host/tiling.c)
+}
+
+// ------------------------------------------------------------- xGMI write + notify exchange
+// The analogue of the reference's best variant, gaspi_write_notify + gaspi_notify_waitsome
+// (src/exchange_data_gaspi.c:105-151,190-305), between processes on one node: the packing kernel
+// writes the rows of every partner straight into that partner's landing arena (its memory,
+// mapped here through a HIP IPC handle -- stores over xGMI), a second kernel then raises the
+// iteration counter in each partner's flag word (system-scope release), and the receiver's
+// stream runs a one-wave kernel that polls its own flag words (system-scope acquire) before the
+// kernels that read the ghost rows.  All plain kernels: a whole iteration is hipGraph-capturable.
+// dst[s] = partner s's landing rows for this rank (parity chosen by the host: two arenas,
+// alternating by iteration, so a push never overwrites rows the partner may still be reading).
+__global__ __launch_bounds__(256) void gg_push_kernel(const int *__restrict__ send_idx, int nsend,
+                                                      const int *__restrict__ slot_of_row,
+                                                      const int *__restrict__ send_off,
+                                                      const double *__restrict__ gradA,
+                                                      const double *__restrict__ gradB,
+                                                      double *const *__restrict__ dst) {
+  const int n = nsend * 21;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int j = i / 21, c = i - 21 * j;
+    const size_t p = (size_t)send_idx[j];
+    const int s = slot_of_row[j];
+    const double v = c < 10 ? gradA[p * 10 + c] : gradB[p * 11 + c - 10];
+    dst[s][(size_t)(j - send_off[s]) * 21 + c] = v;
+  }
+}
+
+// hdr: [0..GG_IPC_MAXSLOTS) arrival counters written by the partners, [GG_IPC_ITER] this rank's
+// iteration counter, [GG_IPC_ERR] set when a wait gave up
+__global__ void gg_notify_kernel(int *__restrict__ hdr, int *const *__restrict__ remote_flag, int nslots) {
+  const int it = hdr[GG_IPC_ITER] + 1;
+  __syncthreads();
+  if ((int)threadIdx.x < nslots)
+    __hip_atomic_store(remote_flag[threadIdx.x], it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) hdr[GG_IPC_ITER] = it;
+}
+
+__global__ void gg_wait_kernel(int *__restrict__ hdr, int nslots, long max_polls) {
+  if ((int)threadIdx.x >= nslots) return;
+  const int need = hdr[GG_IPC_ITER];
+  for (long k = 0; k < max_polls; k++) {
+    if (__hip_atomic_load(&hdr[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= need) return;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  hdr[GG_IPC_ERR] = 1;  // bounded: a lost partner must not hang the device
+}
+
+hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row, const int *send_off,
+                          const gg_grad_view &grad, double *const *dst, hipStream_t stream) {
+  if (nsend <= 0) return hipSuccess;
+  int blocks = (nsend * 21 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gg_push_kernel, dim3(blocks), dim3(256), 0, stream, send_idx, nsend, slot_of_row, send_off,
+                     grad.a, grad.b, dst);
+  return hipGetLastError();
+}
+hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, hipStream_t stream) {
+  hipLaunchKernelGGL(gg_notify_kernel, dim3(1), dim3(64), 0, stream, hdr, remote_flag, nslots);
+  return hipGetLastError();
+}
+hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, hipStream_t stream) {
+  hipLaunchKernelGGL(gg_wait_kernel, dim3(1), dim3(64), 0, stream, hdr, nslots, max_polls);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------ launchers

@@ -60,6 +60,30 @@ struct cfdp_gpu {
   // one process per GPU: this rank's RCCL communicator and the communicator rank of every partner
   ncclComm_t comm = nullptr;
   std::vector<int> peer;
+  // xGMI write + notify exchange (cfdp_gpu_ipc_*): this rank's IPC block [header | landing arena 0
+  // | landing arena 1] -- partners write their rows and their arrival counters into it -- and the
+  // partners' blocks opened here.  The ghost block the kernels read is then landing arena
+  // (xiter & 1), xiter = exchanges started so far.
+  struct ipc_state {
+    bool on = false;
+    unsigned char *block = nullptr;
+    size_t land_bytes = 0;
+    long xiter = 0;
+    std::vector<void *> opened;                  // partner blocks (hipIpcOpenMemHandle)
+    std::vector<std::vector<unsigned char>> opened_handle;
+    std::vector<double *> dst[2];                // [parity][slot] where my rows land at the partner
+    std::vector<int *> rflag;                    // [slot] my arrival counter in the partner's header
+    double **d_dst[2] = {nullptr, nullptr};
+    int **d_rflag = nullptr;
+    int *d_slot_of_row = nullptr, *d_send_off = nullptr;
+    hipGraphExec_t graph = nullptr;
+    int g_exch = -1, g_overlap = -1, g_flux = -1, g_mode = -1;
+    const double *g_cur = nullptr;
+  } ipc;
+  double *land(int parity) const {
+    return reinterpret_cast<double *>(ipc.block + GG_IPC_HDR_BYTES + (size_t)parity * ipc.land_bytes);
+  }
+  int *ipc_hdr() const { return reinterpret_cast<int *>(ipc.block); }
   long iter = 0;               // phase-1 calls so far (in-process rank groups run in lockstep)
   std::vector<int> new2old, partner, send_off, recv_off;
   std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
@@ -74,7 +98,11 @@ struct cfdp_gpu {
   const double *graph_cur = nullptr;  // d_grad at capture: the graph's pointers are baked in
 
   // d_grad: nall*21 doubles laid out [A: nown x 10][ghost rows: nghost x 21][B: nown x 11]
-  gg_grad_view grad_view() const { return gg_grad_view::of(d_grad, nown, nall); }
+  gg_grad_view grad_view() const {
+    gg_grad_view v = gg_grad_view::of(d_grad, nown, nall);
+    if (ipc.on) v.ghost = land((int)(ipc.xiter & 1));  // the latest exchange landed here
+    return v;
+  }
   gg_grad_view alt_view() const { return gg_grad_view::of(d_grad_alt, nown, nall); }
   bool will_fuse() const { return fusion && flux_pending >= 0 && d_grad_alt; }
   // device image <-> rows in FILE numbering
@@ -110,6 +138,10 @@ struct cfdp_gpu {
     return a;
   }
 };
+
+namespace {
+void ipc_release(cfdp_gpu *g);
+}
 
 extern "C" {
 
@@ -162,6 +194,7 @@ void cfdp_gpu_destroy(cfdp_gpu *g) {
   (void)hipSetDevice(g->device);
   (void)hipDeviceSynchronize();
   (void)cfdp_gpu_rccl_finalize(g);
+  ipc_release(g);
   free_device(g);
   if (!g->streams_exported) {  // exported streams may still be referenced by the caller's runtime
     if (g->s_main) (void)hipStreamDestroy(g->s_main);
@@ -328,6 +361,10 @@ int cfdp_gpu_set_grad(cfdp_gpu *g, const double *grad) {
   HIP_TRY(hipMemcpy(g->d_grad, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
   if (g->d_grad_alt)  // rows no kernel writes (ghosts without an exchange, faceless points) read the same from either buffer
     HIP_TRY(hipMemcpy(g->d_grad_alt, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (g->ipc.on && g->nall > g->nown)
+    for (int par = 0; par < 2; par++)
+      HIP_TRY(hipMemcpy(g->land(par), tmp.data() + (size_t)g->nown * 10,
+                        sizeof(double) * 21 * (size_t)(g->nall - g->nown), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -348,6 +385,9 @@ int cfdp_gpu_get_grad(cfdp_gpu *g, double *grad) {
   HIP_TRY(hipDeviceSynchronize());
   std::vector<double> tmp((size_t)g->nall * 21);
   HIP_TRY(hipMemcpy(tmp.data(), g->d_grad, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  if (g->ipc.on && g->nall > g->nown)  // the ghost rows live in the landing arena of the latest exchange
+    HIP_TRY(hipMemcpy(tmp.data() + (size_t)g->nown * 10, g->grad_view().ghost,
+                      sizeof(double) * 21 * (size_t)(g->nall - g->nown), hipMemcpyDeviceToHost));
   g->device_to_rows(tmp, grad);
   return 0;
 }
@@ -918,6 +958,221 @@ int cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int overl
   if (with_exchange && !g->partner.empty() && !g->comm) return fail("no communicator: call cfdp_gpu_rccl_init()");
   for (int i = 0; i < steps; i++)
     if (one_step(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
+  return 0;
+}
+
+// --------------------------------------- one process per GPU: xGMI write + notify (HIP IPC)
+// See gg_push_kernel.  Setup: every rank exports its block (cfdp_gpu_ipc_export), the host
+// exchanges the 64-byte handles and tells each rank, per partner slot, where in the partner's
+// block its rows land for either parity and where its arrival counter is (cfdp_gpu_ipc_connect);
+// cfdp_gpu_ipc_ready uploads the tables and switches the context's ghost block to the landing
+// arenas.  A step needs no communication library and no host involvement beyond kernel launches,
+// so a run of steps is replayed from one hipGraph.
+namespace {
+void ipc_release(cfdp_gpu *g) {
+  auto &I = g->ipc;
+  if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
+  for (void *p : I.opened) (void)hipIpcCloseMemHandle(p);
+  I.opened.clear(); I.opened_handle.clear();
+  for (int par = 0; par < 2; par++) { (void)hipFree(I.d_dst[par]); I.d_dst[par] = nullptr; I.dst[par].clear(); }
+  (void)hipFree(I.d_rflag); I.d_rflag = nullptr; I.rflag.clear();
+  (void)hipFree(I.d_slot_of_row); (void)hipFree(I.d_send_off);
+  I.d_slot_of_row = I.d_send_off = nullptr;
+  (void)hipFree(I.block); I.block = nullptr;
+  I.on = false; I.xiter = 0;
+}
+
+int one_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {
+  const bool comm = with_exchange && !g->partner.empty();
+  g->pending_exchange = false;
+  g->iter++;
+  const bool fused = g->will_fuse();
+  if (!fused && flush_flux(g)) return 1;
+  auto grad_tiles = [&](int which) { return fused ? launch_fused(g, which, g->s_main) : launch_grad(g, which, g->s_main); };
+  if (!comm) {
+    if (grad_tiles(CFDP_TILES_ALL)) return 1;
+    if (fused) fused_done(g);
+  } else {
+    auto &I = g->ipc;
+    const int nslots = (int)g->partner.size(), par = (int)((I.xiter + 1) & 1);
+    // ONE stream: boundary tiles, push + notify (two tiny kernels), interior tiles, wait.  What
+    // overlaps the interior tiles is the partners' side of the exchange -- their boundary tiles,
+    // their pushes, the flight over xGMI; a second stream would only hide this rank's own ~5 us of
+    // push + notify, at the price of a fork/join in every iteration of the graph.
+    if (grad_tiles(overlap ? CFDP_TILES_BOUNDARY : CFDP_TILES_ALL)) return 1;
+    gg_grad_view src = fused ? g->alt_view() : g->grad_view();  // the buffer this iteration's gradients went to
+    HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_main));
+    HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, g->s_main));
+    if (overlap && grad_tiles(CFDP_TILES_INTERIOR)) return 1;
+    if (fused) fused_done(g);
+    I.xiter++;  // from here on the ghost block is the arena this exchange lands in
+    HIP_TRY(gg_launch_wait(g->ipc_hdr(), nslots, 20000000L, g->s_main));  // bounded: a few seconds
+  }
+  if (with_flux) {
+    if (flux_mode != CFDP_FLUX_CONSISTENT && flux_mode != CFDP_FLUX_REFERENCE) return fail("bad flux mode %d", flux_mode);
+    if (g->fusion && g->d_grad_alt) g->flux_pending = flux_mode;
+    else if (launch_flux(g, flux_mode, g->s_main)) return 1;
+  }
+  return 0;
+}
+}  // namespace
+
+int cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes) {
+  NEED_UPLOAD(g);
+  if (!handle64) return fail("null argument");
+  if ((int)g->partner.size() > GG_IPC_MAXSLOTS) return fail("more than %d partners", GG_IPC_MAXSLOTS);
+  for (size_t s = 0; s < g->partner.size(); s++)  // the double-buffered arenas rely on traffic in both directions
+    if (g->send_off[s + 1] == g->send_off[s] || g->recv_off[s + 1] == g->recv_off[s])
+      return fail("partner %d is not a two-way partner", g->partner[s]);
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handles are 64 bytes");
+  ipc_release(g);
+  auto &I = g->ipc;
+  I.land_bytes = (((size_t)(g->nall - g->nown) * 21 * sizeof(double)) + 255) & ~(size_t)255;
+  const size_t bytes = GG_IPC_HDR_BYTES + 2 * I.land_bytes;
+  HIP_TRY(hipMalloc(&I.block, bytes));
+  HIP_TRY(hipMemset(I.block, 0, bytes));
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, I.block));
+  memcpy(handle64, &h, sizeof h);
+  if (land_bytes) *land_bytes = I.land_bytes;
+  const int nslots = (int)g->partner.size();
+  I.dst[0].assign(nslots, nullptr); I.dst[1].assign(nslots, nullptr); I.rflag.assign(nslots, nullptr);
+  return 0;
+}
+
+int cfdp_gpu_ipc_connect(cfdp_gpu *g, int slot, const void *partner_handle64, size_t land_off0,
+                         size_t land_off1, size_t flag_off) {
+  NEED_UPLOAD(g);
+  auto &I = g->ipc;
+  if (!I.block) return fail("cfdp_gpu_ipc_export() first");
+  if (slot < 0 || slot >= (int)g->partner.size() || !partner_handle64) return fail("bad partner slot");
+  void *base = nullptr;
+  for (size_t i = 0; i < I.opened.size(); i++)
+    if (!memcmp(I.opened_handle[i].data(), partner_handle64, 64)) base = I.opened[i];
+  if (!base) {
+    hipIpcMemHandle_t h;
+    memcpy(&h, partner_handle64, sizeof h);
+    HIP_TRY(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+    I.opened.push_back(base);
+    I.opened_handle.emplace_back((const unsigned char *)partner_handle64, (const unsigned char *)partner_handle64 + 64);
+  }
+  unsigned char *b = static_cast<unsigned char *>(base);
+  I.dst[0][slot] = reinterpret_cast<double *>(b + land_off0);
+  I.dst[1][slot] = reinterpret_cast<double *>(b + land_off1);
+  I.rflag[slot] = reinterpret_cast<int *>(b + flag_off);
+  return 0;
+}
+
+int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
+  NEED_UPLOAD(g);
+  auto &I = g->ipc;
+  if (!I.block) return fail("cfdp_gpu_ipc_export() first");
+  const int nslots = (int)g->partner.size();
+  for (int s = 0; s < nslots; s++)
+    if (!I.dst[0][s] || !I.dst[1][s] || !I.rflag[s]) return fail("partner slot %d is not connected", s);
+  const size_t nsend = (size_t)g->send_off.back();
+  std::vector<int> slot_of_row(nsend ? nsend : 1, 0);
+  for (int s = 0; s < nslots; s++)
+    for (int j = g->send_off[s]; j < g->send_off[s + 1]; j++) slot_of_row[j] = s;
+  for (int par = 0; par < 2; par++) {
+    HIP_TRY(hipMalloc(&I.d_dst[par], sizeof(double *) * (size_t)(nslots ? nslots : 1)));
+    if (nslots) HIP_TRY(hipMemcpy(I.d_dst[par], I.dst[par].data(), sizeof(double *) * (size_t)nslots, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMalloc(&I.d_rflag, sizeof(int *) * (size_t)(nslots ? nslots : 1)));
+  if (nslots) HIP_TRY(hipMemcpy(I.d_rflag, I.rflag.data(), sizeof(int *) * (size_t)nslots, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&I.d_slot_of_row, sizeof(int) * slot_of_row.size()));
+  HIP_TRY(hipMemcpy(I.d_slot_of_row, slot_of_row.data(), sizeof(int) * slot_of_row.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&I.d_send_off, sizeof(int) * g->send_off.size()));
+  HIP_TRY(hipMemcpy(I.d_send_off, g->send_off.data(), sizeof(int) * g->send_off.size(), hipMemcpyHostToDevice));
+  if (flush_flux(g)) return 1;
+  HIP_TRY(hipDeviceSynchronize());
+  // the ghost rows move into the landing arenas
+  if (g->nall > g->nown)
+    for (int par = 0; par < 2; par++)
+      HIP_TRY(hipMemcpy(g->land(par), g->d_grad + (size_t)g->nown * 10, sizeof(double) * 21 * (size_t)(g->nall - g->nown),
+                        hipMemcpyDeviceToDevice));
+  I.xiter = 0;
+  I.on = true;
+  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  return 0;
+}
+
+int cfdp_gpu_ipc_disconnect(cfdp_gpu *g) {
+  if (!g) return fail("null context");
+  HIP_TRY(hipSetDevice(g->device));
+  HIP_TRY(hipDeviceSynchronize());
+  ipc_release(g);
+  return 0;
+}
+
+// 1 if a wait for a partner's rows gave up (the partner is gone or far behind), else 0; -1 on error
+int cfdp_gpu_ipc_error(cfdp_gpu *g) {
+  if (!g || !g->ipc.block) return 0;
+  if (hipSetDevice(g->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+  int e = 0;
+  if (hipMemcpy(&e, g->ipc_hdr() + GG_IPC_ERR, sizeof e, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return e != 0;
+}
+
+int cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {
+  NEED_UPLOAD(g);
+  if (!g->ipc.on) return fail("cfdp_gpu_ipc_ready() has not been called");
+  return one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode);
+}
+
+// `steps` iterations.  use_graph: after two lead-in steps, 10 steps at a time are replayed from a
+// hipGraph (a linear chain of kernels, the push / notify / wait kernels included; an even count
+// restores the parity of the landing arenas and of the two grad buffers).
+int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
+                           int flux_mode, int use_graph) {
+  NEED_UPLOAD(g);
+  if (!g->ipc.on) return fail("cfdp_gpu_ipc_ready() has not been called");
+  if (steps < 1) return fail("steps must be >= 1");
+  auto &I = g->ipc;
+  const int chunk = 10;
+  int done = 0;
+  if (use_graph && steps >= chunk + 2) {
+    for (; done < 2; done++)
+      if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
+    if (I.xiter & 1) {  // a graph is tied to the arena parity it was captured at: even
+      if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
+      done++;
+    }
+    const bool stale = !I.graph || I.g_exch != with_exchange || I.g_overlap != overlap || I.g_flux != with_flux ||
+                       I.g_mode != flux_mode || I.g_cur != g->d_grad;
+    if (stale) {
+      if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
+      const double *cur0 = g->d_grad;
+      const int pend0 = g->flux_pending;
+      const long iter0 = g->iter, x0 = I.xiter;
+      hipGraph_t gr = nullptr;
+      HIP_TRY(hipStreamBeginCapture(g->s_main, hipStreamCaptureModeThreadLocal));
+      int rc = 0;
+      for (int i = 0; i < chunk && !rc; i++) rc = one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode);
+      hipError_t ec = hipStreamEndCapture(g->s_main, &gr);
+      const bool ok = !rc && ec == hipSuccess && gr && g->d_grad == cur0 && g->flux_pending == pend0;
+      if (ok && hipGraphInstantiate(&I.graph, gr, nullptr, nullptr, 0) != hipSuccess) I.graph = nullptr;
+      if (gr) (void)hipGraphDestroy(gr);
+      g->iter = iter0;
+      I.xiter = x0;  // nothing of the capture has run
+      if (!ok || !I.graph) {
+        if (g->d_grad != cur0) { std::swap(g->d_grad, g->d_grad_alt); std::swap(g->own_grad, g->own_grad_alt); }
+        g->flux_pending = pend0;
+        (void)hipGetLastError();
+        use_graph = 0;
+      } else {
+        I.g_exch = with_exchange; I.g_overlap = overlap; I.g_flux = with_flux; I.g_mode = flux_mode; I.g_cur = g->d_grad;
+      }
+    }
+    while (use_graph && steps - done >= chunk) {
+      HIP_TRY(hipGraphLaunch(I.graph, g->s_main));
+      g->iter += chunk;
+      if (with_exchange && !g->partner.empty()) I.xiter += chunk;
+      done += chunk;
+    }
+  }
+  for (; done < steps; done++)
+    if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
   return 0;
 }
 

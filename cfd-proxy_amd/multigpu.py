@@ -5,12 +5,22 @@ MPI/GASPI point-to-point messages (reference src/exchange_data_mpi.c:96-166,199-
 src/exchange_data_gaspi.c:105-151).  Here each GPU rank owns N/G whole domains
 (host/domain_merge.c) and exchanges 168-byte gradient rows with its neighbour ranks:
 
-  * transport "rccl" (default): grouped ncclSend/ncclRecv over xGMI issued by the C library itself
+  * transport "ipc": xGMI write + notify -- the analogue of the reference's best variant,
+    gaspi_write_notify / notify_waitsome (src/exchange_data_gaspi.c:105-151,190-305).  Every rank
+    exports a block [flag words | landing arena 0 | landing arena 1] through a HIP IPC handle; the
+    packing kernel writes a partner's rows straight into that partner's arena and a second kernel
+    raises the iteration counter in the partner's flag word; the receiver polls its own flags on
+    the device.  No communication library and no host work beyond kernel launches in the
+    iteration, so runs of iterations are replayed from a hipGraph.  One node only.  The setup
+    checks an exchange against the owners' values (twice, with var rescaled in between, so that a
+    stale copy of a ghost row could not pass) and falls back to "rccl" if it does not hold.
+  * transport "rccl": grouped ncclSend/ncclRecv over xGMI issued by the C library itself
     (cfdp_gpu_step_rccl / cfdp_gpu_run_steps_rccl: one host call per iteration or per batch of
     iterations), on a communicator it creates from a ncclUniqueId broadcast over the process
     group; RCCL is the library PyTorch already loaded.  The send side is the packed send arena,
     the receive side is the ghost block of `grad` itself (ghost rows are numbered in message
-    order), so there is no unpack pass and no staging copy.
+    order), so there is no unpack pass and no staging copy.  Used across nodes, and as the
+    fallback of "ipc".
   * transport "torch": the same messages as torch.distributed batch_isend_irecv ("nccl" backend)
     on the context's comm stream -- the fallback when the library cannot set up its own
     communicator (several Python-level calls per iteration).
@@ -142,6 +152,15 @@ class RankSolver:
             self.send_views.append(self.send_t[so:so + sb // 8])
             # whole rows inside the ghost block, one view per grad buffer
             self.recv_views.append([b[ro:ro + rb // 8] for b in self.grad_bufs])
+        if transport == "ipc" and world > 1:
+            try:
+                self._init_ipc()
+            except Exception as e:
+                import sys
+                print(f"[rank {rank}] xGMI write+notify setup failed ({e}); using RCCL", file=sys.stderr)
+                self.transport = transport = "rccl"
+        elif transport == "ipc":
+            self.transport = transport = "rccl"  # one rank: no exchange at all
         if transport == "rccl" and world > 1:
             try:
                 self._init_own_communicator()
@@ -159,16 +178,84 @@ class RankSolver:
         p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         return p if os.path.exists(p) else ""
 
+    def _coll_device(self):
+        """where tensors of the setup collectives live: the GPU with the nccl backend, else the host"""
+        return self.device if self.dist.get_backend() == "nccl" else "cpu"
+
+    def _all_ok(self, ok: bool) -> bool:
+        t = self.torch.tensor([1 if ok else 0], device=self._coll_device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def _init_ipc(self) -> None:
+        """collective: export / exchange handles / connect / validate; raises on every rank alike"""
+        dist = self.dist
+        ok, info = True, None
+        try:
+            handle, land = self.gpu.ipc_export()
+            roff = [0]
+            for s in range(len(self.partners)):
+                roff.append(roff[-1] + self.gpu.recv_slice(s)[1] // (8 * ROWLEN))
+            info = dict(handle=handle, land=land, partners=list(self.partners), recv_off=roff)
+        except Exception as e:
+            ok, self._ipc_why = False, str(e)
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, info if ok else None)
+        if any(g is None for g in gathered):
+            raise RuntimeError("a rank could not export its IPC block (%s)" % getattr(self, "_ipc_why", "other rank"))
+        try:
+            for s, p in enumerate(self.partners):
+                pi = gathered[p]
+                t = pi["partners"].index(self.rank)
+                base = 256 + pi["recv_off"][t] * 8 * ROWLEN
+                self.gpu.ipc_connect(s, pi["handle"], base, base + pi["land"], 4 * t)
+            self.gpu.ipc_ready()
+        except Exception as e:
+            ok, self._ipc_why = False, str(e)
+        if not self._all_ok(ok):  # (also the barrier: nobody pushes before everybody is ready)
+            self._ipc_off()
+            raise RuntimeError("a rank could not map its partners' IPC blocks (%s)" % getattr(self, "_ipc_why", "other rank"))
+        self.transport = "ipc"
+        if not self.validate_exchange():
+            self._ipc_off()
+            raise RuntimeError("the exchange check failed")
+
+    def _ipc_off(self) -> None:
+        try:
+            self.gpu.sync()
+        finally:
+            self.dist.barrier()
+            self.gpu.ipc_disconnect()
+            self.dist.barrier()
+
+    def validate_exchange(self) -> bool:
+        """collective: after a few iterations every ghost row must equal its owner's row -- checked
+        through the sums of |rows| sent and received over all ranks, for var and for 2*var (a stale
+        copy of a ghost row from the first pass cannot satisfy the second)"""
+        torch, dist, part = self.torch, self.dist, self.gpu.dom
+        sidx = [part.sendindex(k) for k in part.partners]
+        sidx = np.concatenate(sidx) if sidx else np.zeros(0, np.int32)
+        good = True
+        var0 = part.var.copy()
+        for scale in (1.0, 2.0, 1.0):
+            part.var[:] = var0 * scale
+            self.gpu._ck(self.gpu.lib.cfdp_gpu_set_var(self.gpu.h, part.sd.var))
+            dist.barrier()
+            self.run_steps(4, with_exchange=True, overlap=True)
+            g = self.grad_host()
+            t = torch.tensor([float(np.abs(g[sidx]).sum()), float(np.abs(g[part.nown:]).sum()),
+                              float(self.gpu.ipc_error() != 0)], dtype=torch.float64, device=self._coll_device())
+            dist.all_reduce(t)
+            sent, got, err = (float(x) for x in t)
+            good = good and err == 0 and sent > 0 and abs(sent - got) <= 1e-9 * sent
+        return good
+
     def _init_own_communicator(self) -> None:
         """collective over the process group; raises on every rank alike when a step fails"""
         torch, dist = self.torch, self.dist
         lib = self.torch_rccl_path()
 
-        def all_ok(ok: bool) -> bool:
-            t = torch.tensor([1 if ok else 0], device=self.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return bool(int(t.item()))
-
+        all_ok = self._all_ok
         ok = True
         try:
             self.gpu._ck(self.gpu.lib.cfdp_rccl_load(lib.encode()))
@@ -225,6 +312,9 @@ class RankSolver:
         """one iteration = what test_solver times (reference src/solver.c:48-54): two ABI calls
         around one communication call"""
         comm = with_exchange and self.world > 1 and bool(self.partners)
+        if self.transport == "ipc":
+            self.gpu.step_ipc(comm, overlap, with_flux, flux_mode)
+            return
         if self.transport == "rccl":
             self.gpu.step_rccl(comm, overlap, with_flux, flux_mode)  # one call: brackets + ncclGroup
             return
@@ -237,6 +327,9 @@ class RankSolver:
                   flux_mode: int = FLUX_CONSISTENT) -> None:
         """`steps` iterations (one library call with the library's own communicator)"""
         comm = with_exchange and self.world > 1 and bool(self.partners)
+        if self.transport == "ipc":
+            self.gpu.run_steps_ipc(steps, comm, overlap, with_flux, flux_mode, use_graph=True)
+            return
         if self.transport == "rccl":
             self.gpu.run_steps_rccl(steps, comm, overlap, with_flux, flux_mode)
             return
@@ -254,4 +347,6 @@ class RankSolver:
         return self.gpu.dom.grad
 
     def close(self) -> None:
+        if self.transport == "ipc" and self.world > 1:
+            self._ipc_off()  # nobody unmaps or frees a block a partner may still write to
         self.gpu.close()

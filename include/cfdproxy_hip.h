@@ -152,6 +152,31 @@ void cfdp_attach_rccl(solver_data *sd, const void *unique_id128, int nranks, int
 int  cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
                              int flux_mode);
 
+/* one rank per process on one node, exchange by xGMI write + notify -- the analogue of the
+ * reference's best variant, gaspi_write_notify + gaspi_notify_waitsome
+ * (src/exchange_data_gaspi.c:105-151,190-305): the packing kernel writes each partner's rows
+ * straight into that partner's landing arena (mapped through a HIP IPC handle), a second kernel
+ * raises the iteration counter in the partner's flag word, the receiver's stream polls its own
+ * flag words before the ghost rows are read.  No communication library in the iteration, and a
+ * run of iterations is one hipGraph replay (cfdp_gpu_run_steps_ipc).
+ *   cfdp_gpu_ipc_export   allocate this rank's block [256-byte header | arena 0 | arena 1] and
+ *                         return its 64-byte IPC handle; *land_bytes = size of one arena.  A
+ *                         partner's rows for partner slot t land at header + parity*land_bytes +
+ *                         recv_off[t]*168, its arrival counter is the int at 4*t.
+ *   cfdp_gpu_ipc_connect  for my partner slot: the partner's handle and where, in ITS block, my
+ *                         rows land (both parities) and my arrival counter lives
+ *   cfdp_gpu_ipc_ready    switch the context over (the ghost block is then the landing arenas)
+ *   cfdp_gpu_ipc_error    1 if a wait for a partner gave up (bounded polling)                 */
+int  cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes);
+int  cfdp_gpu_ipc_connect(cfdp_gpu *g, int slot, const void *partner_handle64, size_t land_off0,
+                          size_t land_off1, size_t flag_off);
+int  cfdp_gpu_ipc_ready(cfdp_gpu *g);
+int  cfdp_gpu_ipc_disconnect(cfdp_gpu *g);
+int  cfdp_gpu_ipc_error(cfdp_gpu *g);
+int  cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode);
+int  cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
+                            int flux_mode, int use_graph);
+
 /* measurement: `iters` back-to-back launches bracketed by HIP events on the context's
  * main stream; average milliseconds per launch (gradient over all tiles; flux)           */
 int  cfdp_gpu_time_kernels(cfdp_gpu *g, int iters, int flux_mode, float *ms_grad, float *ms_flux);

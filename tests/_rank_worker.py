@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--dims", default="16,12,10")
     ap.add_argument("--ndomains", type=int, default=12)
     ap.add_argument("--files", action="store_true")
+    ap.add_argument("--transport", default="staged")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -57,13 +58,19 @@ def main():
     if args.gpu:
         ftruth = orc.np_flux(whole.fpoint, whole.fnormal, truth, whole.nown, mode=0)
         for fusion in (False, True):
-            solver = mg.RankSolver(part, rank, world, 0, dist, transport="staged", tile_points=32, fusion=fusion)
+            solver = mg.RankSolver(part, rank, world, 0, dist, transport=args.transport, tile_points=32, fusion=fusion)
+            assert solver.transport == args.transport, solver.transport  # no silent fallback in the tests
             for overlap in (True, False):
                 part.grad[:] = 1.0
                 part.psd_flux[:] = 2.0
                 solver.gpu.push_fields()
                 for _ in range(3):  # repeated: buffer reuse hazards, both grad buffers of the fused mode
                     solver.step(with_exchange=True, overlap=overlap, with_flux=True)
+                if args.transport == "ipc":  # batches: lead-in steps + hipGraph replays of 10 + remainder
+                    solver.run_steps(27, with_exchange=True, overlap=overlap)
+                    solver.run_steps(12, with_exchange=True, overlap=overlap)
+                    solver.run_steps(3, with_exchange=False, overlap=overlap)
+                    assert solver.gpu.ipc_error() == 0
                 g = solver.grad_host().copy()
                 err = np.abs(g - truth[gid]).max() / np.abs(truth).max()
                 assert err <= 1e-12, (rank, fusion, overlap, err)

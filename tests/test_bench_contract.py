@@ -27,10 +27,7 @@ def test_bench_line(gpu):
     assert out["value"] > 0 and out["ms_per_step"] > 0
 
 
-@pytest.mark.gpu
-def test_bench_two_ranks_staged_transport(gpu):
-    """the N>1 code path of bench.py (mesh partitioning across ranks, request exchange, overlapped
-    halo exchange, overlap report) with 2 ranks sharing this GPU and the host-staged transport"""
+def _bench_two_ranks(transport):
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -41,7 +38,7 @@ def test_bench_two_ranks_staged_transport(gpu):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
-                                       "--warmup", "3", "--transport", "staged", "--no-files"], env=env, cwd=ROOT,
+                                       "--warmup", "3", "--transport", transport, "--no-files"], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (so, se) in zip(procs, outs):
@@ -52,5 +49,21 @@ def test_bench_two_ranks_staged_transport(gpu):
     assert out["config"]["ghost_points_per_gpu"] > 0 and "overlap" in out
     assert 0 < out["overlap"]["efficiency_async"] <= 1.5
     assert out["exchange_check"]["ok"], out["exchange_check"]
-    assert out["config"]["transport"] == "staged" and out["config"]["fused_iterations"]
+    assert out["config"]["transport"] == transport and out["config"]["fused_iterations"]
     assert "cpu_baseline" not in out
+    return out
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_staged_transport(gpu):
+    """the N>1 code path of bench.py (mesh partitioning across ranks, request exchange, overlapped
+    halo exchange, overlap report) with 2 ranks sharing this GPU and the host-staged transport"""
+    _bench_two_ranks("staged")
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_xgmi_write_notify(gpu):
+    """bench.py --gpus 2 with its default transport (xGMI write + notify through HIP IPC, steps
+    replayed from hipGraphs), the two ranks sharing this GPU; every sent row must have arrived"""
+    out = _bench_two_ranks("ipc")
+    assert out["exchange_check"]["wait_timeouts"] == 0

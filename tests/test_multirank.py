@@ -50,6 +50,17 @@ def test_multirank_ranksolver_staged_on_one_gpu(gpu):
     _launch(3, ["--gpu", "--files"])
 
 
+@pytest.mark.gpu
+def test_multirank_xgmi_write_notify_between_processes_on_one_gpu(gpu):
+    """the "ipc" transport for real: 2, 3 and 4 processes sharing this GPU map each other's landing
+    arenas through HIP IPC handles, push rows and flags into them from kernels, poll flags on the
+    device, replay steps from hipGraphs; owned AND ghost gradient rows and the flux are checked
+    against the un-partitioned mesh"""
+    _launch(2, ["--gpu", "--transport", "ipc"])
+    _launch(3, ["--gpu", "--transport", "ipc", "--files"])
+    _launch(4, ["--gpu", "--transport", "ipc", "--dims", "16,16,12", "--ndomains", "8"])
+
+
 MPIEXEC = "/opt/conda/bin/mpiexec"
 MPI_DRIVER = os.path.join(ROOT, "cfd-proxy_amd", "bin", "hybrid.f6.hip.mpi")
 
