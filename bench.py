@@ -68,10 +68,11 @@ def main() -> None:
     ap.add_argument("--no-finest", action="store_true", help="skip the finest-level single-GPU roofline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--cpu-samples", type=int, default=7)
-    ap.add_argument("--transport", default="ipc", choices=["ipc", "rccl", "torch", "staged"],
-                    help="ipc: xGMI write + notify between the processes of a node (falls back to rccl if its "
-                         "check fails); rccl: ncclSend/ncclRecv issued by the C library; torch: torch.distributed "
-                         "P2P ops; staged: through the host (tests)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "ipc", "rccl", "torch", "staged"],
+                    help="auto: set up ipc and rccl, time both briefly, keep the faster; ipc: xGMI write + notify "
+                         "between the processes of a node (falls back to rccl if its check fails); rccl: "
+                         "ncclSend/ncclRecv issued by the C library; torch: torch.distributed P2P ops; staged: "
+                         "through the host (tests)")
     args = ap.parse_args()
 
     import numpy as np
@@ -108,6 +109,8 @@ def main() -> None:
     solver = mg.RankSolver(part, rank, world, device, dist, transport=args.transport,
                            tile_points=args.tile_points, grad_lanes=args.grad_lanes, flux_lanes=args.flux_lanes,
                            fusion=not args.no_fusion)
+    if world > 1 and args.transport == "auto":
+        solver.choose_transport()
     t_setup = time.time() - t0
     coll_device = solver.device if dist is not None and dist.get_backend() == "nccl" else "cpu"
 
@@ -158,6 +161,7 @@ def main() -> None:
             "ghost_points_per_gpu": nadd, "iteration": "gradients + halo exchange + pseudo flux",
             "fused_iterations": not args.no_fusion,
             "transport": solver.transport if world > 1 else "none (one partition)",
+            "transport_probe_us_per_iteration": solver.probe if world > 1 else {},
             "mesh_iterations_per_s": its, "via_dualgrid_files": not args.no_files,
             "tiles": solver.gpu.stats["ntiles"], "tile_points": solver.gpu.stats["tile_points"],
             "setup_s": round(t_setup, 2),

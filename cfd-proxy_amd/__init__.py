@@ -248,6 +248,7 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_ipc_export.argtypes = [vp, vp, P(C.c_size_t)]
     lib.cfdp_gpu_ipc_connect.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_size_t]
     lib.cfdp_gpu_ipc_ready.argtypes = [vp]
+    lib.cfdp_gpu_ipc_enable.argtypes = [vp, C.c_int]
     lib.cfdp_gpu_ipc_disconnect.argtypes = [vp]
     lib.cfdp_gpu_ipc_error.argtypes = [vp]
     lib.cfdp_gpu_step_ipc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -737,6 +738,9 @@ class GpuPartition:
 
     def ipc_ready(self) -> None:
         self._ck(self.lib.cfdp_gpu_ipc_ready(self.h))
+
+    def ipc_enable(self, on: bool) -> None:
+        self._ck(self.lib.cfdp_gpu_ipc_enable(self.h, int(on)))
 
     def ipc_disconnect(self) -> None:
         self._ck(self.lib.cfdp_gpu_ipc_disconnect(self.h))

@@ -1097,6 +1097,19 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
   return 0;
 }
 
+// switch between the landing arenas and the ghost block of grad (e.g. to time another transport
+// on the same context); the mappings stay
+int cfdp_gpu_ipc_enable(cfdp_gpu *g, int on) {
+  NEED_UPLOAD(g);
+  auto &I = g->ipc;
+  if (on && (!I.block || !I.d_rflag)) return fail("cfdp_gpu_ipc_ready() has not been called");
+  if (flush_flux(g)) return 1;
+  HIP_TRY(hipDeviceSynchronize());
+  I.on = on != 0;
+  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  return 0;
+}
+
 int cfdp_gpu_ipc_disconnect(cfdp_gpu *g) {
   if (!g) return fail("null context");
   HIP_TRY(hipSetDevice(g->device));

@@ -113,7 +113,7 @@ class RankSolver:
     """The per-rank iteration: gradients (+ halo exchange) + pseudo flux on one GPU."""
 
     def __init__(self, part: Domain, rank: int, world: int, device: int, dist=None,
-                 transport: str = "rccl", tile_points: int = 0, grad_lanes: int = 0, flux_lanes: int = 0,
+                 transport: str = "auto", tile_points: int = 0, grad_lanes: int = 0, flux_lanes: int = 0,
                  fusion: bool = True):
         import torch
 
@@ -152,22 +152,36 @@ class RankSolver:
             self.send_views.append(self.send_t[so:so + sb // 8])
             # whole rows inside the ghost block, one view per grad buffer
             self.recv_views.append([b[ro:ro + rb // 8] for b in self.grad_bufs])
-        if transport == "ipc" and world > 1:
+        # "auto": set up both device-side transports and let choose_transport() time them
+        self.available: List[str] = []
+        self.probe: Dict[str, float] = {}
+        if transport in ("ipc", "auto") and world > 1:
             try:
                 self._init_ipc()
+                self.available.append("ipc")
             except Exception as e:
                 import sys
                 print(f"[rank {rank}] xGMI write+notify setup failed ({e}); using RCCL", file=sys.stderr)
-                self.transport = transport = "rccl"
-        elif transport == "ipc":
-            self.transport = transport = "rccl"  # one rank: no exchange at all
-        if transport == "rccl" and world > 1:
+                if transport == "ipc":
+                    transport = "rccl"
+        elif transport in ("ipc", "auto"):
+            transport = "rccl"  # one rank: no exchange at all
+        if transport == "rccl" and world > 1 and dist.get_backend() != "nccl":
+            raise ValueError("the rccl transport needs one device per rank (process group backend nccl)")
+        if transport in ("rccl", "auto") and world > 1 and dist.get_backend() == "nccl":
             try:
                 self._init_own_communicator()
+                self.available.append("rccl")
             except Exception as e:  # keep going on the torch.distributed transport
                 import sys
                 print(f"[rank {rank}] own RCCL communicator failed ({e}); using torch.distributed P2P", file=sys.stderr)
-                self.transport = transport = "torch"
+                if transport == "rccl":
+                    transport = "torch"
+        if transport == "auto":
+            transport = self.available[0] if self.available else "torch"
+        if "ipc" in self.available and transport != "ipc":
+            self.gpu.ipc_enable(False)
+        self.transport = transport
         if transport == "staged":
             self.h_send = [torch.empty(v.numel(), dtype=torch.float64).pin_memory() for v in self.send_views]
             self.h_recv = [torch.empty(v[0].numel(), dtype=torch.float64).pin_memory() for v in self.recv_views]
@@ -219,6 +233,36 @@ class RankSolver:
         if not self.validate_exchange():
             self._ipc_off()
             raise RuntimeError("the exchange check failed")
+
+    def use_transport(self, name: str) -> None:
+        """switch between the transports set up by transport="auto" (collective: all ranks alike)"""
+        if name not in self.available:
+            raise ValueError(f"transport {name} is not available ({self.available})")
+        self.synchronize()
+        if "ipc" in self.available:
+            self.gpu.ipc_enable(name == "ipc")
+        self.transport = name
+        self.dist.barrier()
+
+    def choose_transport(self, steps: int = 200) -> str:
+        """collective: time `steps` overlapped iterations on every available transport (max over
+        ranks) and keep the fastest; self.probe holds the microseconds per iteration"""
+        import time
+        torch, dist = self.torch, self.dist
+        for name in list(self.available):
+            self.use_transport(name)
+            self.run_steps(20, with_exchange=True, overlap=True)
+            self.synchronize()
+            dist.barrier()
+            t = time.perf_counter()
+            self.run_steps(steps, with_exchange=True, overlap=True)
+            self.synchronize()
+            dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=self._coll_device())
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            self.probe[name] = float(dt.item()) / steps * 1e6
+        if self.probe:
+            self.use_transport(min(self.probe, key=self.probe.get))
+        return self.transport
 
     def _ipc_off(self) -> None:
         try:
@@ -347,6 +391,6 @@ class RankSolver:
         return self.gpu.dom.grad
 
     def close(self) -> None:
-        if self.transport == "ipc" and self.world > 1:
+        if "ipc" in self.available and self.world > 1:
             self._ipc_off()  # nobody unmaps or frees a block a partner may still write to
         self.gpu.close()

@@ -171,6 +171,7 @@ int  cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes);
 int  cfdp_gpu_ipc_connect(cfdp_gpu *g, int slot, const void *partner_handle64, size_t land_off0,
                           size_t land_off1, size_t flag_off);
 int  cfdp_gpu_ipc_ready(cfdp_gpu *g);
+int  cfdp_gpu_ipc_enable(cfdp_gpu *g, int on);   /* keep the mappings, use / do not use them */
 int  cfdp_gpu_ipc_disconnect(cfdp_gpu *g);
 int  cfdp_gpu_ipc_error(cfdp_gpu *g);
 int  cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode);
