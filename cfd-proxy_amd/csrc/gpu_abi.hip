@@ -982,7 +982,7 @@ void ipc_release(cfdp_gpu *g) {
   I.on = false; I.xiter = 0;
 }
 
-int one_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {
+int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   const bool comm = with_exchange && !g->partner.empty();
   g->pending_exchange = false;
   g->iter++;
@@ -1008,6 +1008,11 @@ int one_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int
     I.xiter++;  // from here on the ghost block is the arena this exchange lands in
     HIP_TRY(gg_launch_wait(g->ipc_hdr(), nslots, 20000000L, g->s_main));  // bounded: a few seconds
   }
+  return 0;
+}
+
+int one_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {
+  if (ipc_pre(g, with_exchange, overlap)) return 1;
   if (with_flux) {
     if (flux_mode != CFDP_FLUX_CONSISTENT && flux_mode != CFDP_FLUX_REFERENCE) return fail("bad flux mode %d", flux_mode);
     if (g->fusion && g->d_grad_alt) g->flux_pending = flux_mode;
@@ -1125,6 +1130,14 @@ int cfdp_gpu_ipc_error(cfdp_gpu *g) {
   int e = 0;
   if (hipMemcpy(&e, g->ipc_hdr() + GG_IPC_ERR, sizeof e, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return e != 0;
+}
+
+// the part of an iteration before the flux (gradients, push, notify, wait); cfdp_gpu_step_post
+// closes the iteration -- for hosts that call the two face loops separately
+int cfdp_gpu_step_ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
+  NEED_UPLOAD(g);
+  if (!g->ipc.on) return fail("cfdp_gpu_ipc_ready() has not been called");
+  return ipc_pre(g, with_exchange, overlap);
 }
 
 int cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {

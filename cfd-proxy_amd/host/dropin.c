@@ -33,7 +33,7 @@ typedef struct cfdp_solver { /* what solver_data.gpu points to */
   cfdp_gpu *gpu;
   cfdp_group *group;
   int rank;
-  int external; /* partners live in other processes: exchange = RCCL (cfdp_attach_rccl) */
+  int external; /* partners live in other processes: 1 = RCCL (cfdp_attach_rccl), 2 = xGMI write + notify */
 } cfdp_solver;
 
 #define GPU_OK(call)                                                                       \
@@ -165,11 +165,17 @@ void cfdp_attach_rccl(solver_data *sd, const void *unique_id128, int nranks, int
   sv->external = 1;
 }
 
+void cfdp_attach_ipc(solver_data *sd) { solver_of(sd)->external = 2; }
+
 cfdp_gpu *cfdp_dropin_context(solver_data *sd) { return solver_of(sd)->gpu; }
 
 /* --------------------------------------------------------------- gradients (10 variants) */
 static void gradients(solver_data *sd, int with_exchange, int overlap) {
   cfdp_solver *sv = solver_of(sd);
+  if (sv->external == 2) { /* gradients, push, notify, wait; compute_psd_flux closes the step */
+    GPU_OK(cfdp_gpu_step_ipc_pre(sv->gpu, with_exchange, overlap));
+    return;
+  }
   if (sv->external) { /* step bracket + this iteration's RCCL group; compute_psd_flux closes the step */
     GPU_OK(cfdp_gpu_step_pre(sv->gpu, with_exchange, overlap));
     if (with_exchange) GPU_OK(cfdp_gpu_exchange_rccl(sv->gpu));

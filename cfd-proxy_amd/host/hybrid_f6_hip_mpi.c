@@ -4,13 +4,15 @@
  * here one rank per GPU:
  *
  *     mpiexec -n G hybrid.f6.hip.mpi -lvl [1-4] GRID_PREFIX [--flux-ref] [--var one|hash]
- *                                    [--cluster] [--dry-run]
+ *                                    [--cluster] [--rccl] [--dry-run]
  *
  * MPI is the control plane only: rank/size, the broadcast of the ncclUniqueId and the exchange
  * of the (domain, idx) request lists -- what create_recvsend_index does with MPI_Send/Recv
- * (src/comm_data.c:203-249).  The data path of an iteration is RCCL over xGMI, issued by the
- * library (cfdp_attach_rccl; compute_gradients_gg_* / compute_psd_flux are the reference's entry
- * points).  Rank r merges the N/G domain files that fall to it and times the same three
+ * (src/comm_data.c:203-249) -- or, when all ranks share a node (and --rccl is not given), of
+ * the HIP IPC handles of the landing arenas.  The data path of an iteration is then xGMI write +
+ * notify from kernels (cfdp_attach_ipc), otherwise RCCL over xGMI issued by the library
+ * (cfdp_attach_rccl); compute_gradients_gg_* / compute_psd_flux are the reference's entry
+ * points.  Rank r merges the N/G domain files that fall to it and times the same three
  * variants as test_solver, with MPI_Barrier + device sync around every sample
  * (src/solver.c:42-58).  --dry-run stops before the GPU is touched and checks the halo tables
  * (usable on a machine without GPUs).
@@ -46,12 +48,13 @@ int main(int argc, char *argv[]) {
   }
   const int lvl = atoi(argv[2]);
   const char *prefix = argv[3];
-  int flux_ref = 0, var_hash = 0, cluster = 0, dry = 0;
+  int flux_ref = 0, var_hash = 0, cluster = 0, dry = 0, force_rccl = 0;
   for (int i = 4; i < argc; i++) {
     if (!strcmp(argv[i], "--flux-ref")) flux_ref = 1;
     else if (!strcmp(argv[i], "--var") && i + 1 < argc) var_hash = !strcmp(argv[++i], "hash");
     else if (!strcmp(argv[i], "--cluster")) cluster = 1;
     else if (!strcmp(argv[i], "--dry-run")) dry = 1;
+    else if (!strcmp(argv[i], "--rccl")) force_rccl = 1;
   }
   char fname[4096];
   snprintf(fname, sizeof fname, "%s_domain_%d_lvl_%d", prefix, 0, lvl);
@@ -144,17 +147,69 @@ int main(int argc, char *argv[]) {
   init_threads(&cd, &sd, 0);
   cfdp_gpu *gpu = cfdp_dropin_context(&sd);
   if (flux_ref) cfdp_group_set_flux_mode((cfdp_group *)cd.group, CFDP_FLUX_REFERENCE);
-  if (G > 1) {
+  int use_ipc = 0;
+  if (G > 1 && !force_rccl) { /* one node? then the ranks can map each other's memory */
+    MPI_Comm node;
+    int nsize = 0;
+    MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, r, MPI_INFO_NULL, &node);
+    MPI_Comm_size(node, &nsize);
+    MPI_Comm_free(&node);
+    use_ipc = nsize == G;
+  }
+  if (use_ipc) {
+    /* every rank publishes {handle, arena size, partner list, receive offsets}; rank r's rows for
+     * its partner p land in p's block at header + parity*arena + recv_off_p[slot of r] rows */
+    enum { MAXP = 48 };
+    typedef struct { unsigned char handle[64]; long land; int np, partner[MAXP], recv_off[MAXP + 1]; } ipc_info;
+    ipc_info mine, *all_info = malloc((size_t)G * sizeof(ipc_info));
+    memset(&mine, 0, sizeof mine);
+    size_t land = 0;
+    int ok = cfdp_gpu_ipc_export(gpu, mine.handle, &land) == 0 && cfdp_gpu_npartners(gpu) <= MAXP;
+    mine.land = (long)land;
+    mine.np = ok ? cfdp_gpu_npartners(gpu) : -1;
+    for (int s = 0; s < mine.np; s++) {
+      size_t bytes = 0;
+      mine.partner[s] = cfdp_gpu_partner_rank(gpu, s);
+      (void)cfdp_gpu_recv_ptr(gpu, s, &bytes);
+      mine.recv_off[s + 1] = mine.recv_off[s] + (int)(bytes / (NGRAD * 3 * sizeof(double)));
+    }
+    MPI_Allgather(&mine, (int)sizeof mine, MPI_BYTE, all_info, (int)sizeof mine, MPI_BYTE, MPI_COMM_WORLD);
+    for (int p = 0; p < G; p++) ok = ok && all_info[p].np >= 0;
+    for (int s = 0; ok && s < mine.np; s++) {
+      const ipc_info *pi = &all_info[mine.partner[s]];
+      int t = -1;
+      for (int i = 0; i < pi->np; i++)
+        if (pi->partner[i] == r) t = i;
+      const size_t base = 256 + (size_t)pi->recv_off[t < 0 ? 0 : t] * NGRAD * 3 * sizeof(double);
+      ok = t >= 0 && cfdp_gpu_ipc_connect(gpu, s, pi->handle, base, base + (size_t)pi->land, 4 * (size_t)t) == 0;
+    }
+    ok = ok && cfdp_gpu_ipc_ready(gpu) == 0;
+    int all_ok = 0;
+    MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD); /* also: nobody pushes before everybody is ready */
+    free(all_info);
+    if (all_ok) {
+      cfdp_attach_ipc(&sd);
+      if (r == 0) printf("exchange: xGMI write + notify (HIP IPC)\n");
+    } else {
+      if (r == 0) printf("exchange: HIP IPC setup failed (%s), using RCCL\n", ok ? "another rank" : cfdp_gpu_last_error());
+      MPI_Barrier(MPI_COMM_WORLD);
+      cfdp_gpu_ipc_disconnect(gpu);
+      use_ipc = 0;
+    }
+  }
+  if (G > 1 && !use_ipc) {
     unsigned char id[128];
     if (cfdp_rccl_load(getenv("CFDP_RCCL_LIB"))) { fprintf(stderr, "Error: %s\n", cfdp_gpu_last_error()); MPI_Abort(MPI_COMM_WORLD, 1); }
     if (r == 0 && cfdp_rccl_unique_id(id)) { fprintf(stderr, "Error: %s\n", cfdp_gpu_last_error()); MPI_Abort(MPI_COMM_WORLD, 1); }
     MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
     cfdp_attach_rccl(&sd, id, G, r);
+    if (r == 0) printf("exchange: RCCL send/recv\n");
   }
 
   /* ---- test_solver across processes ---- */
   typedef void (*grad_fn)(comm_data *, solver_data *, int);
-  static const char *names[N_VARIANT] = {"comm_free", "exchange_dbl_rccl_bulk_sync", "exchange_dbl_rccl_async"};
+  const char *names[N_VARIANT] = {"comm_free", use_ipc ? "exchange_dbl_xgmi_notify_bulk_sync" : "exchange_dbl_rccl_bulk_sync",
+                                  use_ipc ? "exchange_dbl_xgmi_notify_async" : "exchange_dbl_rccl_async"};
   grad_fn fns[N_VARIANT] = {compute_gradients_gg_comm_free, compute_gradients_gg_mpi_bulk_sync,
                             compute_gradients_gg_gaspi_async};
   const int nvar = G == 1 ? 1 : N_VARIANT;
@@ -199,6 +254,14 @@ int main(int argc, char *argv[]) {
   MPI_Allreduce(sums, gs, 2, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
   const int ok = G == 1 || fabs(gs[0] - gs[1]) <= 1e-9 * (gs[0] > 1e-300 ? gs[0] : 1e-300);
   if (r == 0) printf("\nexchange check: sent %.12e received %.12e %s\n", gs[0], gs[1], ok ? "ok" : "MISMATCH");
+  if (use_ipc) {
+    int e = cfdp_gpu_ipc_error(gpu), any = 0;
+    MPI_Allreduce(&e, &any, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
+    if (any && r == 0) printf("exchange: a device-side wait for a partner timed out\n");
+    MPI_Barrier(MPI_COMM_WORLD); /* nobody unmaps a block a partner may still write to */
+    cfdp_gpu_ipc_disconnect(gpu);
+    MPI_Barrier(MPI_COMM_WORLD);
+  }
   free_communication_ressources(&cd);
   MPI_Barrier(MPI_COMM_WORLD);
   if (r == 0) printf(ok ? "*** SUCCESS\n" : "*** FAILURE\n");

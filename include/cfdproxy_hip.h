@@ -149,6 +149,9 @@ int  cfdp_gpu_step_rccl(cfdp_gpu *g, int with_exchange, int overlap, int with_fl
  * setup, src/exchange_data_mpi.c:27-76, src/exchange_data_gaspi.c:38-103)                     */
 cfdp_gpu *cfdp_dropin_context(solver_data *sd);
 void cfdp_attach_rccl(solver_data *sd, const void *unique_id128, int nranks, int rank);
+/* the same for the xGMI write + notify exchange: call after cfdp_gpu_ipc_export / _connect /
+ * _ready on cfdp_dropin_context(sd)                                                          */
+void cfdp_attach_ipc(solver_data *sd);
 int  cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
                              int flux_mode);
 
@@ -174,6 +177,7 @@ int  cfdp_gpu_ipc_ready(cfdp_gpu *g);
 int  cfdp_gpu_ipc_enable(cfdp_gpu *g, int on);   /* keep the mappings, use / do not use them */
 int  cfdp_gpu_ipc_disconnect(cfdp_gpu *g);
 int  cfdp_gpu_ipc_error(cfdp_gpu *g);
+int  cfdp_gpu_step_ipc_pre(cfdp_gpu *g, int with_exchange, int overlap); /* then cfdp_gpu_step_post */
 int  cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode);
 int  cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
                             int flux_mode, int use_graph);

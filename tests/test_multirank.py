@@ -93,3 +93,21 @@ def test_mpi_launched_driver_one_rank_on_gpu(gpu, tmp_path):
         pytest.skip("MPI runtime libraries not resolvable on this box")
     assert r.returncode == 0, r.stdout + r.stderr
     assert "*** SUCCESS" in r.stdout and "comm_free:" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(MPIEXEC) and os.path.exists(MPI_DRIVER)), reason="no MPI in this image")
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_mpi_launched_driver_xgmi_write_notify_on_one_gpu(gpu, tmp_path, nranks):
+    """mpiexec -n G hybrid.f6.hip.mpi with the ranks sharing this GPU: MPI control plane, HIP IPC
+    handles exchanged with MPI_Allgather, the reference's entry points driving push / notify / wait
+    kernels; the driver itself checks that every sent row arrived"""
+    prefix = str(tmp_path / "dualgrid")
+    gpu.write_mesh(gpu.gen_params(20, 16, 12, ndomains=6), prefix, 2)
+    r = subprocess.run([MPIEXEC, "-n", str(nranks), MPI_DRIVER, "-lvl", "2", prefix, "--var", "hash"],
+                       capture_output=True, text=True, timeout=400)
+    if r.returncode == 127:
+        pytest.skip("MPI runtime libraries not resolvable on this box")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "exchange: xGMI write + notify" in r.stdout and "*** SUCCESS" in r.stdout
+    assert "exchange_dbl_xgmi_notify_async:" in r.stdout and "exchange check:" in r.stdout and " ok" in r.stdout
