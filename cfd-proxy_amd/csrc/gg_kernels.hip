@@ -1015,6 +1015,7 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
     return hipGetLastError();                                                                     \
   } while (0)
   if (cb <= 5 && kv <= 3 && kg <= 4) LAUNCH_FUSED(5, 3, 4);
+  if (cb <= 5 && kv <= 4 && kg <= 4) LAUNCH_FUSED(5, 4, 4);  // 52 KiB: still three workgroups per CU
   if (cb <= 5 && kv <= 4 && kg <= 5) LAUNCH_FUSED(5, 4, 5);
   if (cb <= 6 && kv <= 5 && kg <= 6) LAUNCH_FUSED(6, 5, 6);
   if (cb <= 8 && kv <= 6 && kg <= 8) LAUNCH_FUSED(8, 6, 8);
@@ -1101,6 +1102,7 @@ hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
   SET_LDS((gg_fused_dma_kernel<true, false, CB, KV, KG>), all)   \
   SET_LDS((gg_fused_dma_kernel<true, true, CB, KV, KG>), all)
   SET_LDS_FUSED(5, 3, 4)
+  SET_LDS_FUSED(5, 4, 4)
   SET_LDS_FUSED(5, 4, 5)
   SET_LDS_FUSED(6, 5, 6)
   SET_LDS_FUSED(8, 6, 8)

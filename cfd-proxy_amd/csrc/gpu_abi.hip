@@ -430,30 +430,45 @@ static int pipe_for(const cfdp_gpu *g, int ntiles) {
   return g->pipeline >= 0 ? g->pipeline : 0;
 }
 
+// A launch covers one tile range.  The two tile classes (boundary tiles are half-size sheets)
+// only get launches of their own when the schedule needs the boundary tiles early; otherwise
+// ALL tiles go in ONE launch sized for the larger class -- a separate launch for the few hundred
+// boundary tiles of a rank costs ~15 us of mostly idle device per iteration (measured: 58 vs 43 us
+// for rank 0 of the 2- and 8-rank decompositions).
+struct tile_range { int begin, n, tp, max_halo, max_blob; size_t lds_grad, lds_flux; };
+static tile_range range_of(const cfdp_gpu *g, int which) {
+  auto cls = [&](int c) {
+    return tile_range{c ? g->nbtiles : 0, c ? g->ntiles - g->nbtiles : g->nbtiles, g->tp[c], g->max_halo[c],
+                      g->max_blob[c], g->lds_grad[c], g->lds_flux[c]};
+  };
+  if (which == CFDP_TILES_BOUNDARY) return cls(0);
+  if (which == CFDP_TILES_INTERIOR) return cls(1);
+  const tile_range b = cls(0), i = cls(1);
+  if (b.n == 0) return i;
+  if (i.n == 0) return b;
+  return tile_range{0, g->ntiles, b.tp > i.tp ? b.tp : i.tp, b.max_halo > i.max_halo ? b.max_halo : i.max_halo,
+                    b.max_blob > i.max_blob ? b.max_blob : i.max_blob, b.lds_grad > i.lds_grad ? b.lds_grad : i.lds_grad,
+                    b.lds_flux > i.lds_flux ? b.lds_flux : i.lds_flux};
+}
+
 static int launch_grad(cfdp_gpu *g, int which, hipStream_t st, const gg_grad_view *into = nullptr) {
   gg_args a = g->args();
   if (into) a.grad = *into;
-  if (which == CFDP_TILES_ALL || which == CFDP_TILES_BOUNDARY)
-    HIP_TRY(gg_launch_gradient(a, g->grad_lanes, 0, g->nbtiles, g->tp[0], g->lds_grad[0], g->max_halo[0],
-                               g->max_blob[0], pipe_for(g, g->nbtiles), g->streaming, st));
-  if (which == CFDP_TILES_ALL || which == CFDP_TILES_INTERIOR)
-    HIP_TRY(gg_launch_gradient(a, g->grad_lanes, g->nbtiles, g->ntiles - g->nbtiles, g->tp[1],
-                               g->lds_grad[1], g->max_halo[1], g->max_blob[1],
-                               pipe_for(g, g->ntiles - g->nbtiles), g->streaming, st));
+  const tile_range r = range_of(g, which);
+  HIP_TRY(gg_launch_gradient(a, g->grad_lanes, r.begin, r.n, r.tp, r.lds_grad, r.max_halo, r.max_blob, pipe_for(g, r.n),
+                             g->streaming, st));
   return 0;
 }
 
-static int launch_flux_range(cfdp_gpu *g, int mode, int c, hipStream_t st) {
+static int launch_flux_tiles(cfdp_gpu *g, int mode, int which, hipStream_t st) {
   const gg_args a = g->args();
-  const int begin = c ? g->nbtiles : 0, n = c ? g->ntiles - g->nbtiles : g->nbtiles;
-  HIP_TRY(gg_launch_flux(a, g->flux_lanes, mode == CFDP_FLUX_REFERENCE, begin, n, g->tp[c], g->lds_flux[c],
-                         g->max_halo[c], g->max_blob[c], g->streaming, st));
+  const tile_range r = range_of(g, which);
+  HIP_TRY(gg_launch_flux(a, g->flux_lanes, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.lds_flux, r.max_halo,
+                         r.max_blob, g->streaming, st));
   return 0;
 }
 
-static int launch_flux(cfdp_gpu *g, int mode, hipStream_t st) {
-  return launch_flux_range(g, mode, 0, st) || launch_flux_range(g, mode, 1, st);
-}
+static int launch_flux(cfdp_gpu *g, int mode, hipStream_t st) { return launch_flux_tiles(g, mode, CFDP_TILES_ALL, st); }
 
 // the deferred flux (from d_grad) + the next gradients (into d_grad_alt) over the selected tiles
 // in one pass; falls back to the two separate kernels when no fused capacity fits the tiles.
@@ -462,17 +477,14 @@ static int launch_fused(cfdp_gpu *g, int which, hipStream_t st) {
   const gg_args a = g->args();
   const gg_grad_view gnew = g->alt_view();
   const int mode = g->flux_pending;
-  for (int c = 0; c < 2; c++) {
-    if (which == (c ? CFDP_TILES_BOUNDARY : CFDP_TILES_INTERIOR)) continue;
-    const int begin = c ? g->nbtiles : 0, n = c ? g->ntiles - g->nbtiles : g->nbtiles;
-    const hipError_t e = gg_launch_fused(a, gnew, mode == CFDP_FLUX_REFERENCE, begin, n, g->tp[c], g->max_halo[c],
-                                         g->max_blob[c], g->streaming, st);
-    if (e == hipErrorNotSupported) {
-      if (launch_flux_range(g, mode, c, st)) return 1;
-      if (launch_grad(g, c ? CFDP_TILES_INTERIOR : CFDP_TILES_BOUNDARY, st, &gnew)) return 1;
-    } else {
-      HIP_TRY(e);
-    }
+  const tile_range r = range_of(g, which);
+  const hipError_t e = gg_launch_fused(a, gnew, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.max_halo, r.max_blob,
+                                       g->streaming, st);
+  if (e == hipErrorNotSupported) {
+    if (launch_flux_tiles(g, mode, which, st)) return 1;
+    if (launch_grad(g, which, st, &gnew)) return 1;
+  } else {
+    HIP_TRY(e);
   }
   return 0;
 }
@@ -553,8 +565,8 @@ int cfdp_gpu_counts(const cfdp_gpu *g, int *nown, int *nall, int *nsend, int *nr
 // The caller owns the transport (e.g. RCCL send/recv enqueued on this context's comm stream
 // between the two calls); these two calls enqueue everything else of one iteration, so a
 // host pays two ABI calls + one communication call per step.
-//   pre : [boundary tiles -> pack -> ev_pack] on main; comm waits ev_pack and the previous
-//         flux (ghost rows are still being read); interior tiles on main
+//   pre : comm waits for the previous iteration (ev_fluxdone); [boundary tiles -> pack] on comm,
+//         interior tiles on main, concurrently (bulk: all tiles -> pack on main, comm waits ev_pack)
 //   post: main waits for everything enqueued on comm so far; flux; ev_fluxdone
 int cfdp_gpu_step_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   NEED_UPLOAD(g);
@@ -566,19 +578,28 @@ int cfdp_gpu_step_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   // the exchange between pre() and post() delivers)
   const bool fused = g->will_fuse();
   if (!fused && flush_flux(g)) return 1;
-  auto grad_tiles = [&](int which) { return fused ? launch_fused(g, which, g->s_main) : launch_grad(g, which, g->s_main); };
+  auto grad_tiles = [&](int which, hipStream_t st) { return fused ? launch_fused(g, which, st) : launch_grad(g, which, st); };
   if (!comm) {
-    if (grad_tiles(CFDP_TILES_ALL)) return 1;
+    if (grad_tiles(CFDP_TILES_ALL, g->s_main)) return 1;
     if (fused) fused_done(g);
     return 0;
   }
-  if (grad_tiles(overlap ? CFDP_TILES_BOUNDARY : CFDP_TILES_ALL)) return 1;
-  HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), fused ? g->alt_view() : g->grad_view(), g->d_sendbuf,
-                         g->s_main));
-  HIP_TRY(hipEventRecord(g->ev_pack, g->s_main));
-  HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_pack, 0));
+  const gg_grad_view src = fused ? g->alt_view() : g->grad_view();  // where this iteration's gradients go
+  // the comm stream starts after everything of the previous iteration (ev_fluxdone ends step_post)
   HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fluxdone, 0));
-  if (overlap && grad_tiles(CFDP_TILES_INTERIOR)) return 1;
+  if (overlap) {
+    // boundary tiles + pack (+ the caller's exchange) on the comm stream, interior tiles on the main
+    // stream AT THE SAME TIME: the few hundred boundary tiles alone would leave most of the device
+    // idle for the ~7 us a tile takes
+    if (grad_tiles(CFDP_TILES_BOUNDARY, g->s_comm)) return 1;
+    HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), src, g->d_sendbuf, g->s_comm));
+    if (grad_tiles(CFDP_TILES_INTERIOR, g->s_main)) return 1;
+  } else {
+    if (grad_tiles(CFDP_TILES_ALL, g->s_main)) return 1;
+    HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), src, g->d_sendbuf, g->s_main));
+    HIP_TRY(hipEventRecord(g->ev_pack, g->s_main));
+    HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_pack, 0));
+  }
   if (fused) fused_done(g);
   return 0;
 }
@@ -988,22 +1009,29 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   g->iter++;
   const bool fused = g->will_fuse();
   if (!fused && flush_flux(g)) return 1;
-  auto grad_tiles = [&](int which) { return fused ? launch_fused(g, which, g->s_main) : launch_grad(g, which, g->s_main); };
+  auto grad_tiles = [&](int which, hipStream_t st) { return fused ? launch_fused(g, which, st) : launch_grad(g, which, st); };
   if (!comm) {
-    if (grad_tiles(CFDP_TILES_ALL)) return 1;
+    if (grad_tiles(CFDP_TILES_ALL, g->s_main)) return 1;
     if (fused) fused_done(g);
   } else {
     auto &I = g->ipc;
     const int nslots = (int)g->partner.size(), par = (int)((I.xiter + 1) & 1);
-    // ONE stream: boundary tiles, push + notify (two tiny kernels), interior tiles, wait.  What
-    // overlaps the interior tiles is the partners' side of the exchange -- their boundary tiles,
-    // their pushes, the flight over xGMI; a second stream would only hide this rank's own ~5 us of
-    // push + notify, at the price of a fork/join in every iteration of the graph.
-    if (grad_tiles(overlap ? CFDP_TILES_BOUNDARY : CFDP_TILES_ALL)) return 1;
-    gg_grad_view src = fused ? g->alt_view() : g->grad_view();  // the buffer this iteration's gradients went to
-    HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_main));
-    HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, g->s_main));
-    if (overlap && grad_tiles(CFDP_TILES_INTERIOR)) return 1;
+    const gg_grad_view src = fused ? g->alt_view() : g->grad_view();  // the buffer this iteration's gradients go to
+    if (overlap) {
+      // boundary tiles -> push -> notify on the comm stream, the interior tiles on the main stream at
+      // the same time (see cfdp_gpu_step_pre); the wait joins them
+      HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fluxdone, 0));  // the previous iteration (recorded below)
+      if (grad_tiles(CFDP_TILES_BOUNDARY, g->s_comm)) return 1;
+      HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_comm));
+      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, g->s_comm));
+      HIP_TRY(hipEventRecord(g->ev_senddone, g->s_comm));
+      if (grad_tiles(CFDP_TILES_INTERIOR, g->s_main)) return 1;
+      HIP_TRY(hipStreamWaitEvent(g->s_main, g->ev_senddone, 0));
+    } else {
+      if (grad_tiles(CFDP_TILES_ALL, g->s_main)) return 1;
+      HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_main));
+      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, g->s_main));
+    }
     if (fused) fused_done(g);
     I.xiter++;  // from here on the ghost block is the arena this exchange lands in
     HIP_TRY(gg_launch_wait(g->ipc_hdr(), nslots, 20000000L, g->s_main));  // bounded: a few seconds
@@ -1018,6 +1046,7 @@ int one_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int
     if (g->fusion && g->d_grad_alt) g->flux_pending = flux_mode;
     else if (launch_flux(g, flux_mode, g->s_main)) return 1;
   }
+  HIP_TRY(hipEventRecord(g->ev_fluxdone, g->s_main));  // the iteration is complete (as in cfdp_gpu_step_post)
   return 0;
 }
 }  // namespace
@@ -1147,8 +1176,8 @@ int cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux
 }
 
 // `steps` iterations.  use_graph: after two lead-in steps, 10 steps at a time are replayed from a
-// hipGraph (a linear chain of kernels, the push / notify / wait kernels included; an even count
-// restores the parity of the landing arenas and of the two grad buffers).
+// hipGraph (both streams, the push / notify / wait kernels included; an even count restores the
+// parity of the landing arenas and of the two grad buffers).
 int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
                            int flux_mode, int use_graph) {
   NEED_UPLOAD(g);
@@ -1173,9 +1202,12 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       const long iter0 = g->iter, x0 = I.xiter;
       hipGraph_t gr = nullptr;
       HIP_TRY(hipStreamBeginCapture(g->s_main, hipStreamCaptureModeThreadLocal));
-      int rc = 0;
+      // the first captured step's comm stream waits for "the previous iteration": an in-capture record
+      int rc = hipEventRecord(g->ev_fluxdone, g->s_main) != hipSuccess;
       for (int i = 0; i < chunk && !rc; i++) rc = one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode);
       hipError_t ec = hipStreamEndCapture(g->s_main, &gr);
+      (void)hipEventRecord(g->ev_fluxdone, g->s_main);  // events last recorded inside a capture may not
+      (void)hipEventRecord(g->ev_senddone, g->s_comm);  // be waited for outside it: re-arm them
       const bool ok = !rc && ec == hipSuccess && gr && g->d_grad == cur0 && g->flux_pending == pend0;
       if (ok && hipGraphInstantiate(&I.graph, gr, nullptr, nullptr, 0) != hipSuccess) I.graph = nullptr;
       if (gr) (void)hipGraphDestroy(gr);

@@ -50,6 +50,10 @@ typedef struct {
   int *order; int norder;
   int *tile_first; int ntiles, cap_tiles;
   int cursor;
+  /* optional bound on a tile's halo (points it reads but does not own): hseen[q] == tile + 1
+   * marks q as a member or a halo point of the tile being grown; NULL = unbounded */
+  int *hseen;
+  int halo_cap;
 } tiler;
 
 static void tiler_open_tile(tiler *T) {
@@ -70,8 +74,11 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
   while (remaining > 0) {
     const int t = T->ntiles;
     tiler_open_tile(T);
-    int cnt = 0, head = 0, tail = 0;
+    int cnt = 0, head = 0, tail = 0, seen = 0;
     while (cnt < TP) {
+      /* a tile made of leftovers scattered between finished tiles reads ~14 rows per point; close
+       * it early rather than let one such tile size the LDS image of the whole launch */
+      if (T->hseen && cnt >= 4 && seen - cnt > T->halo_cap) break;
       if (head == tail) { /* need a seed */
         int seed = -1;
         while (T->sq_head < T->sq_tail) {
@@ -94,8 +101,10 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
       T->order[T->norder++] = p;
       cnt++;
       remaining--;
+      if (T->hseen && T->hseen[p] != t + 1) { T->hseen[p] = t + 1; seen++; }
       for (int e = T->xadj[p]; e < T->xadj[p + 1]; e++) {
         int q = T->adj_other[e];
+        if (T->hseen && T->hseen[q] != t + 1) { T->hseen[q] = t + 1; seen++; }
         if (q >= nown || T->tile_of[q] >= 0 || T->stamp[q] == t + 1) continue;
         if (mask && mask[q] != want) continue;
         T->stamp[q] = t + 1;
@@ -217,19 +226,31 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
   T.seedq = cfdp_malloc((size_t)nown * sizeof(int));
   T.lq = cfdp_malloc((size_t)nown * sizeof(int));
   T.order = cfdp_malloc((size_t)nown * sizeof(int));
+  /* bound the halo so that own + halo rows fit the smallest staging capacity of the kernels:
+   * (tile_points + halo) * 5 sixteen-byte pieces <= 4 * (4 lanes * tile_points) */
+  T.hseen = cfdp_calloc((size_t)nall, sizeof(int));
+  T.halo_cap = o.tile_points * 2 < 96 ? 96 : o.tile_points * 2;  /* small tiles: only the scattered ones */
   if (any_send && o.boundary_first) {
     int btp = o.tile_points / 2 < 8 ? 8 : o.tile_points / 2; /* sheets have big halos */
     tiler_pass(&T, is_send, 1, btp);
     P->nbtiles = T.ntiles;
-    /* seed the interior from the inner side of the boundary sheet */
-    memset(T.seeded, 0, (size_t)nown);
-    T.sq_head = T.sq_tail = 0;
-    for (int i = 0; i < T.norder; i++) {
-      int p = T.order[i];
-      for (int e = xadj[p]; e < xadj[p + 1]; e++) {
-        int q = adj_other[e];
-        if (q < nown && T.tile_of[q] < 0 && !T.seeded[q]) { T.seeded[q] = 1; T.seedq[T.sq_tail++] = q; }
+    /* the interior grows from ONE seed, layer by layer, like an un-partitioned mesh: seeding it
+     * from the whole inner side of the boundary sheet makes fronts collide everywhere and leaves
+     * ragged tiles (mean halo 130 instead of 113 rows, maximum 187 instead of 122 -- enough to
+     * push the kernels into the next LDS capacity class and down to 2 workgroups per CU) */
+    if (getenv("CFDP_TILER_SHELL_SEEDS")) { /* the old behaviour, for comparison */
+      memset(T.seeded, 0, (size_t)nown);
+      T.sq_head = T.sq_tail = 0;
+      for (int i = 0; i < T.norder; i++) {
+        int p = T.order[i];
+        for (int e = xadj[p]; e < xadj[p + 1]; e++) {
+          int q = adj_other[e];
+          if (q < nown && T.tile_of[q] < 0 && !T.seeded[q]) { T.seeded[q] = 1; T.seedq[T.sq_tail++] = q; }
+        }
       }
+    } else {
+      memset(T.seeded, 0, (size_t)nown);
+      T.sq_head = T.sq_tail = 0;
     }
     tiler_pass(&T, is_send, 0, o.tile_points);
   } else {
@@ -510,6 +531,7 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
   P->lds_flux = lds_f[0] > lds_f[1] ? lds_f[0] : lds_f[1];
   PLAN_STAGE("tile blobs");
 #undef PLAN_STAGE
+  free(T.hseen);
   free(T.tile_of); free(T.stamp); free(T.seeded); free(T.seedq); free(T.lq);
   free(T.order); free(T.tile_first);
   free(xadj); free(adj_face); free(adj_other); free(is_send);
