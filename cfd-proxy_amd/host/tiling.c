@@ -238,20 +238,8 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
      * from the whole inner side of the boundary sheet makes fronts collide everywhere and leaves
      * ragged tiles (mean halo 130 instead of 113 rows, maximum 187 instead of 122 -- enough to
      * push the kernels into the next LDS capacity class and down to 2 workgroups per CU) */
-    if (getenv("CFDP_TILER_SHELL_SEEDS")) { /* the old behaviour, for comparison */
-      memset(T.seeded, 0, (size_t)nown);
-      T.sq_head = T.sq_tail = 0;
-      for (int i = 0; i < T.norder; i++) {
-        int p = T.order[i];
-        for (int e = xadj[p]; e < xadj[p + 1]; e++) {
-          int q = adj_other[e];
-          if (q < nown && T.tile_of[q] < 0 && !T.seeded[q]) { T.seeded[q] = 1; T.seedq[T.sq_tail++] = q; }
-        }
-      }
-    } else {
-      memset(T.seeded, 0, (size_t)nown);
-      T.sq_head = T.sq_tail = 0;
-    }
+    memset(T.seeded, 0, (size_t)nown);
+    T.sq_head = T.sq_tail = 0;
     tiler_pass(&T, is_send, 0, o.tile_points);
   } else {
     tiler_pass(&T, NULL, 0, o.tile_points);

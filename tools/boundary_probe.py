@@ -17,15 +17,11 @@ for world in (1, 2, 8):
         reqs = [{int(k): (v[0], v[1]) for k, v in pkg.merge_requests(p).items()} for p in parts]
         mg.exchange_requests(parts[0], 0, world, None, all_requests=reqs)
         part = parts[0]
-    for tp_env in ("", "full"):
-        if tp_env == "full":
-            os.environ["CFDP_BOUNDARY_FULL"] = "1"
-        else:
-            os.environ.pop("CFDP_BOUNDARY_FULL", None)
+    if True:
         g = pkg.GpuPartition(part)
         g.set_fusion(True)
         g.run_iterations(50)
         ms = g.run_iterations(500) / 500
-        print("world", world, "boundary", tp_env or "half", "own", part.nown, "ghost", part.nall - part.nown, "partners", part.partners,
+        print("world", world, "own", part.nown, "ghost", part.nall - part.nown, "partners", part.partners,
               "tiles", g.stats["ntiles"], "boundary tiles", g.stats["nbtiles"], "iteration %.1f us" % (ms * 1e3), flush=True)
         g.close()
