@@ -631,21 +631,28 @@ int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, i
   ga->iter++;
   const bool fused = ga->will_fuse();  // see cfdp_gpu_step_pre
   if (!fused && flush_flux(ga)) return 1;
-  auto grad_tiles = [&](int which) { return fused ? launch_fused(ga, which, ga->s_main) : launch_grad(ga, which, ga->s_main); };
+  auto grad_tiles = [&](int which, hipStream_t st) { return fused ? launch_fused(ga, which, st) : launch_grad(ga, which, st); };
   if (!comm) {
-    if (grad_tiles(CFDP_TILES_ALL)) return 1;
+    if (grad_tiles(CFDP_TILES_ALL, ga->s_main)) return 1;
     if (fused) fused_done(ga);
     return 0;
   }
-  // the send arena is free again once last iteration's peer copies have drained
-  HIP_TRY(hipStreamWaitEvent(ga->s_main, ga->ev_senddone, 0));
-  if (grad_tiles(overlap ? CFDP_TILES_BOUNDARY : CFDP_TILES_ALL)) return 1;
-  HIP_TRY(gg_launch_pack(ga->d_sendidx, ga->send_off.back(), fused ? ga->alt_view() : ga->grad_view(),
-                         ga->d_sendbuf, ga->s_main));
-  HIP_TRY(hipEventRecord(ga->ev_pack, ga->s_main));
-  if (overlap && grad_tiles(CFDP_TILES_INTERIOR)) return 1;
+  const gg_grad_view src = fused ? ga->alt_view() : ga->grad_view();
+  // the comm stream starts after this rank's previous iteration (ev_fluxdone ends rank_flux); the
+  // send arena is free by then too (last iteration's copies are earlier on the same stream)
+  HIP_TRY(hipStreamWaitEvent(ga->s_comm, ga->ev_fluxdone, 0));
+  if (overlap) {  // boundary tiles + pack + copies on the comm stream, interior tiles beside them (cfdp_gpu_step_pre)
+    if (grad_tiles(CFDP_TILES_BOUNDARY, ga->s_comm)) return 1;
+    HIP_TRY(gg_launch_pack(ga->d_sendidx, ga->send_off.back(), src, ga->d_sendbuf, ga->s_comm));
+    if (grad_tiles(CFDP_TILES_INTERIOR, ga->s_main)) return 1;
+  } else {
+    if (grad_tiles(CFDP_TILES_ALL, ga->s_main)) return 1;
+    HIP_TRY(hipStreamWaitEvent(ga->s_main, ga->ev_senddone, 0));  // arena free (copies of the last iteration)
+    HIP_TRY(gg_launch_pack(ga->d_sendidx, ga->send_off.back(), src, ga->d_sendbuf, ga->s_main));
+    HIP_TRY(hipEventRecord(ga->ev_pack, ga->s_main));
+    HIP_TRY(hipStreamWaitEvent(ga->s_comm, ga->ev_pack, 0));
+  }
   if (fused) fused_done(ga);
-  HIP_TRY(hipStreamWaitEvent(ga->s_comm, ga->ev_pack, 0));
   for (size_t s = 0; s < ga->partner.size(); s++) {
     const int b = ga->partner[s];
     if (b < 0 || b >= G) return fail("partner rank %d outside the in-process group", b);
@@ -655,7 +662,7 @@ int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, i
       if (gb->partner[i] == a) slot = (int)i;
     if (slot < 0) return fail("rank %d sends to %d which does not list it as partner", a, b);
     size_t sbytes = 0, rbytes = 0;
-    void *src = cfdp_gpu_send_ptr(ga, (int)s, &sbytes);
+    void *from = cfdp_gpu_send_ptr(ga, (int)s, &sbytes);
     void *dst = cfdp_gpu_recv_ptr(gb, slot, &rbytes);
     // b's ghost block of THIS iteration: ranks of a group run their phases in lockstep, so b
     // has either done its phase 1 already (iter equal: its buffers are swapped) or will fuse
@@ -666,7 +673,7 @@ int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, i
     if (!sbytes) continue;
     // b's ghost rows may still be read by b's previous flux (write-after-read)
     HIP_TRY(hipStreamWaitEvent(ga->s_comm, gb->ev_fluxdone, 0));
-    HIP_TRY(hipMemcpyPeerAsync(dst, gb->device, src, ga->device, sbytes, ga->s_comm));
+    HIP_TRY(hipMemcpyPeerAsync(dst, gb->device, from, ga->device, sbytes, ga->s_comm));
   }
   HIP_TRY(hipEventRecord(ga->ev_senddone, ga->s_comm));
   return 0;
@@ -677,8 +684,10 @@ int cfdp_gpu_rank_flux(cfdp_gpu **ranks, int G, int b, int with_flux, int flux_m
   if (!ranks || G < 1 || b < 0 || b >= G) return fail("bad rank group");
   cfdp_gpu *gb = ranks[b];
   NEED_UPLOAD(gb);
-  if (gb->pending_exchange)
+  if (gb->pending_exchange) {
+    HIP_TRY(hipStreamWaitEvent(gb->s_main, gb->ev_senddone, 0));  // this rank's own comm stream (boundary tiles, copies)
     for (int a : gb->partner) HIP_TRY(hipStreamWaitEvent(gb->s_main, ranks[a]->ev_senddone, 0));
+  }
   gb->pending_exchange = false;
   if (with_flux) {
     if (flux_mode != CFDP_FLUX_CONSISTENT && flux_mode != CFDP_FLUX_REFERENCE) return fail("bad flux mode %d", flux_mode);
