@@ -557,3 +557,48 @@ def test_rccl_exchange_from_c_library_self_sendrecv(gpu, fusion):
         assert np.abs(sent).max() > 0 and not np.any(sent == -1.0)
         assert np.array_equal(got, sent), (steps, overlap)
     g.close()
+
+
+# ------------------------------------------------------------------ randomized sweep
+def test_randomized_partitions_match_the_unpartitioned_mesh(gpu, orc):
+    """seeded sweep over mesh shapes, domain counts, rank counts, tile sizes, fused / unfused,
+    overlapped / bulk: after a few iterations of G in-process ranks every owned AND ghost gradient row
+    and every owned flux row equals the un-partitioned mesh's (numpy statement)"""
+    pkg = gpu
+    from cfd_proxy_amd import multigpu as mg
+    rng = np.random.default_rng(20241)
+    for case in range(14):
+        dims = tuple(int(x) for x in rng.integers(5, 15, 3))
+        nd = int(rng.integers(1, 7))
+        G = int(rng.integers(1, nd + 1))
+        tp = int(rng.choice([16, 32, 64]))
+        fusion, overlap = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        iters = int(rng.integers(1, 5))
+        g1 = pkg.gen_params(*dims, ndomains=1)
+        whole = pkg.gen_domain(g1, 0)
+        pkg.fill_var(whole, None, pkg.VAR_HASH, *dims)
+        truth = orc.np_gradients(whole.fpoint, whole.fnormal, whole.pvolume, whole.var, whole.nown)
+        ftruth = orc.np_flux(whole.fpoint, whole.fnormal, truth, whole.nown, mode=0)
+        gp = pkg.gen_params(*dims, ndomains=nd)
+        parts = [mg.build_rank_partition(gp, nd, G, r, via_files=False)[0] for r in range(G)]
+        pkg.merge_link_group(parts)
+        gparts = [pkg.GpuPartition(p, tile_points=tp) for p in parts]
+        for gpart in gparts:
+            gpart.set_fusion(fusion)
+        for _ in range(iters):
+            pkg.group_iteration(gparts, with_exchange=True, overlap=overlap, with_flux=True)
+        pkg.group_sync(gparts)
+        tag = (case, dims, nd, G, tp, fusion, overlap, iters)
+        for r, (p, gpart) in enumerate(zip(parts, gparts)):
+            gpart.pull_fields()
+            ids = pkg.rank_domain_list(r, nd, G)
+            for dl, d in enumerate(ids):
+                dom = pkg.gen_domain(gp, d)
+                gid = pkg.gen_global_ids(gp, d, dom.nall)
+                back = pkg.merge_scatter(p, dl, dom.nall, p.grad)
+                assert np.abs(back - truth[gid]).max() <= 1e-12 * np.abs(truth).max(), tag
+                fb = pkg.merge_scatter(p, dl, dom.nall, p.psd_flux)
+                assert np.abs(fb[: dom.nown] - ftruth[gid[: dom.nown]]).max() <= 1e-12 * np.abs(ftruth).max(), tag
+                dom.free()
+            gpart.close()
+        whole.free()
