@@ -230,7 +230,7 @@ def main() -> None:
                         ftraffic = v["traffic_bytes"]
             except Exception:
                 ftraffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "gg_fused_dma_kernel", "achieved": (bg + bf) / (ms_fu * 1e-3) / 1e9,
+        out["roofline"] = {"bound": "hbm", "kernel": "gg_fused_split_kernel", "achieved": (bg + bf) / (ms_fu * 1e-3) / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (bg + bf) / (ms_fu * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "traffic": ftraffic, "algorithmic_bytes_per_launch": bg + bf, "us_per_launch": ms_fu * 1e3,
                            "gradient_kernel": grad_k, "flux_kernel": flux_k}

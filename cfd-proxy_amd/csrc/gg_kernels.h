@@ -40,9 +40,12 @@ hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_be
                           hipStream_t stream);
 // flux(i) read from a.grad + gradients(i+1) written to `gnew` in one pass over the tile blobs;
 // hipErrorNotSupported when the tile sizes fit no instantiated capacity
+// allow_split: the phase-split form (36 instead of 48 KiB of LDS per tile, 4 workgroups per CU) may
+// be used -- not while an RCCL kernel has to squeeze in beside the interior tiles: a retiring
+// workgroup then frees too little LDS for it (measured: 56 vs 52 us per overlapped iteration)
 hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refmode, int tile_begin,
                            int ntiles, int tile_points, int max_halo, int max_blob_qw, bool nt,
-                           hipStream_t stream);
+                           bool allow_split, hipStream_t stream);
 hipError_t gg_launch_pack(const int *send_idx, int nsend, const gg_grad_view &grad, double *sendbuf,
                           hipStream_t stream);
 hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view &grad,
@@ -54,6 +57,7 @@ hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row
 hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, hipStream_t stream);
 hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, hipStream_t stream);
 extern int gg_debug_flags;
+extern int gg_fused_split;
 hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux);
 
 #endif

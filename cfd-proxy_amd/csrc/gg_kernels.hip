@@ -768,6 +768,85 @@ __global__ __launch_bounds__(256) void gg_unpack_kernel(const double *__restrict
     ghost[i] = recvbuf[i];  // ghost rows are in message order (host/tiling.c)
 }
 
+// Phase-split form of the fused pass: ONE row region of LDS holds the gradient rows during the flux
+// phase and the var rows during the gradient phase (the var rows are gathered after the flux phase,
+// their row numbers were fetched at the start), so a tile occupies CB + KX pieces per thread instead
+// of CB + KV + KG: 36 KiB instead of 48 KiB for 64-point tiles = FOUR workgroups per CU.  The price is
+// a second, exposed gather round trip per tile.
+template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
+void gg_fused_split_kernel(
+    const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
+    const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
+    const double *__restrict__ gradA_old /*[nown][10]*/, const double *__restrict__ ghost_old /*[nghost][21]*/,
+    double *__restrict__ flux /*[nown][3]*/, int nown,
+    double *__restrict__ gradA_new /*[nown][10]*/, double *__restrict__ gradB_new /*[nown][11]*/, int dbg) {
+  static_assert(KX >= KV && KX >= KG, "the shared row region must hold either set of rows");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int LPP = 4;
+  const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
+  const cfdp_tile_desc td = tiles[t];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, w0 = tid & ~63;
+  const int *hid = halo_idx + td.halo_off;
+  const int hmax = td.nhalo > 0 ? td.nhalo - 1 : 0;
+  int hv[KV], hg[KG], part[KG], rloc[KG];
+#pragma unroll
+  for (int k = 0; k < KV; k++) {
+    int h = ((tid + k * nthr) >> 2) - td.npts;
+    h = h < 0 ? 0 : (h > hmax ? hmax : h);
+    hv[k] = ld_i32_nowait(hid + h);
+  }
+#pragma unroll
+  for (int k = 0; k < KG; k++) {
+    const int q = tid + k * nthr;
+    rloc[k] = q / 5;
+    part[k] = q - 5 * rloc[k];
+    int h = rloc[k] - td.npts;
+    h = h < 0 ? 0 : (h > hmax ? hmax : h);
+    hg[k] = ld_i32_nowait(hid + h);
+  }
+  const uint4 *b4 = blob + td.blob_off;
+  const int qmax = td.blob_qw - 1;
+#pragma unroll
+  for (int i = 0; i < CB; i++) {
+    const int q0 = w0 + i * nthr;
+    const int q = q0 + lane < qmax ? q0 + lane : qmax;
+    if constexpr (NT) glds16_nt(b4 + q, smem + (size_t)q0 * 16);
+    else glds16(b4 + q, smem + (size_t)q0 * 16);
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CB) : "memory");
+#pragma unroll
+  for (int k = 0; k < KV; k++) asm volatile("" : "+v"(hv[k]));
+#pragma unroll
+  for (int k = 0; k < KG; k++) asm volatile("" : "+v"(hg[k]));
+  unsigned char *xbuf = smem + (size_t)CB * nthr * 16;  // the shared row region
+  const unsigned char *abytes = reinterpret_cast<const unsigned char *>(gradA_old);
+  const unsigned char *hbytes = reinterpret_cast<const unsigned char *>(ghost_old);
+#pragma unroll
+  for (int k = 0; k < KG; k++) {
+    const int row = rloc[k] < td.npts ? td.pstart + rloc[k] : hg[k];
+    if (row < nown)
+      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * 80 + part[k] * 16), xbuf + (size_t)(w0 + k * nthr) * 16);
+    else
+      glds16_sys(reinterpret_cast<const uint4 *>(hbytes + (size_t)(row - nown) * 168 + part[k] * 16),
+                 xbuf + (size_t)(w0 + k * nthr) * 16);
+  }
+  __syncthreads();
+  flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
+  __syncthreads();  // every wave is done with the gradient rows: the region takes the var rows
+  const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
+#pragma unroll
+  for (int k = 0; k < KV; k++) {
+    const int q = tid + k * nthr, r = q >> 2;
+    const int row = r < td.npts ? td.pstart + r : hv[k];
+    glds16(gv4 + (size_t)row * 4 + (q & 3), xbuf + (size_t)(w0 + k * nthr) * 16);
+  }
+  __syncthreads();  // vmcnt(0) + barrier
+  grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
+                                   CB * nthr * 16);
+}
+
 // ------------------------------------------------------------- xGMI write + notify exchange
 // The analogue of the reference's best variant, gaspi_write_notify + gaspi_notify_waitsome
 // (src/exchange_data_gaspi.c:105-151,190-305), between processes on one node: the packing kernel
@@ -833,6 +912,7 @@ hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, hipStream_t stre
 }
 
 // ------------------------------------------------------------------------------ launchers
+int gg_fused_split = 1;  // fused pass: prefer the phase-split form (one shared row region, 4 workgroups per CU)
 int gg_debug_flags = 0;  // timing experiments only: 1 = skip arithmetic, 2 = skip tile streaming
 
 #define LAUNCH_GRAD(L, N)                                                                         \
@@ -994,7 +1074,7 @@ hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_be
 // capacity fits this launch -- the caller runs the two separate kernels instead.
 hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refmode, int tile_begin,
                            int ntiles, int tile_points, int max_halo, int max_blob_qw, bool nt,
-                           hipStream_t stream) {
+                           bool allow_split, hipStream_t stream) {
   if (ntiles <= 0) return hipSuccess;
   const int block = ((tile_points * 4 + 63) / 64) * 64;
   if (block > 1024 || (gg_debug_flags & 16)) return hipErrorNotSupported;
@@ -1002,6 +1082,17 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
   const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;
   const int kg = ((tile_points + max_halo) * 5 + block - 1) / block;
   if (cb < 1 || kv < 1 || kg < 1) return hipErrorNotSupported;
+  if (gg_fused_split && allow_split && cb <= 5 && kv <= 4 && kg <= 4) {
+    const size_t split_lds = (size_t)(5 + 4) * block * 16;
+#define LAUNCH_SPLIT(R, N)                                                                        \
+  hipLaunchKernelGGL((gg_fused_split_kernel<R, N, 5, 4, 4, 4>), dim3(ntiles), dim3(block), split_lds, stream, a.tiles, \
+                     tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, \
+                     gg_debug_flags)
+    if (refmode) { if (nt) LAUNCH_SPLIT(true, true); else LAUNCH_SPLIT(true, false); }
+    else { if (nt) LAUNCH_SPLIT(false, true); else LAUNCH_SPLIT(false, false); }
+#undef LAUNCH_SPLIT
+    return hipGetLastError();
+  }
 #define LAUNCH_FUSED_RN(R, N, CB, KV, KG)                                                         \
   hipLaunchKernelGGL((gg_fused_dma_kernel<R, N, CB, KV, KG>), dim3(ntiles), dim3(block), fused_lds, \
                      stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, \
@@ -1101,6 +1192,10 @@ hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
   SET_LDS((gg_fused_dma_kernel<false, true, CB, KV, KG>), all)   \
   SET_LDS((gg_fused_dma_kernel<true, false, CB, KV, KG>), all)   \
   SET_LDS((gg_fused_dma_kernel<true, true, CB, KV, KG>), all)
+  SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4>), all)
+  SET_LDS((gg_fused_split_kernel<false, true, 5, 4, 4, 4>), all)
+  SET_LDS((gg_fused_split_kernel<true, false, 5, 4, 4, 4>), all)
+  SET_LDS((gg_fused_split_kernel<true, true, 5, 4, 4, 4>), all)
   SET_LDS_FUSED(5, 3, 4)
   SET_LDS_FUSED(5, 4, 4)
   SET_LDS_FUSED(5, 4, 5)

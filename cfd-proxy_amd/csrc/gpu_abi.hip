@@ -57,6 +57,7 @@ struct cfdp_gpu {
   double *d_grad_alt = nullptr;
   bool own_grad_alt = true;
   int fusion = 0, flux_pending = -1;
+  bool beside_rccl = false;    // the tiles being launched share the device with an RCCL kernel
   // one process per GPU: this rank's RCCL communicator and the communicator rank of every partner
   ncclComm_t comm = nullptr;
   std::vector<int> peer;
@@ -164,8 +165,18 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
   g->device = device;
   if (const char *e = getenv("CFDP_PIPELINE")) g->pipeline = atoi(e);
   if (const char *e = getenv("CFDP_DEBUG_ABLATE")) gg_debug_flags = atoi(e);
+  if (const char *e = getenv("CFDP_FUSED_SPLIT")) gg_fused_split = atoi(e);
   HIP_TRY(hipStreamCreateWithFlags(&g->s_main, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&g->s_comm, hipStreamNonBlocking));
+  {
+    // the comm stream carries the latency chain of an iteration (boundary tiles -> pack/push ->
+    // exchange) while thousands of interior workgroups queue on the main stream: its kernels must
+    // get the slots that free up first
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const char *pe = getenv("CFDP_COMM_PRIORITY");
+    const int prio = pe ? atoi(pe) : hi;  // numerically lowest = highest priority
+    HIP_TRY(hipStreamCreateWithPriority(&g->s_comm, hipStreamNonBlocking, prio));
+  }
   HIP_TRY(hipEventCreate(&g->ev_a));
   HIP_TRY(hipEventCreate(&g->ev_b));
   HIP_TRY(hipEventCreateWithFlags(&g->ev_pack, hipEventDisableTiming));
@@ -479,7 +490,7 @@ static int launch_fused(cfdp_gpu *g, int which, hipStream_t st) {
   const int mode = g->flux_pending;
   const tile_range r = range_of(g, which);
   const hipError_t e = gg_launch_fused(a, gnew, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.max_halo, r.max_blob,
-                                       g->streaming, st);
+                                       g->streaming, !g->beside_rccl, st);
   if (e == hipErrorNotSupported) {
     if (launch_flux_tiles(g, mode, which, st)) return 1;
     if (launch_grad(g, which, st, &gnew)) return 1;
@@ -591,9 +602,13 @@ int cfdp_gpu_step_pre(cfdp_gpu *g, int with_exchange, int overlap) {
     // boundary tiles + pack (+ the caller's exchange) on the comm stream, interior tiles on the main
     // stream AT THE SAME TIME: the few hundred boundary tiles alone would leave most of the device
     // idle for the ~7 us a tile takes
-    if (grad_tiles(CFDP_TILES_BOUNDARY, g->s_comm)) return 1;
-    HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), src, g->d_sendbuf, g->s_comm));
-    if (grad_tiles(CFDP_TILES_INTERIOR, g->s_main)) return 1;
+    g->beside_rccl = g->comm != nullptr;
+    int rc = grad_tiles(CFDP_TILES_BOUNDARY, g->s_comm);
+    if (!rc && gg_launch_pack(g->d_sendidx, g->send_off.back(), src, g->d_sendbuf, g->s_comm) != hipSuccess)
+      rc = fail("pack launch failed");
+    if (!rc) rc = grad_tiles(CFDP_TILES_INTERIOR, g->s_main);
+    g->beside_rccl = false;
+    if (rc) return 1;
   } else {
     if (grad_tiles(CFDP_TILES_ALL, g->s_main)) return 1;
     HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), src, g->d_sendbuf, g->s_main));
