@@ -95,8 +95,9 @@ def main() -> None:
     dist = None
     if world > 1:
         import torch.distributed as dist
-        # RCCL needs one device per rank; ranks sharing a device (tests on a 1-GPU box) rendezvous over gloo
-        backend = "gloo" if args.transport == "staged" or ndev < world else "nccl"
+        # RCCL needs one device per rank; ranks told to share a device (CFDP_SHARED_GPU=1: tests on a
+        # 1-GPU box) rendezvous over gloo
+        backend = "gloo" if args.transport == "staged" or os.environ.get("CFDP_SHARED_GPU") == "1" else "nccl"
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 device_id=torch.device("cuda", device) if backend == "nccl" else None)
 
