@@ -57,8 +57,8 @@ def usable_cores() -> int:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=5000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--tile-points", type=int, default=0)
     ap.add_argument("--grad-lanes", type=int, default=0)
     ap.add_argument("--flux-lanes", type=int, default=0)

@@ -888,9 +888,14 @@ __global__ void gg_wait_kernel(int *__restrict__ hdr, int nslots, long max_polls
   const int need = hdr[GG_IPC_ITER];
   for (long k = 0; k < max_polls; k++) {
     if (__hip_atomic_load(&hdr[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= need) return;
-    __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_s_sleep(32);  // ~1 us between polls: the flag line is not hammered
   }
-  hdr[GG_IPC_ERR] = 1;  // bounded: a lost partner must not hang the device
+  // bounded: a lost partner must not hang the device.  Leave what was seen for the post-mortem.
+  hdr[GG_IPC_ERR] = 1;
+  hdr[GG_IPC_ERR + 1] = (int)threadIdx.x;
+  hdr[GG_IPC_ERR + 2] = need;
+  hdr[GG_IPC_ERR + 3] = __hip_atomic_load(&hdr[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+  atomicAdd(&hdr[GG_IPC_ERR + 4], 1);
 }
 
 hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row, const int *send_off,

@@ -40,7 +40,7 @@ struct cfdp_gpu {
   int device = 0;
   hipStream_t s_main = nullptr, s_comm = nullptr;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_pack = nullptr, ev_senddone = nullptr,
-             ev_fluxdone = nullptr;
+             ev_fluxdone = nullptr, ev_fork = nullptr;
   bool uploaded = false;
   int nown = 0, nall = 0, ntiles = 0, nbtiles = 0;
   int tp[2] = {0, 0};         // max owned points per tile: [0] boundary, [1] interior
@@ -182,6 +182,7 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
   HIP_TRY(hipEventCreateWithFlags(&g->ev_pack, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&g->ev_senddone, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&g->ev_fluxdone, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
   *out = g;
   return 0;
 }
@@ -211,7 +212,7 @@ void cfdp_gpu_destroy(cfdp_gpu *g) {
     if (g->s_main) (void)hipStreamDestroy(g->s_main);
     if (g->s_comm) (void)hipStreamDestroy(g->s_comm);
   }
-  for (hipEvent_t e : {g->ev_a, g->ev_b, g->ev_pack, g->ev_senddone, g->ev_fluxdone})
+  for (hipEvent_t e : {g->ev_a, g->ev_b, g->ev_pack, g->ev_senddone, g->ev_fluxdone, g->ev_fork})
     if (e) (void)hipEventDestroy(e);
   delete g;
 }
@@ -576,7 +577,7 @@ int cfdp_gpu_counts(const cfdp_gpu *g, int *nown, int *nall, int *nsend, int *nr
 // The caller owns the transport (e.g. RCCL send/recv enqueued on this context's comm stream
 // between the two calls); these two calls enqueue everything else of one iteration, so a
 // host pays two ABI calls + one communication call per step.
-//   pre : comm waits for the previous iteration (ev_fluxdone); [boundary tiles -> pack] on comm,
+//   pre : comm forks off main (ev_fork: after the previous iteration); [boundary tiles -> pack] on comm,
 //         interior tiles on main, concurrently (bulk: all tiles -> pack on main, comm waits ev_pack)
 //   post: main waits for everything enqueued on comm so far; flux; ev_fluxdone
 int cfdp_gpu_step_pre(cfdp_gpu *g, int with_exchange, int overlap) {
@@ -596,8 +597,10 @@ int cfdp_gpu_step_pre(cfdp_gpu *g, int with_exchange, int overlap) {
     return 0;
   }
   const gg_grad_view src = fused ? g->alt_view() : g->grad_view();  // where this iteration's gradients go
-  // the comm stream starts after everything of the previous iteration (ev_fluxdone ends step_post)
-  HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fluxdone, 0));
+  // the comm stream starts after everything enqueued on the main stream so far (the previous
+  // iteration, or whatever else the caller launched there)
+  HIP_TRY(hipEventRecord(g->ev_fork, g->s_main));
+  HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fork, 0));
   if (overlap) {
     // boundary tiles + pack (+ the caller's exchange) on the comm stream, interior tiles on the main
     // stream AT THE SAME TIME: the few hundred boundary tiles alone would leave most of the device
@@ -653,9 +656,10 @@ int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, i
     return 0;
   }
   const gg_grad_view src = fused ? ga->alt_view() : ga->grad_view();
-  // the comm stream starts after this rank's previous iteration (ev_fluxdone ends rank_flux); the
-  // send arena is free by then too (last iteration's copies are earlier on the same stream)
-  HIP_TRY(hipStreamWaitEvent(ga->s_comm, ga->ev_fluxdone, 0));
+  // the comm stream forks off the main stream here (after this rank's previous iteration); the send
+  // arena is free by then too (last iteration's copies are earlier on the comm stream)
+  HIP_TRY(hipEventRecord(ga->ev_fork, ga->s_main));
+  HIP_TRY(hipStreamWaitEvent(ga->s_comm, ga->ev_fork, 0));
   if (overlap) {  // boundary tiles + pack + copies on the comm stream, interior tiles beside them (cfdp_gpu_step_pre)
     if (grad_tiles(CFDP_TILES_BOUNDARY, ga->s_comm)) return 1;
     HIP_TRY(gg_launch_pack(ga->d_sendidx, ga->send_off.back(), src, ga->d_sendbuf, ga->s_comm));
@@ -824,41 +828,70 @@ int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode
     return fail("bad flux mode %d", flux_mode);
   if (flush_flux(g)) return 1;
   hipStream_t st = g->s_main;
-  const int chunk = 25;  // NITER of the reference harness (src/hybrid.f6.c:72)
   const bool fuse = g->fusion && g->d_grad_alt && with_flux;
-  auto enqueue = [&](int n) -> int { return enqueue_iterations(g, n, with_flux, flux_mode, st); };
-  if (use_graph) {
-    const bool stale = !g->graph || g->graph_flux != with_flux || g->graph_mode != flux_mode ||
-                       g->graph_gl != g->grad_lanes || g->graph_fl != g->flux_lanes ||
-                       g->graph_fuse != (int)fuse || g->graph_cur != g->d_grad;
-    if (stale) {
-      if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
-      hipGraph_t gr = nullptr;
-      const double *cur0 = g->d_grad;
-      HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      const int rc = enqueue(chunk);
-      hipError_t ec = hipStreamEndCapture(st, &gr);
-      if (rc) { if (gr) (void)hipGraphDestroy(gr); return 1; }
-      HIP_TRY(ec);
-      if (g->d_grad != cur0) { (void)hipGraphDestroy(gr); return fail("graph chunk must leave the grad buffers in place"); }
-      HIP_TRY(hipGraphInstantiate(&g->graph, gr, nullptr, nullptr, 0));
-      HIP_TRY(hipGraphDestroy(gr));
-      g->graph_iters = chunk; g->graph_flux = with_flux; g->graph_mode = flux_mode;
-      g->graph_gl = g->grad_lanes; g->graph_fl = g->flux_lanes;
-      g->graph_fuse = (int)fuse; g->graph_cur = g->d_grad;
-    }
-  }
+  // graph chunk: 25 iterations = NITER of the reference harness (src/hybrid.f6.c:72) for the two
+  // kernels per iteration; in fused mode 50 fused passes (flux(i) + gradients(i+1)) with a flux
+  // pending at entry and at exit, so that chunks chain without an un-fused seam -- the iterations
+  // are then: gradients(1), iters-1 fused passes, flux(iters).  Even counts leave the two grad
+  // buffers where they were.
+  const int chunk = fuse ? 50 : 25;
+  auto one_pass = [&]() -> int {  // fused mode, a flux pending
+    if (launch_fused(g, CFDP_TILES_ALL, st)) return 1;
+    fused_done(g);
+    g->flux_pending = flux_mode;
+    return 0;
+  };
+  auto capture = [&](auto &&body) -> int {  // 0 ok, 1 error
+    if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+    hipGraph_t gr = nullptr;
+    const double *cur0 = g->d_grad;
+    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = body();
+    hipError_t ec = hipStreamEndCapture(st, &gr);
+    if (rc) { if (gr) (void)hipGraphDestroy(gr); return 1; }
+    HIP_TRY(ec);
+    if (g->d_grad != cur0) { (void)hipGraphDestroy(gr); return fail("graph chunk must leave the grad buffers in place"); }
+    HIP_TRY(hipGraphInstantiate(&g->graph, gr, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphDestroy(gr));
+    g->graph_iters = chunk; g->graph_flux = with_flux; g->graph_mode = flux_mode;
+    g->graph_gl = g->grad_lanes; g->graph_fl = g->flux_lanes;
+    g->graph_fuse = (int)fuse; g->graph_cur = g->d_grad;
+    return 0;
+  };
+  auto stale = [&]() {
+    return !g->graph || g->graph_flux != with_flux || g->graph_mode != flux_mode || g->graph_gl != g->grad_lanes ||
+           g->graph_fl != g->flux_lanes || g->graph_fuse != (int)fuse || g->graph_cur != g->d_grad;
+  };
   HIP_TRY(hipEventRecord(g->ev_a, st));
   int done = 0;
-  while (done < iters) {
+  if (fuse) {
+    if (launch_grad(g, CFDP_TILES_ALL, st)) return 1;  // iteration 1's gradients; its flux rides with iteration 2
+    g->flux_pending = flux_mode;
+    done = 1;
     if (use_graph && iters - done >= chunk) {
-      HIP_TRY(hipGraphLaunch(g->graph, st));
-      done += chunk;
-    } else {
-      const int n = use_graph ? iters - done : (iters - done < chunk ? iters - done : chunk);
-      if (enqueue(n)) return 1;
-      done += n;
+      if (stale() && capture([&]() -> int {
+            for (int i = 0; i < chunk; i++)
+              if (one_pass()) return 1;
+            return 0;
+          }))
+        return 1;
+      while (iters - done >= chunk) {
+        HIP_TRY(hipGraphLaunch(g->graph, st));
+        done += chunk;
+      }
     }
+    for (; done < iters; done++)
+      if (one_pass()) return 1;
+    if (flush_flux(g, false, st)) return 1;  // flux of the last iteration
+  } else {
+    if (use_graph && iters >= chunk) {
+      if (stale() && capture([&]() -> int { return enqueue_iterations(g, chunk, with_flux, flux_mode, st); })) return 1;
+      while (iters - done >= chunk) {
+        HIP_TRY(hipGraphLaunch(g->graph, st));
+        done += chunk;
+      }
+    }
+    if (done < iters && enqueue_iterations(g, iters - done, with_flux, flux_mode, st)) return 1;
   }
   HIP_TRY(hipEventRecord(g->ev_b, st));
   HIP_TRY(hipEventSynchronize(g->ev_b));
@@ -1014,6 +1047,16 @@ int cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int overl
 // arenas.  A step needs no communication library and no host involvement beyond kernel launches,
 // so a run of steps is replayed from one hipGraph.
 namespace {
+// polls (~1 us each) before a device-side wait for a partner gives up: about 30 s by default
+long ipc_max_polls() {
+  static long n = 0;
+  if (!n) {
+    const char *e = getenv("CFDP_IPC_WAIT_SECONDS");
+    n = (long)((e && atof(e) > 0 ? atof(e) : 30.0) * 1e6);
+  }
+  return n;
+}
+
 void ipc_release(cfdp_gpu *g) {
   auto &I = g->ipc;
   if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
@@ -1044,7 +1087,8 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
     if (overlap) {
       // boundary tiles -> push -> notify on the comm stream, the interior tiles on the main stream at
       // the same time (see cfdp_gpu_step_pre); the wait joins them
-      HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fluxdone, 0));  // the previous iteration (recorded below)
+      HIP_TRY(hipEventRecord(g->ev_fork, g->s_main));  // the comm stream forks off the main stream here
+      HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fork, 0));
       if (grad_tiles(CFDP_TILES_BOUNDARY, g->s_comm)) return 1;
       HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_comm));
       HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, g->s_comm));
@@ -1058,7 +1102,7 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
     }
     if (fused) fused_done(g);
     I.xiter++;  // from here on the ghost block is the arena this exchange lands in
-    HIP_TRY(gg_launch_wait(g->ipc_hdr(), nslots, 20000000L, g->s_main));  // bounded: a few seconds
+    HIP_TRY(gg_launch_wait(g->ipc_hdr(), nslots, (long)ipc_max_polls(), g->s_main));  // bounded
   }
   return 0;
 }
@@ -1180,9 +1224,14 @@ int cfdp_gpu_ipc_disconnect(cfdp_gpu *g) {
 int cfdp_gpu_ipc_error(cfdp_gpu *g) {
   if (!g || !g->ipc.block) return 0;
   if (hipSetDevice(g->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
-  int e = 0;
-  if (hipMemcpy(&e, g->ipc_hdr() + GG_IPC_ERR, sizeof e, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return e != 0;
+  int h[64];
+  if (hipMemcpy(h, g->ipc_hdr(), sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  const int *e = h + GG_IPC_ERR;
+  if (getenv("CFDP_DEBUG_TRACE"))
+    fprintf(stderr, "[cfdp] ipc state: host xiter %ld, device iteration counter %d, arrival counter of slot 0: %d; "
+                    "%d waits gave up (last: slot %d, waiting for %d, saw %d)\n",
+            g->ipc.xiter, h[GG_IPC_ITER], h[0], e[4], e[1], e[2], e[3]);
+  return e[0] != 0;
 }
 
 // the part of an iteration before the flux (gradients, push, notify, wait); cfdp_gpu_step_post
@@ -1226,12 +1275,12 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       const long iter0 = g->iter, x0 = I.xiter;
       hipGraph_t gr = nullptr;
       HIP_TRY(hipStreamBeginCapture(g->s_main, hipStreamCaptureModeThreadLocal));
-      // the first captured step's comm stream waits for "the previous iteration": an in-capture record
-      int rc = hipEventRecord(g->ev_fluxdone, g->s_main) != hipSuccess;
+      int rc = 0;
       for (int i = 0; i < chunk && !rc; i++) rc = one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode);
       hipError_t ec = hipStreamEndCapture(g->s_main, &gr);
       (void)hipEventRecord(g->ev_fluxdone, g->s_main);  // events last recorded inside a capture may not
-      (void)hipEventRecord(g->ev_senddone, g->s_comm);  // be waited for outside it: re-arm them
+      (void)hipEventRecord(g->ev_fork, g->s_main);      // be waited for outside it: re-arm them
+      (void)hipEventRecord(g->ev_senddone, g->s_comm);
       const bool ok = !rc && ec == hipSuccess && gr && g->d_grad == cur0 && g->flux_pending == pend0;
       if (ok && hipGraphInstantiate(&I.graph, gr, nullptr, nullptr, 0) != hipSuccess) I.graph = nullptr;
       if (gr) (void)hipGraphDestroy(gr);
@@ -1248,6 +1297,10 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
     }
     while (use_graph && steps - done >= chunk) {
       HIP_TRY(hipGraphLaunch(I.graph, g->s_main));
+      // (a replay does not touch the event OBJECTS recorded inside the capture: anything ordered
+      // after "the previous iteration" must use a fresh record -- ev_fork at the start of a step,
+      // and this one for the in-process peers that wait for ev_fluxdone)
+      HIP_TRY(hipEventRecord(g->ev_fluxdone, g->s_main));
       g->iter += chunk;
       if (with_exchange && !g->partner.empty()) I.xiter += chunk;
       done += chunk;

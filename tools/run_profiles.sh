@@ -5,5 +5,5 @@ tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 500 --warmup 50 --no-cpu --no-finest > $R/gpurun_out/prof_${tag}_bench.json 2> $R/gpurun_out/prof_${tag}_bench.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 5000 --warmup 200 --no-cpu --no-finest > $R/gpurun_out/prof_${tag}_bench.json 2> $R/gpurun_out/prof_${tag}_bench.err || exit 1
 cd $R && python3 tools/measure_traffic.py $tag > gpurun_out/traffic_$tag.log 2>&1
