@@ -833,7 +833,8 @@ void gg_fused_split_kernel(
                  xbuf + (size_t)(w0 + k * nthr) * 16);
   }
   __syncthreads();
-  flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
+  if (!(dbg & 128))  // timing experiment: no flux phase
+    flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   __syncthreads();  // every wave is done with the gradient rows: the region takes the var rows
   const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
 #pragma unroll
