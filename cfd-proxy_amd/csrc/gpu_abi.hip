@@ -58,6 +58,10 @@ struct cfdp_gpu {
   bool own_grad_alt = true;
   int fusion = 0, flux_pending = -1;
   bool beside_rccl = false;    // the tiles being launched share the device with an RCCL kernel
+  // true while ev_fluxdone marks the END of everything enqueued on the main stream (set when it is
+  // recorded, cleared by every launch): the comm stream of the next step can then fork off that
+  // record instead of paying for another marker in the main queue (~5 us of device time each)
+  bool main_marked = false;
   // one process per GPU: this rank's RCCL communicator and the communicator rank of every partner
   ncclComm_t comm = nullptr;
   std::vector<int> peer;
@@ -315,7 +319,10 @@ static int flush_flux(cfdp_gpu *g, bool record = true, hipStream_t st = nullptr)
   const int mode = g->flux_pending;
   g->flux_pending = -1;
   if (launch_flux(g, mode, st ? st : g->s_main)) return 1;
-  if (record) HIP_TRY(hipEventRecord(g->ev_fluxdone, st ? st : g->s_main));
+  if (record) {
+    HIP_TRY(hipEventRecord(g->ev_fluxdone, st ? st : g->s_main));
+    g->main_marked = !st || st == g->s_main;
+  }
   return 0;
 }
 
@@ -447,6 +454,23 @@ static int pipe_for(const cfdp_gpu *g, int ntiles) {
 // ALL tiles go in ONE launch sized for the larger class -- a separate launch for the few hundred
 // boundary tiles of a rank costs ~15 us of mostly idle device per iteration (measured: 58 vs 43 us
 // for rank 0 of the 2- and 8-rank decompositions).
+// "the iteration is complete": record ev_fluxdone at the end of the main stream
+static int mark_main(cfdp_gpu *g) {
+  HIP_TRY(hipEventRecord(g->ev_fluxdone, g->s_main));
+  g->main_marked = true;
+  return 0;
+}
+// the comm stream starts after everything enqueued on the main stream so far
+static int fork_comm(cfdp_gpu *g) {
+  if (g->main_marked) {
+    HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fluxdone, 0));
+  } else {
+    HIP_TRY(hipEventRecord(g->ev_fork, g->s_main));
+    HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fork, 0));
+  }
+  return 0;
+}
+
 struct tile_range { int begin, n, tp, max_halo, max_blob; size_t lds_grad, lds_flux; };
 static tile_range range_of(const cfdp_gpu *g, int which) {
   auto cls = [&](int c) {
@@ -464,6 +488,7 @@ static tile_range range_of(const cfdp_gpu *g, int which) {
 }
 
 static int launch_grad(cfdp_gpu *g, int which, hipStream_t st, const gg_grad_view *into = nullptr) {
+  g->main_marked = false;
   gg_args a = g->args();
   if (into) a.grad = *into;
   const tile_range r = range_of(g, which);
@@ -473,6 +498,7 @@ static int launch_grad(cfdp_gpu *g, int which, hipStream_t st, const gg_grad_vie
 }
 
 static int launch_flux_tiles(cfdp_gpu *g, int mode, int which, hipStream_t st) {
+  g->main_marked = false;
   const gg_args a = g->args();
   const tile_range r = range_of(g, which);
   HIP_TRY(gg_launch_flux(a, g->flux_lanes, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.lds_flux, r.max_halo,
@@ -486,6 +512,7 @@ static int launch_flux(cfdp_gpu *g, int mode, hipStream_t st) { return launch_fl
 // in one pass; falls back to the two separate kernels when no fused capacity fits the tiles.
 // The caller swaps the buffers (fused_done) once every tile range of the iteration is enqueued.
 static int launch_fused(cfdp_gpu *g, int which, hipStream_t st) {
+  g->main_marked = false;
   const gg_args a = g->args();
   const gg_grad_view gnew = g->alt_view();
   const int mode = g->flux_pending;
@@ -599,8 +626,7 @@ int cfdp_gpu_step_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   const gg_grad_view src = fused ? g->alt_view() : g->grad_view();  // where this iteration's gradients go
   // the comm stream starts after everything enqueued on the main stream so far (the previous
   // iteration, or whatever else the caller launched there)
-  HIP_TRY(hipEventRecord(g->ev_fork, g->s_main));
-  HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fork, 0));
+  if (fork_comm(g)) return 1;
   if (overlap) {
     // boundary tiles + pack (+ the caller's exchange) on the comm stream, interior tiles on the main
     // stream AT THE SAME TIME: the few hundred boundary tiles alone would leave most of the device
@@ -634,8 +660,7 @@ int cfdp_gpu_step_post(cfdp_gpu *g, int with_flux, int flux_mode) {
     if (g->fusion && g->d_grad_alt) g->flux_pending = flux_mode;  // rides with the next gradients (or the next sync)
     else if (launch_flux(g, flux_mode, g->s_main)) return 1;
   }
-  HIP_TRY(hipEventRecord(g->ev_fluxdone, g->s_main));
-  return 0;
+  return mark_main(g);
 }
 
 // ----------------------------------------------------------------- in-process rank group
@@ -658,8 +683,7 @@ int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, i
   const gg_grad_view src = fused ? ga->alt_view() : ga->grad_view();
   // the comm stream forks off the main stream here (after this rank's previous iteration); the send
   // arena is free by then too (last iteration's copies are earlier on the comm stream)
-  HIP_TRY(hipEventRecord(ga->ev_fork, ga->s_main));
-  HIP_TRY(hipStreamWaitEvent(ga->s_comm, ga->ev_fork, 0));
+  if (fork_comm(ga)) return 1;
   if (overlap) {  // boundary tiles + pack + copies on the comm stream, interior tiles beside them (cfdp_gpu_step_pre)
     if (grad_tiles(CFDP_TILES_BOUNDARY, ga->s_comm)) return 1;
     HIP_TRY(gg_launch_pack(ga->d_sendidx, ga->send_off.back(), src, ga->d_sendbuf, ga->s_comm));
@@ -713,8 +737,7 @@ int cfdp_gpu_rank_flux(cfdp_gpu **ranks, int G, int b, int with_flux, int flux_m
     if (gb->fusion && gb->d_grad_alt) gb->flux_pending = flux_mode;
     else if (launch_flux(gb, flux_mode, gb->s_main)) return 1;
   }
-  HIP_TRY(hipEventRecord(gb->ev_fluxdone, gb->s_main));
-  return 0;
+  return mark_main(gb);
 }
 
 int cfdp_gpu_iteration_group(cfdp_gpu **ranks, int G, int with_exchange, int overlap, int with_flux,
@@ -807,6 +830,7 @@ int cfdp_gpu_time_fused(cfdp_gpu *g, int iters, int flux_mode, float *ms_fused) 
   HIP_TRY(ec);
   HIP_TRY(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
   HIP_TRY(hipGraphDestroy(gr));
+  g->main_marked = false;
   HIP_TRY(hipGraphLaunch(ge, st));
   HIP_TRY(hipEventRecord(g->ev_a, st));
   HIP_TRY(hipGraphLaunch(ge, st));
@@ -876,6 +900,7 @@ int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode
           }))
         return 1;
       while (iters - done >= chunk) {
+        g->main_marked = false;
         HIP_TRY(hipGraphLaunch(g->graph, st));
         done += chunk;
       }
@@ -887,6 +912,7 @@ int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode
     if (use_graph && iters >= chunk) {
       if (stale() && capture([&]() -> int { return enqueue_iterations(g, chunk, with_flux, flux_mode, st); })) return 1;
       while (iters - done >= chunk) {
+        g->main_marked = false;
         HIP_TRY(hipGraphLaunch(g->graph, st));
         done += chunk;
       }
@@ -1087,8 +1113,7 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
     if (overlap) {
       // boundary tiles -> push -> notify on the comm stream, the interior tiles on the main stream at
       // the same time (see cfdp_gpu_step_pre); the wait joins them
-      HIP_TRY(hipEventRecord(g->ev_fork, g->s_main));  // the comm stream forks off the main stream here
-      HIP_TRY(hipStreamWaitEvent(g->s_comm, g->ev_fork, 0));
+      if (fork_comm(g)) return 1;  // the comm stream forks off the main stream here
       if (grad_tiles(CFDP_TILES_BOUNDARY, g->s_comm)) return 1;
       HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_comm));
       HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, g->s_comm));
@@ -1102,6 +1127,7 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
     }
     if (fused) fused_done(g);
     I.xiter++;  // from here on the ghost block is the arena this exchange lands in
+    g->main_marked = false;
     HIP_TRY(gg_launch_wait(g->ipc_hdr(), nslots, (long)ipc_max_polls(), g->s_main));  // bounded
   }
   return 0;
@@ -1114,8 +1140,7 @@ int one_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int
     if (g->fusion && g->d_grad_alt) g->flux_pending = flux_mode;
     else if (launch_flux(g, flux_mode, g->s_main)) return 1;
   }
-  HIP_TRY(hipEventRecord(g->ev_fluxdone, g->s_main));  // the iteration is complete (as in cfdp_gpu_step_post)
-  return 0;
+  return mark_main(g);  // the iteration is complete (as in cfdp_gpu_step_post)
 }
 }  // namespace
 
@@ -1275,12 +1300,13 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       const long iter0 = g->iter, x0 = I.xiter;
       hipGraph_t gr = nullptr;
       HIP_TRY(hipStreamBeginCapture(g->s_main, hipStreamCaptureModeThreadLocal));
+      g->main_marked = false;  // the first captured step must fork off a record made INSIDE the capture
       int rc = 0;
       for (int i = 0; i < chunk && !rc; i++) rc = one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode);
       hipError_t ec = hipStreamEndCapture(g->s_main, &gr);
-      (void)hipEventRecord(g->ev_fluxdone, g->s_main);  // events last recorded inside a capture may not
-      (void)hipEventRecord(g->ev_fork, g->s_main);      // be waited for outside it: re-arm them
-      (void)hipEventRecord(g->ev_senddone, g->s_comm);
+      (void)hipEventRecord(g->ev_fork, g->s_main);      // events last recorded inside a capture may not
+      (void)hipEventRecord(g->ev_senddone, g->s_comm);  // be waited for outside it: re-arm them
+      (void)mark_main(g);
       const bool ok = !rc && ec == hipSuccess && gr && g->d_grad == cur0 && g->flux_pending == pend0;
       if (ok && hipGraphInstantiate(&I.graph, gr, nullptr, nullptr, 0) != hipSuccess) I.graph = nullptr;
       if (gr) (void)hipGraphDestroy(gr);
@@ -1297,10 +1323,10 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
     }
     while (use_graph && steps - done >= chunk) {
       HIP_TRY(hipGraphLaunch(I.graph, g->s_main));
-      // (a replay does not touch the event OBJECTS recorded inside the capture: anything ordered
-      // after "the previous iteration" must use a fresh record -- ev_fork at the start of a step,
-      // and this one for the in-process peers that wait for ev_fluxdone)
-      HIP_TRY(hipEventRecord(g->ev_fluxdone, g->s_main));
+      // (a replay does not touch the event OBJECTS recorded inside the capture: whatever is ordered
+      // after "the previous iteration" needs a fresh record)
+      g->main_marked = false;
+      if (mark_main(g)) return 1;
       g->iter += chunk;
       if (with_exchange && !g->partner.empty()) I.xiter += chunk;
       done += chunk;
@@ -1360,7 +1386,7 @@ int cfdp_gpu_vcycle(cfdp_gpu **levels, int nlevels, int sweeps, int cycles, int 
         }
   }
   auto run = [&]() -> int {
-    if (ge) { HIP_TRY(hipGraphLaunch(ge, st)); return 0; }
+    if (ge) { for (int l = 0; l < nlevels; l++) levels[l]->main_marked = false; HIP_TRY(hipGraphLaunch(ge, st)); return 0; }
     return one_cycle();
   };
   if (run()) return 1;  // warm
