@@ -253,6 +253,7 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_ipc_error.argtypes = [vp]
     lib.cfdp_gpu_step_ipc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_run_steps_ipc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.cfdp_gpu_time_schedule.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]
     lib.cfdp_gpu_vcycle.argtypes = [P(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]
     lib.cfdp_gpu_counts.argtypes = [vp, P(C.c_int), P(C.c_int), P(C.c_int), P(C.c_int)]
 
@@ -755,6 +756,11 @@ class GpuPartition:
                       flux_mode: int = FLUX_CONSISTENT, use_graph: bool = True) -> None:
         self._ck(self.lib.cfdp_gpu_run_steps_ipc(self.h, steps, int(with_exchange), int(overlap), int(with_flux),
                                                  flux_mode, int(use_graph)))
+
+    def time_schedule(self, steps: int, with_exchange: bool, overlap: bool, use_graph: bool) -> float:
+        ms = C.c_float()
+        self._ck(self.lib.cfdp_gpu_time_schedule(self.h, steps, int(with_exchange), int(overlap), int(use_graph), C.byref(ms)))
+        return ms.value
 
     def set_fusion(self, on: bool) -> None:
         """defer each iteration's flux into the pass that computes the next gradients"""

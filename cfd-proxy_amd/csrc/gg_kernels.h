@@ -20,6 +20,22 @@ struct gg_grad_view {
   }
 };
 
+// xGMI write + notify done by the tiles themselves (fused pass): per boundary tile t the entries
+// [tile_off[t], tile_off[t+1]) name its send rows -- ent = tile-local point | partner slot << 16,
+// ent_row = row in that partner's landing slice; dst[slot] = that slice (this iteration's parity).
+// `done` counts finished boundary tiles; the last one raises the iteration counter in every
+// partner's flag word.  tile_off == nullptr: no push.
+struct gg_push_args {
+  const int *tile_off;
+  const int *ent;
+  const int *ent_row;
+  double *const *dst;
+  int *hdr;
+  int *const *rflag;
+  int *done;
+  int nbtiles, nslots;
+};
+
 struct gg_args {
   const cfdp_tile_desc *tiles;  // device copies
   const uint4 *blob;
@@ -45,13 +61,15 @@ hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_be
 // workgroup then frees too little LDS for it (measured: 56 vs 52 us per overlapped iteration)
 hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refmode, int tile_begin,
                            int ntiles, int tile_points, int max_halo, int max_blob_qw, bool nt,
-                           bool allow_split, hipStream_t stream);
+                           bool allow_split, hipStream_t stream, const gg_push_args *push = nullptr);
+// would gg_launch_fused run a fused kernel (not hipErrorNotSupported) for these tile sizes?
+bool gg_fused_fits(int tile_points, int max_halo, int max_blob_qw);
 hipError_t gg_launch_pack(const int *send_idx, int nsend, const gg_grad_view &grad, double *sendbuf,
                           hipStream_t stream);
 hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view &grad,
                             hipStream_t stream);
 // xGMI write + notify exchange (see gg_kernels.hip): header words of a rank's IPC block
-enum { GG_IPC_MAXSLOTS = 48, GG_IPC_ITER = 48, GG_IPC_ERR = 49, GG_IPC_HDR_BYTES = 256 };
+enum { GG_IPC_MAXSLOTS = 48, GG_IPC_ITER = 48, GG_IPC_ERR = 49, GG_IPC_DONE = 56, GG_IPC_HDR_BYTES = 256 };
 hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row, const int *send_off,
                           const gg_grad_view &grad, double *const *dst, hipStream_t stream);
 hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, hipStream_t stream);

@@ -37,6 +37,7 @@
 // while the halo exchange still delivers whole 168-byte rows straight into the ghost block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "gg_kernels.h"
 
@@ -139,7 +140,8 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
                                                   int tid, double *__restrict__ gradA,
                                                   double *__restrict__ gradB,
                                                   double *__restrict__ stage, int dbg = 0,
-                                                  int var_off = -1) {
+                                                  int var_off = -1, const gg_push_args *pa = nullptr,
+                                                  int tile = 0) {
   constexpr int NE = grad_cfg<LPP>::NE;
   constexpr int PPW = 64 / LPP;  // points per wave
   const int li = tid / LPP, sub = tid % LPP;
@@ -177,6 +179,25 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     }
     if (k < ke) grad_batch<1, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
     tmp = 1.0 / var_l[li * 8 + 7];  // 1/pvolume, src/gradients.c:138
+  }
+  // xGMI write + notify, pushed from the tile itself: every send point of this tile goes straight
+  // from the registers into the partners' landing arenas (whole 168-byte rows, written by the LPP
+  // lanes of the point); the entries of a tile are few (its send points x ~1.2 partners)
+  if (pa && pa->tile_off) {
+    const int e0 = pa->tile_off[tile], e1 = pa->tile_off[tile + 1];  // uniform: scalar loads
+    for (int e = e0; e < e1; e++) {
+      const int w = pa->ent[e];
+      if (active && (w & 0xFFFF) == li && ke0 > ks) {
+        double *row = pa->dst[w >> 16] + (size_t)pa->ent_row[e] * 21 + eq0 * 3;
+#pragma unroll
+        for (int j = 0; j < NE; j++)
+          if (eq0 + j < 7) {
+            row[3 * j + 0] = acc[j][0] * tmp;
+            row[3 * j + 1] = acc[j][1] * tmp;
+            row[3 * j + 2] = acc[j][2] * tmp;
+          }
+      }
+    }
   }
   // SYNC: `stage` aliases a region of the tile image other waves may still be reading
   if constexpr (SYNC) __syncthreads();
@@ -236,6 +257,26 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
       else st_row<NT>(slab[SPP * 10 + c - na], &gb[c - na]);
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// After the pushes of a boundary tile: count it; the last one of the launch raises this rank's
+// iteration counter in every partner's flag word (gg_notify_kernel's job, done in place).  Every
+// thread has made its remote stores visible (system-scope fence) before the tile is counted.
+__device__ __forceinline__ void push_tile_done(const gg_push_args &pa, int tile, int tid) {
+  if (!pa.tile_off || tile >= pa.nbtiles) return;  // uniform per workgroup
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) {
+    const int old = atomicAdd(pa.done, 1);
+    if (old == pa.nbtiles - 1) {
+      __threadfence();
+      *pa.done = 0;  // nobody counts again before the next launch
+      const int it = pa.hdr[GG_IPC_ITER] + 1;
+      for (int s = 0; s < pa.nslots; s++)
+        __hip_atomic_store(pa.rflag[s], it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      pa.hdr[GG_IPC_ITER] = it;
+    }
   }
 }
 
@@ -677,7 +718,8 @@ void gg_fused_dma_kernel(
     const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
     const double *__restrict__ gradA_old /*[nown][10]*/, const double *__restrict__ ghost_old /*[nghost][21]*/,
     double *__restrict__ flux /*[nown][3]*/, int nown,
-    double *__restrict__ gradA_new /*[nown][10]*/, double *__restrict__ gradB_new /*[nown][11]*/, int dbg) {
+    double *__restrict__ gradA_new /*[nown][10]*/, double *__restrict__ gradB_new /*[nown][11]*/, int dbg,
+    gg_push_args pa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LPP = 4;
   const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
@@ -745,7 +787,8 @@ void gg_fused_dma_kernel(
     flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
   if (dbg & 512) return;  // timing experiment: no gradient phase
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(gbuf), dbg,
-                                   CB * nthr * 16);
+                                   CB * nthr * 16, &pa, t);
+  push_tile_done(pa, t, tid);
 }
 
 // --------------------------------------------------------------------------- pack/unpack
@@ -780,7 +823,8 @@ void gg_fused_split_kernel(
     const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
     const double *__restrict__ gradA_old /*[nown][10]*/, const double *__restrict__ ghost_old /*[nghost][21]*/,
     double *__restrict__ flux /*[nown][3]*/, int nown,
-    double *__restrict__ gradA_new /*[nown][10]*/, double *__restrict__ gradB_new /*[nown][11]*/, int dbg) {
+    double *__restrict__ gradA_new /*[nown][10]*/, double *__restrict__ gradB_new /*[nown][11]*/, int dbg,
+    gg_push_args pa) {
   static_assert(KX >= KV && KX >= KG, "the shared row region must hold either set of rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LPP = 4;
@@ -845,7 +889,8 @@ void gg_fused_split_kernel(
   }
   __syncthreads();  // vmcnt(0) + barrier
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
-                                   CB * nthr * 16);
+                                   CB * nthr * 16, &pa, t);
+  push_tile_done(pa, t, tid);
 }
 
 // ------------------------------------------------------------- xGMI write + notify exchange
@@ -1078,10 +1123,23 @@ hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_be
 
 // flux(i) from `a.grad`, gradients(i+1) into `gnew`.  hipErrorNotSupported: no instantiated
 // capacity fits this launch -- the caller runs the two separate kernels instead.
+bool gg_fused_fits(int tile_points, int max_halo, int max_blob_qw) {
+  const int block = ((tile_points * 4 + 63) / 64) * 64;
+  if (block > 1024 || (gg_debug_flags & 16)) return false;
+  const int cb = (max_blob_qw + block - 1) / block;
+  const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;
+  const int kg = ((tile_points + max_halo) * 5 + block - 1) / block;
+  return cb >= 1 && kv >= 1 && kg >= 1 && cb <= 8 && kv <= 6 && kg <= 8 &&
+         (size_t)(8 + 6 + 8) * block * 16 <= 160 * 1024;  // the largest instantiated capacity
+}
+
 hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refmode, int tile_begin,
                            int ntiles, int tile_points, int max_halo, int max_blob_qw, bool nt,
-                           bool allow_split, hipStream_t stream) {
+                           bool allow_split, hipStream_t stream, const gg_push_args *push) {
   if (ntiles <= 0) return hipSuccess;
+  gg_push_args pa;
+  memset(&pa, 0, sizeof pa);
+  if (push) pa = *push;
   const int block = ((tile_points * 4 + 63) / 64) * 64;
   if (block > 1024 || (gg_debug_flags & 16)) return hipErrorNotSupported;
   const int cb = (max_blob_qw + block - 1) / block;
@@ -1093,7 +1151,7 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
 #define LAUNCH_SPLIT(R, N)                                                                        \
   hipLaunchKernelGGL((gg_fused_split_kernel<R, N, 5, 4, 4, 4>), dim3(ntiles), dim3(block), split_lds, stream, a.tiles, \
                      tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, \
-                     gg_debug_flags)
+                     gg_debug_flags, pa)
     if (refmode) { if (nt) LAUNCH_SPLIT(true, true); else LAUNCH_SPLIT(true, false); }
     else { if (nt) LAUNCH_SPLIT(false, true); else LAUNCH_SPLIT(false, false); }
 #undef LAUNCH_SPLIT
@@ -1102,7 +1160,7 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
 #define LAUNCH_FUSED_RN(R, N, CB, KV, KG)                                                         \
   hipLaunchKernelGGL((gg_fused_dma_kernel<R, N, CB, KV, KG>), dim3(ntiles), dim3(block), fused_lds, \
                      stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, \
-                     a.flux, a.nown, gnew.a, gnew.b, gg_debug_flags)
+                     a.flux, a.nown, gnew.a, gnew.b, gg_debug_flags, pa)
 #define LAUNCH_FUSED(CB, KV, KG)                                                                  \
   do {                                                                                            \
     const size_t fused_lds = (size_t)((CB) + (KV) + (KG)) * block * 16;                           \

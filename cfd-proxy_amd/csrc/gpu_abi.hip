@@ -81,6 +81,8 @@ struct cfdp_gpu {
     double **d_dst[2] = {nullptr, nullptr};
     int **d_rflag = nullptr;
     int *d_slot_of_row = nullptr, *d_send_off = nullptr;
+    int *d_tile_off = nullptr, *d_ent = nullptr, *d_ent_row = nullptr;  // send rows per boundary tile
+    bool inkernel = false;   // the fused pass pushes and notifies by itself
     hipGraphExec_t graph = nullptr;
     int g_exch = -1, g_overlap = -1, g_flux = -1, g_mode = -1;
     const double *g_cur = nullptr;
@@ -90,7 +92,8 @@ struct cfdp_gpu {
   }
   int *ipc_hdr() const { return reinterpret_cast<int *>(ipc.block); }
   long iter = 0;               // phase-1 calls so far (in-process rank groups run in lockstep)
-  std::vector<int> new2old, partner, send_off, recv_off;
+  std::vector<int> new2old, partner, send_off, recv_off, send_idx_host;
+  std::vector<cfdp_tile_desc> h_tiles;
   std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
   int max_halo[2] = {0, 0}, max_blob[2] = {0, 0};  // per tile class: halo rows, blob 16-byte units
   bool streaming = false;      // per-iteration bytes exceed the Infinity Cache: non-temporal blobs/rows
@@ -243,6 +246,7 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
     return fail("tile needs %ld / %ld bytes of LDS (> 160 KiB): use a smaller tile_points",
                 p->lds_grad, p->lds_flux);
   g->new2old.assign(p->new2old, p->new2old + p->nall);
+  g->h_tiles.assign(p->tiles, p->tiles + p->ntiles);
   g->partner.assign(p->partner, p->partner + p->npartners);
   g->send_off.assign(1, 0);
   g->recv_off.assign(1, 0);
@@ -271,6 +275,7 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
     g->streaming = per_iter > 192.0 * 1024 * 1024;
     if (const char *e = getenv("CFDP_STREAMING")) g->streaming = atoi(e) != 0;
   }
+  g->send_idx_host.assign(p->send_idx, p->send_idx + nsend);
   if (nsend)
     HIP_TRY(hipMemcpy(g->d_sendidx, p->send_idx, sizeof(int) * nsend, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(g->d_var, 0, sizeof(double) * 8 * (size_t)p->nall));
@@ -511,14 +516,18 @@ static int launch_flux(cfdp_gpu *g, int mode, hipStream_t st) { return launch_fl
 // the deferred flux (from d_grad) + the next gradients (into d_grad_alt) over the selected tiles
 // in one pass; falls back to the two separate kernels when no fused capacity fits the tiles.
 // The caller swaps the buffers (fused_done) once every tile range of the iteration is enqueued.
-static int launch_fused(cfdp_gpu *g, int which, hipStream_t st) {
+// push != nullptr: the tiles push and notify themselves; returns 2 (nothing launched) if no fused
+// kernel fits these tiles, so that the caller can take the separate-kernel path
+static int launch_fused(cfdp_gpu *g, int which, hipStream_t st, const gg_push_args *push = nullptr) {
   g->main_marked = false;
   const gg_args a = g->args();
   const gg_grad_view gnew = g->alt_view();
   const int mode = g->flux_pending;
   const tile_range r = range_of(g, which);
+  if (push && !gg_fused_fits(r.tp, r.max_halo, r.max_blob)) return 2;
   const hipError_t e = gg_launch_fused(a, gnew, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.max_halo, r.max_blob,
-                                       g->streaming, !g->beside_rccl, st);
+                                       g->streaming, !g->beside_rccl, st, push);
+  if (e == hipErrorNotSupported && push) return 2;
   if (e == hipErrorNotSupported) {
     if (launch_flux_tiles(g, mode, which, st)) return 1;
     if (launch_grad(g, which, st, &gnew)) return 1;
@@ -1091,7 +1100,9 @@ void ipc_release(cfdp_gpu *g) {
   for (int par = 0; par < 2; par++) { (void)hipFree(I.d_dst[par]); I.d_dst[par] = nullptr; I.dst[par].clear(); }
   (void)hipFree(I.d_rflag); I.d_rflag = nullptr; I.rflag.clear();
   (void)hipFree(I.d_slot_of_row); (void)hipFree(I.d_send_off);
-  I.d_slot_of_row = I.d_send_off = nullptr;
+  (void)hipFree(I.d_tile_off); (void)hipFree(I.d_ent); (void)hipFree(I.d_ent_row);
+  I.d_slot_of_row = I.d_send_off = I.d_tile_off = I.d_ent = I.d_ent_row = nullptr;
+  I.inkernel = false;
   (void)hipFree(I.block); I.block = nullptr;
   I.on = false; I.xiter = 0;
 }
@@ -1110,7 +1121,22 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
     auto &I = g->ipc;
     const int nslots = (int)g->partner.size(), par = (int)((I.xiter + 1) & 1);
     const gg_grad_view src = fused ? g->alt_view() : g->grad_view();  // the buffer this iteration's gradients go to
-    if (overlap) {
+    int pushed = 0;
+    if (fused && I.inkernel) {
+      // ONE launch for all tiles: the boundary tiles (first in the grid) push their send rows to the
+      // partners straight from their registers, the last of them raises the flags; the partners'
+      // rows arrive while the interior tiles run.  (Both exchange schedules map to this one: a
+      // fork/join between two streams costs 8-18 us per iteration inside a hipGraph.)
+      gg_push_args pa;
+      pa.tile_off = I.d_tile_off; pa.ent = I.d_ent; pa.ent_row = I.d_ent_row; pa.dst = I.d_dst[par];
+      pa.hdr = g->ipc_hdr(); pa.rflag = I.d_rflag; pa.done = g->ipc_hdr() + GG_IPC_DONE;
+      pa.nbtiles = g->nbtiles; pa.nslots = nslots;
+      const int rc = launch_fused(g, CFDP_TILES_ALL, g->s_main, &pa);
+      if (rc == 1) return 1;
+      pushed = rc == 0;
+    }
+    if (pushed) {
+    } else if (overlap) {
       // boundary tiles -> push -> notify on the comm stream, the interior tiles on the main stream at
       // the same time (see cfdp_gpu_step_pre); the wait joins them
       if (fork_comm(g)) return 1;  // the comm stream forks off the main stream here
@@ -1211,6 +1237,41 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
   HIP_TRY(hipMemcpy(I.d_slot_of_row, slot_of_row.data(), sizeof(int) * slot_of_row.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&I.d_send_off, sizeof(int) * g->send_off.size()));
   HIP_TRY(hipMemcpy(I.d_send_off, g->send_off.data(), sizeof(int) * g->send_off.size(), hipMemcpyHostToDevice));
+  {  // the send rows of every boundary tile: (tile-local point | slot << 16, row in the partner's slice)
+    std::vector<int> tile_off((size_t)g->ntiles + 1, 0), ent(nsend ? nsend : 1, 0), ent_row(nsend ? nsend : 1, 0), tile_of(nsend ? nsend : 1, 0);
+    bool ok = nslots <= 0x7FFF;
+    for (size_t j = 0; j < nsend && ok; j++) {
+      const int p = g->send_idx_host[j];
+      int lo = 0, hi = g->nbtiles - 1, t = -1;  // boundary tiles hold the send points, sorted by pstart
+      while (lo <= hi) {
+        const int mid = (lo + hi) / 2;
+        if (p < g->h_tiles[mid].pstart) hi = mid - 1;
+        else if (p >= g->h_tiles[mid].pstart + g->h_tiles[mid].npts) lo = mid + 1;
+        else { t = mid; break; }
+      }
+      if (t < 0 || p - g->h_tiles[t].pstart > 0xFFFF) { ok = false; break; }
+      tile_of[j] = t;
+      tile_off[t + 1]++;
+    }
+    I.inkernel = false;
+    if (ok && nsend) {
+      for (int t = 0; t < g->ntiles; t++) tile_off[t + 1] += tile_off[t];
+      std::vector<int> fill(tile_off.begin(), tile_off.end() - 1);
+      for (size_t j = 0; j < nsend; j++) {
+        const int t = tile_of[j], s = slot_of_row[j], at = fill[t]++;
+        ent[at] = (g->send_idx_host[j] - g->h_tiles[t].pstart) | (s << 16);
+        ent_row[at] = (int)j - g->send_off[s];
+      }
+      HIP_TRY(hipMalloc(&I.d_tile_off, sizeof(int) * tile_off.size()));
+      HIP_TRY(hipMemcpy(I.d_tile_off, tile_off.data(), sizeof(int) * tile_off.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&I.d_ent, sizeof(int) * ent.size()));
+      HIP_TRY(hipMemcpy(I.d_ent, ent.data(), sizeof(int) * ent.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&I.d_ent_row, sizeof(int) * ent_row.size()));
+      HIP_TRY(hipMemcpy(I.d_ent_row, ent_row.data(), sizeof(int) * ent_row.size(), hipMemcpyHostToDevice));
+      const char *e = getenv("CFDP_IPC_INKERNEL");
+      I.inkernel = g->nbtiles > 0 && !(e && atoi(e) == 0);
+    }
+  }
   if (flush_flux(g)) return 1;
   HIP_TRY(hipDeviceSynchronize());
   // the ghost rows move into the landing arenas
@@ -1335,6 +1396,59 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
   for (; done < steps; done++)
     if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
   return 0;
+}
+
+// measurement: the schedule of an exchange step WITHOUT the exchange (brackets only: boundary tiles
+// + pack beside / before the interior tiles, fork and join), `steps` of them replayed from one
+// hipGraph or launched from the streams; average milliseconds per step.  What does the two-stream
+// schedule itself cost?
+int cfdp_gpu_time_schedule(cfdp_gpu *g, int steps, int with_exchange, int overlap, int use_graph, float *ms_step) {
+  NEED_UPLOAD(g);
+  if (steps < 2) return fail("steps must be >= 2");
+  steps += steps & 1;
+  if (flush_flux(g)) return 1;
+  auto one = [&]() -> int {
+    if (cfdp_gpu_step_pre(g, with_exchange, overlap)) return 1;
+    return cfdp_gpu_step_post(g, 1, CFDP_FLUX_CONSISTENT);
+  };
+  for (int i = 0; i < 4; i++)
+    if (one()) return 1;
+  hipGraphExec_t ge = nullptr;
+  if (use_graph) {
+    hipGraph_t gr = nullptr;
+    HIP_TRY(hipStreamBeginCapture(g->s_main, hipStreamCaptureModeThreadLocal));
+    g->main_marked = false;
+    int rc = 0;
+    for (int i = 0; i < steps && !rc; i++) rc = one();
+    hipError_t ec = hipStreamEndCapture(g->s_main, &gr);
+    (void)hipEventRecord(g->ev_fork, g->s_main);
+    (void)hipEventRecord(g->ev_pack, g->s_main);
+    (void)hipEventRecord(g->ev_senddone, g->s_comm);
+    (void)mark_main(g);
+    if (rc) { if (gr) (void)hipGraphDestroy(gr); return 1; }
+    HIP_TRY(ec);
+    HIP_TRY(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphDestroy(gr));
+    g->main_marked = false;
+    HIP_TRY(hipGraphLaunch(ge, g->s_main));
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipEventRecord(g->ev_a, g->s_main));
+  if (ge) {
+    g->main_marked = false;
+    HIP_TRY(hipGraphLaunch(ge, g->s_main));
+  } else {
+    for (int i = 0; i < steps; i++)
+      if (one()) return 1;
+  }
+  HIP_TRY(hipEventRecord(g->ev_b, g->s_main));
+  HIP_TRY(hipEventSynchronize(g->ev_b));
+  HIP_TRY(hipDeviceSynchronize());
+  if (ge) HIP_TRY(hipGraphExecDestroy(ge));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, g->ev_a, g->ev_b));
+  if (ms_step) *ms_step = ms / (float)steps;
+  return flush_flux(g);
 }
 
 // ------------------------------------------------------------------------ multigrid V cycle

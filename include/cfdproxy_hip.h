@@ -187,6 +187,9 @@ int  cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overl
 int  cfdp_gpu_time_kernels(cfdp_gpu *g, int iters, int flux_mode, float *ms_grad, float *ms_flux);
 /* average milliseconds of the fused pass (flux(i) + gradients(i+1), all tiles); fusion on  */
 int  cfdp_gpu_time_fused(cfdp_gpu *g, int iters, int flux_mode, float *ms_fused);
+/* the schedule of an exchange step without the exchange itself (the two brackets only), from one
+ * hipGraph or from the streams: average milliseconds per step                             */
+int  cfdp_gpu_time_schedule(cfdp_gpu *g, int steps, int with_exchange, int overlap, int use_graph, float *ms_step);
 /* K full iterations (gradients [+flux]) captured in one hipGraph and replayed            */
 int  cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode,
                              int use_graph, float *ms_total);
