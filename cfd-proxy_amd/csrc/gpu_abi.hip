@@ -94,6 +94,7 @@ struct cfdp_gpu {
   long iter = 0;               // phase-1 calls so far (in-process rank groups run in lockstep)
   std::vector<int> new2old, partner, send_off, recv_off, send_idx_host;
   std::vector<cfdp_tile_desc> h_tiles;
+  bool interior_reads_ghosts = false;  // some tile without send points has a ghost in its halo
   std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
   int max_halo[2] = {0, 0}, max_blob[2] = {0, 0};  // per tile class: halo rows, blob 16-byte units
   bool streaming = false;      // per-iteration bytes exceed the Infinity Cache: non-temporal blobs/rows
@@ -247,6 +248,10 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
                 p->lds_grad, p->lds_flux);
   g->new2old.assign(p->new2old, p->new2old + p->nall);
   g->h_tiles.assign(p->tiles, p->tiles + p->ntiles);
+  g->interior_reads_ghosts = false;
+  for (int t = p->nbtiles; t < p->ntiles && !g->interior_reads_ghosts; t++)
+    for (int h = 0; h < p->tiles[t].nhalo; h++)
+      if (p->halo_idx[p->tiles[t].halo_off + h] >= p->nown) { g->interior_reads_ghosts = true; break; }
   g->partner.assign(p->partner, p->partner + p->npartners);
   g->send_off.assign(1, 0);
   g->recv_off.assign(1, 0);
@@ -1177,6 +1182,10 @@ int cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes) {
   for (size_t s = 0; s < g->partner.size(); s++)  // the double-buffered arenas rely on traffic in both directions
     if (g->send_off[s + 1] == g->send_off[s] || g->recv_off[s + 1] == g->recv_off[s])
       return fail("partner %d is not a two-way partner", g->partner[s]);
+  // the two landing arenas are safe without credit messages because only tiles that hold send
+  // points read ghost rows, and those tiles are done before this rank's next push is announced
+  if (g->interior_reads_ghosts)
+    return fail("a tile without send points reads ghost rows (one-way halo): not supported by this exchange");
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handles are 64 bytes");
   ipc_release(g);
   auto &I = g->ipc;
