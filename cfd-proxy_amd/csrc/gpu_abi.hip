@@ -84,7 +84,7 @@ struct cfdp_gpu {
     int *d_tile_off = nullptr, *d_ent = nullptr, *d_ent_row = nullptr;  // send rows per boundary tile
     bool inkernel = false;   // the fused pass pushes and notifies by itself
     hipGraphExec_t graph = nullptr;
-    int g_exch = -1, g_overlap = -1, g_flux = -1, g_mode = -1;
+    int g_exch = -1, g_overlap = -1, g_flux = -1, g_mode = -1, g_xpar = -1;
     const double *g_cur = nullptr;
   } ipc;
   double *land(int parity) const {
@@ -1361,8 +1361,9 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
       done++;
     }
+    // (the arena the ghost rows are read from is baked into the kernels' arguments too)
     const bool stale = !I.graph || I.g_exch != with_exchange || I.g_overlap != overlap || I.g_flux != with_flux ||
-                       I.g_mode != flux_mode || I.g_cur != g->d_grad;
+                       I.g_mode != flux_mode || I.g_cur != g->d_grad || I.g_xpar != (int)(I.xiter & 1);
     if (stale) {
       if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
       const double *cur0 = g->d_grad;
@@ -1389,6 +1390,7 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
         use_graph = 0;
       } else {
         I.g_exch = with_exchange; I.g_overlap = overlap; I.g_flux = with_flux; I.g_mode = flux_mode; I.g_cur = g->d_grad;
+        I.g_xpar = (int)(I.xiter & 1);
       }
     }
     while (use_graph && steps - done >= chunk) {
