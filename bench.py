@@ -158,8 +158,8 @@ def main() -> None:
         "data": "synthetic (F6-like dualgrid stand-in; the f6/dualgrid.N files are not distributed)",
         "config": {
             "workload": {1: "dualgrid.12 lvl 2 stand-in (64^3, 12 domains merged on 1 GPU, no halo exchange)",
-                         8: "dualgrid.384 finest-level stand-in (128^3, 384 domains, 48 per GPU, RCCL halo exchange)"}.get(
-                world, f"{dims[0]}x{dims[1]}x{dims[2]} lattice, {ndom} domains, {ndom // world} per GPU, RCCL halo exchange"),
+                         8: "dualgrid.384 finest-level stand-in (128^3, 384 domains, 48 per GPU, halo exchange over xGMI)"}.get(
+                world, f"{dims[0]}x{dims[1]}x{dims[2]} lattice, {ndom} domains, {ndom // world} per GPU, halo exchange over xGMI"),
             "mesh_points": dims[0] * dims[1] * dims[2], "points_per_gpu": nown, "faces_per_gpu": nfaces_part,
             "ghost_points_per_gpu": nadd, "iteration": "gradients + halo exchange + pseudo flux",
             "fused_iterations": not args.no_fusion,
