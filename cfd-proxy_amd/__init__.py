@@ -251,6 +251,7 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_ipc_enable.argtypes = [vp, C.c_int]
     lib.cfdp_gpu_ipc_disconnect.argtypes = [vp]
     lib.cfdp_gpu_ipc_error.argtypes = [vp]
+    lib.cfdp_ipc_set_wait_seconds.argtypes = [C.c_double]
     lib.cfdp_gpu_step_ipc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_run_steps_ipc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_time_schedule.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]

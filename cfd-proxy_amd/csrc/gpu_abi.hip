@@ -1088,13 +1088,13 @@ int cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int overl
 // so a run of steps is replayed from one hipGraph.
 namespace {
 // polls (~1 us each) before a device-side wait for a partner gives up: about 30 s by default
+double g_ipc_wait_seconds = 0.0;
 long ipc_max_polls() {
-  static long n = 0;
-  if (!n) {
+  if (g_ipc_wait_seconds <= 0.0) {
     const char *e = getenv("CFDP_IPC_WAIT_SECONDS");
-    n = (long)((e && atof(e) > 0 ? atof(e) : 30.0) * 1e6);
+    g_ipc_wait_seconds = e && atof(e) > 0 ? atof(e) : 30.0;
   }
-  return n;
+  return (long)(g_ipc_wait_seconds * 1e6);
 }
 
 void ipc_release(cfdp_gpu *g) {
@@ -1304,6 +1304,14 @@ int cfdp_gpu_ipc_enable(cfdp_gpu *g, int on) {
   HIP_TRY(hipDeviceSynchronize());
   I.on = on != 0;
   if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  return 0;
+}
+
+// how long a device-side wait polls before it gives up (process-wide; also CFDP_IPC_WAIT_SECONDS).
+// Graphs captured earlier keep the bound they were captured with.
+int cfdp_ipc_set_wait_seconds(double seconds) {
+  if (!(seconds > 0.0)) return fail("the wait bound must be positive");
+  g_ipc_wait_seconds = seconds;
   return 0;
 }
 

@@ -281,6 +281,8 @@ class RankSolver:
         sidx = np.concatenate(sidx) if sidx else np.zeros(0, np.int32)
         good = True
         var0 = part.var.copy()
+        lib = self.gpu.lib
+        lib.cfdp_ipc_set_wait_seconds(2.0)  # a broken mapping must not cost half a minute per iteration here
         for scale in (1.0, 2.0, 1.0):
             part.var[:] = var0 * scale
             self.gpu._ck(self.gpu.lib.cfdp_gpu_set_var(self.gpu.h, part.sd.var))
@@ -292,6 +294,7 @@ class RankSolver:
             dist.all_reduce(t)
             sent, got, err = (float(x) for x in t)
             good = good and err == 0 and sent > 0 and abs(sent - got) <= 1e-9 * sent
+        lib.cfdp_ipc_set_wait_seconds(float(os.environ.get("CFDP_IPC_WAIT_SECONDS", "30")))
         return good
 
     def _init_own_communicator(self) -> None:
