@@ -931,6 +931,7 @@ __global__ void gg_notify_kernel(int *__restrict__ hdr, int *const *__restrict__
 
 __global__ void gg_wait_kernel(int *__restrict__ hdr, int nslots, long max_polls) {
   if ((int)threadIdx.x >= nslots) return;
+  if (hdr[GG_IPC_ERR]) return;  // a wait has given up before: the run is void anyway, do not stall every step
   const int need = hdr[GG_IPC_ITER];
   for (long k = 0; k < max_polls; k++) {
     if (__hip_atomic_load(&hdr[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= need) return;

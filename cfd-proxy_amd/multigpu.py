@@ -260,8 +260,17 @@ class RankSolver:
             dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=self._coll_device())
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             self.probe[name] = float(dt.item()) / steps * 1e6
+            if name == "ipc":  # a wait that gave up voids the transport (all ranks alike)
+                bad = torch.tensor([float(self.gpu.ipc_error() != 0)], dtype=torch.float64, device=self._coll_device())
+                dist.all_reduce(bad)
+                if float(bad.item()) > 0:
+                    del self.probe[name]
+                    self.available.remove(name)
+                    self.gpu.ipc_enable(False)
         if self.probe:
             self.use_transport(min(self.probe, key=self.probe.get))
+        elif self.transport not in self.available:
+            self.transport = "torch"  # nothing device-side is left: torch.distributed P2P ops
         return self.transport
 
     def _ipc_off(self) -> None:
