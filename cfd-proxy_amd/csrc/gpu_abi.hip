@@ -1351,7 +1351,7 @@ int cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux
   return one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode);
 }
 
-// `steps` iterations.  use_graph: after two lead-in steps, 10 steps at a time are replayed from a
+// `steps` iterations.  use_graph: after two lead-in steps, 50 steps at a time are replayed from a
 // hipGraph (both streams, the push / notify / wait kernels included; an even count restores the
 // parity of the landing arenas and of the two grad buffers).
 int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
@@ -1360,7 +1360,7 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
   if (!g->ipc.on) return fail("cfdp_gpu_ipc_ready() has not been called");
   if (steps < 1) return fail("steps must be >= 1");
   auto &I = g->ipc;
-  const int chunk = 10;
+  const int chunk = 50;  // steps per graph replay (2 kernels each with the in-kernel push)
   int done = 0;
   if (use_graph && steps >= chunk + 2) {
     for (; done < 2; done++)

@@ -251,7 +251,7 @@ class RankSolver:
         torch, dist = self.torch, self.dist
         for name in list(self.available):
             self.use_transport(name)
-            self.run_steps(20, with_exchange=True, overlap=True)
+            self.run_steps(56, with_exchange=True, overlap=True)  # warm: the step graph is captured here
             self.synchronize()
             dist.barrier()
             t = time.perf_counter()

@@ -66,19 +66,19 @@ def main():
                 solver.gpu.push_fields()
                 for _ in range(3):  # repeated: buffer reuse hazards, both grad buffers of the fused mode
                     solver.step(with_exchange=True, overlap=overlap, with_flux=True)
-                if args.transport == "ipc":  # batches: lead-in steps + hipGraph replays of 10 + remainder
-                    solver.run_steps(27, with_exchange=True, overlap=overlap)
-                    solver.run_steps(12, with_exchange=True, overlap=overlap)
+                if args.transport == "ipc":  # batches: lead-in steps + hipGraph replays of 50 + remainder
+                    solver.run_steps(107, with_exchange=True, overlap=overlap)
+                    solver.run_steps(52, with_exchange=True, overlap=overlap)
                     solver.run_steps(3, with_exchange=False, overlap=overlap)
                     assert solver.gpu.ipc_error() == 0
                     # a replayed graph has the landing arena baked in: capture one without exchange, flip the
                     # arena parity with ONE exchange step on doubled data, run without exchange again -- the
                     # flux must see the new ghost rows (everything is linear in var)
-                    solver.run_steps(13, with_exchange=False, overlap=overlap)
+                    solver.run_steps(53, with_exchange=False, overlap=overlap)
                     part.var[:] *= 2.0
                     solver.gpu._ck(solver.gpu.lib.cfdp_gpu_set_var(solver.gpu.h, part.sd.var))
                     solver.run_steps(1, with_exchange=True, overlap=overlap)
-                    solver.run_steps(13, with_exchange=False, overlap=overlap)
+                    solver.run_steps(53, with_exchange=False, overlap=overlap)
                     g2 = solver.grad_host().copy()
                     assert np.abs(g2 - 2.0 * truth[gid]).max() / np.abs(truth).max() <= 1e-12, (rank, fusion, overlap)
                     f2 = part.psd_flux[: part.nown]
