@@ -1164,14 +1164,23 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   return 0;
 }
 
+int ipc_post(cfdp_gpu *g, int with_flux, int flux_mode);
+
 int one_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {
   if (ipc_pre(g, with_exchange, overlap)) return 1;
+  return ipc_post(g, with_flux, flux_mode);
+}
+
+int ipc_post(cfdp_gpu *g, int with_flux, int flux_mode) {
   if (with_flux) {
     if (flux_mode != CFDP_FLUX_CONSISTENT && flux_mode != CFDP_FLUX_REFERENCE) return fail("bad flux mode %d", flux_mode);
     if (g->fusion && g->d_grad_alt) g->flux_pending = flux_mode;
     else if (launch_flux(g, flux_mode, g->s_main)) return 1;
   }
-  return mark_main(g);  // the iteration is complete (as in cfdp_gpu_step_post)
+  // no end-of-iteration marker here (each costs ~5 us on the device): a later step that needs to
+  // fork its comm stream records one itself (fork_comm), and the single-stream schedules need none
+  g->main_marked = false;
+  return 0;
 }
 }  // namespace
 
@@ -1337,8 +1346,14 @@ int cfdp_gpu_ipc_error(cfdp_gpu *g) {
   return e[0] != 0;
 }
 
-// the part of an iteration before the flux (gradients, push, notify, wait); cfdp_gpu_step_post
-// closes the iteration -- for hosts that call the two face loops separately
+// for hosts that call the two face loops separately: the part of an iteration before the flux
+// (gradients, push, notify, wait) and the flux part
+int cfdp_gpu_step_ipc_post(cfdp_gpu *g, int with_flux, int flux_mode) {
+  NEED_UPLOAD(g);
+  if (!g->ipc.on) return fail("cfdp_gpu_ipc_ready() has not been called");
+  return ipc_post(g, with_flux, flux_mode);
+}
+
 int cfdp_gpu_step_ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   NEED_UPLOAD(g);
   if (!g->ipc.on) return fail("cfdp_gpu_ipc_ready() has not been called");
@@ -1404,9 +1419,8 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
     while (use_graph && steps - done >= chunk) {
       HIP_TRY(hipGraphLaunch(I.graph, g->s_main));
       // (a replay does not touch the event OBJECTS recorded inside the capture: whatever is ordered
-      // after "the previous iteration" needs a fresh record)
+      // after "the previous iteration" later needs a fresh record -- fork_comm makes one)
       g->main_marked = false;
-      if (mark_main(g)) return 1;
       g->iter += chunk;
       if (with_exchange && !g->partner.empty()) I.xiter += chunk;
       done += chunk;

@@ -214,6 +214,10 @@ ASYNC(compute_gradients_gg_mpipscw_async)
 
 void compute_psd_flux(solver_data *sd) {
   cfdp_solver *sv = solver_of(sd);
+  if (sv->external == 2) {
+    GPU_OK(cfdp_gpu_step_ipc_post(sv->gpu, 1, sv->group->flux_mode));
+    return;
+  }
   if (sv->external) {
     GPU_OK(cfdp_gpu_step_post(sv->gpu, 1, sv->group->flux_mode));
     return;

@@ -178,7 +178,8 @@ int  cfdp_gpu_ipc_enable(cfdp_gpu *g, int on);   /* keep the mappings, use / do 
 int  cfdp_gpu_ipc_disconnect(cfdp_gpu *g);
 int  cfdp_gpu_ipc_error(cfdp_gpu *g);
 int  cfdp_ipc_set_wait_seconds(double seconds);   /* bound of the device-side waits (default 30 s) */
-int  cfdp_gpu_step_ipc_pre(cfdp_gpu *g, int with_exchange, int overlap); /* then cfdp_gpu_step_post */
+int  cfdp_gpu_step_ipc_pre(cfdp_gpu *g, int with_exchange, int overlap);  /* gradients + exchange ... */
+int  cfdp_gpu_step_ipc_post(cfdp_gpu *g, int with_flux, int flux_mode);    /* ... then the flux         */
 int  cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode);
 int  cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
                             int flux_mode, int use_graph);
