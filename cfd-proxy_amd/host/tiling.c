@@ -229,7 +229,9 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
   /* bound the halo so that own + halo rows fit the smallest staging capacity of the kernels:
    * (tile_points + halo) * 5 sixteen-byte pieces <= 4 * (4 lanes * tile_points) */
   T.hseen = cfdp_calloc((size_t)nall, sizeof(int));
-  T.halo_cap = o.tile_points * 2 < 96 ? 96 : o.tile_points * 2;  /* small tiles: only the scattered ones */
+  /* (a point adds at most 14 halo rows on these meshes and the check precedes the addition: the cap
+   * leaves room for that, 126 + 14 = 140 <= 2.2 * 64; small tiles: only the scattered ones) */
+  T.halo_cap = o.tile_points * 2 - 2 < 96 ? 96 : o.tile_points * 2 - 2;
   if (any_send && o.boundary_first) {
     int btp = o.tile_points / 2 < 8 ? 8 : o.tile_points / 2; /* sheets have big halos */
     tiler_pass(&T, is_send, 1, btp);
