@@ -51,6 +51,25 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {
   return x * base + (x < rem ? x : rem) + i;
 }
 
+// The same for a launch whose first nbt tiles are a rank's boundary tiles (smaller, and the ones
+// whose results the partners wait for): those are dealt round-robin over ALL XCDs, first in the
+// grid -- one round instead of three on a single XCD, and no XCD left with a chunk of half-size
+// tiles -- and each XCD owns a contiguous chunk of the remaining tiles.
+__device__ __forceinline__ int xcd_tile_bfirst(int b, int nb, int nbt) {
+  if (nbt <= 0) return xcd_tile(b, nb);
+  if (b < nbt) return b;
+  const int x = b & 7;
+  int start = 0, mine = 0;
+#pragma unroll
+  for (int y = 0; y < 8; y++) {
+    const int b0 = nbt + ((y - nbt) & 7);  // the first non-boundary block that lands on XCD y
+    const int cnt = b0 < nb ? (nb - b0 + 7) >> 3 : 0;
+    if (y < x) start += cnt;
+    if (y == x) mine = (b - b0) >> 3;
+  }
+  return nbt + start + mine;
+}
+
 // non-temporal 16-byte load: for data that is streamed exactly once per launch
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ld_nt(const uint4 *p) {
@@ -722,7 +741,7 @@ void gg_fused_dma_kernel(
     gg_push_args pa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LPP = 4;
-  const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
+  const int t = tile_begin + xcd_tile_bfirst(blockIdx.x, gridDim.x, pa.tile_off && tile_begin == 0 ? pa.nbtiles : 0);
   const cfdp_tile_desc td = tiles[t];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
@@ -828,7 +847,7 @@ void gg_fused_split_kernel(
   static_assert(KX >= KV && KX >= KG, "the shared row region must hold either set of rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LPP = 4;
-  const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
+  const int t = tile_begin + xcd_tile_bfirst(blockIdx.x, gridDim.x, pa.tile_off && tile_begin == 0 ? pa.nbtiles : 0);
   const cfdp_tile_desc td = tiles[t];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
