@@ -626,3 +626,57 @@ def test_full_size_fused_iterations_match_separate_kernels(gpu, n):
     assert np.array_equal(dom.psd_flux[: dom.nown], f0[: dom.nown])
     part.close()
     dom.free()
+
+
+# ------------------------------------------------------------------ BASELINE.json configs 3-5
+@pytest.mark.parametrize("label,n,nd,G", [
+    ("dualgrid.48 lvl 2 on 4 ranks", 64, 48, 4),
+    ("dualgrid.192 lvl 2 on 8 ranks", 64, 192, 8),
+    ("dualgrid.384 finest level on 8 ranks", 128, 384, 8),
+])
+def test_baseline_multi_rank_configs_match_whole_mesh_oracle(gpu, orc, label, n, nd, G):
+    """the partitioned configs BASELINE.json names, at their real domain and rank counts (stand-in
+    meshes of SURVEY 8d), all ranks in this process on one GPU: N/G domain files merged per rank,
+    fused iterations with the overlapped halo exchange.  Own rows AND delivered ghost rows against
+    the C oracle run on the un-partitioned mesh (1e-10, north_star); flux likewise."""
+    pkg = gpu
+    from cfd_proxy_amd import multigpu as mg
+    g1 = pkg.gen_params(n, ndomains=1)
+    whole = pkg.gen_domain(g1, 0)
+    pkg.fill_var(whole, None, pkg.VAR_HASH, n, n, n)
+    ref = orc.CpuRef(whole.fpoint, whole.fnormal, whole.pvolume, whole.nown, nthreads=8)
+    truth = ref.gradients(whole.var)
+    ftruth = ref.flux(truth, mode=0)
+    ref.close()
+    gscale, fscale = np.abs(truth).max(), np.abs(ftruth[: whole.nown]).max()
+
+    gp = pkg.gen_params(n, ndomains=nd)
+    parts, gids = [], []
+    for r in range(G):
+        part, st = mg.build_rank_partition(gp, nd, G, r, via_files=False)
+        assert st["domains"] == nd // G
+        gid = np.full(part.nall, -1, np.int64)
+        mi = part.merge_info.contents
+        for dl, d in enumerate(pkg.rank_domain_list(r, nd, G)):
+            dom = pkg.gen_domain(gp, d)
+            l2m = np.ctypeslib.as_array(mi.local2merged[dl], shape=(dom.nall,))
+            gid[l2m] = pkg.gen_global_ids(gp, d, dom.nall)
+            dom.free()
+        assert (gid >= 0).all() and np.array_equal(part.var, whole.var[gid])
+        parts.append(part)
+        gids.append(gid)
+    assert sum(p.nown for p in parts) == whole.nown
+    pkg.merge_link_group(parts)
+    gparts = [pkg.GpuPartition(p) for p in parts]
+    for gpart in gparts:
+        gpart.set_fusion(True)
+    for _ in range(3):
+        pkg.group_iteration(gparts, with_exchange=True, overlap=True, with_flux=True)
+    pkg.group_sync(gparts)
+    for r, (p, gpart, gid) in enumerate(zip(parts, gparts, gids)):
+        gpart.pull_fields()
+        assert p.nall > p.nown, label
+        assert np.abs(p.grad - truth[gid]).max() <= TOL * gscale, (label, r)
+        assert np.abs(p.psd_flux[: p.nown] - ftruth[gid[: p.nown]]).max() <= TOL * fscale, (label, r)
+        gpart.close()
+    whole.free()
