@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void gg_unpack_kernel(const double *__restrict
 // their row numbers were fetched at the start), so a tile occupies CB + KX pieces per thread instead
 // of CB + KV + KG: 36 KiB instead of 48 KiB for 64-point tiles = FOUR workgroups per CU.  The price is
 // a second, exposed gather round trip per tile.
-template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX>
+template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, bool EARLY = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
@@ -895,16 +895,33 @@ void gg_fused_split_kernel(
       glds16_sys(reinterpret_cast<const uint4 *>(hbytes + (size_t)(row - nown) * 168 + part[k] * 16),
                  xbuf + (size_t)(w0 + k * nthr) * 16);
   }
+  // the var rows travel with the gradient rows, into registers (4 VGPRs per piece): they wait out the
+  // flux phase there and drop into the row region behind it, so the second gather costs no round trip
+  const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 vr[KV];
+  if constexpr (EARLY) {
+#pragma unroll
+    for (int k = 0; k < KV; k++) {
+      const int q = tid + k * nthr, r = q >> 2;
+      const int row = r < td.npts ? td.pstart + r : hv[k];
+      vr[k] = *reinterpret_cast<const u32x4 *>(gv4 + (size_t)row * 4 + (q & 3));
+    }
+  }
   __syncthreads();
   if (!(dbg & 128))  // timing experiment: no flux phase
     flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   __syncthreads();  // every wave is done with the gradient rows: the region takes the var rows
-  const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
+  if constexpr (EARLY) {
 #pragma unroll
-  for (int k = 0; k < KV; k++) {
-    const int q = tid + k * nthr, r = q >> 2;
-    const int row = r < td.npts ? td.pstart + r : hv[k];
-    glds16(gv4 + (size_t)row * 4 + (q & 3), xbuf + (size_t)(w0 + k * nthr) * 16);
+    for (int k = 0; k < KV; k++) *reinterpret_cast<u32x4 *>(xbuf + (size_t)(tid + k * nthr) * 16) = vr[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < KV; k++) {
+      const int q = tid + k * nthr, r = q >> 2;
+      const int row = r < td.npts ? td.pstart + r : hv[k];
+      glds16(gv4 + (size_t)row * 4 + (q & 3), xbuf + (size_t)(w0 + k * nthr) * 16);
+    }
   }
   __syncthreads();  // vmcnt(0) + barrier
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
@@ -1172,6 +1189,12 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
   hipLaunchKernelGGL((gg_fused_split_kernel<R, N, 5, 4, 4, 4>), dim3(ntiles), dim3(block), split_lds, stream, a.tiles, \
                      tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, \
                      gg_debug_flags, pa)
+    if (gg_debug_flags & 1024) {  // timing experiment: the var rows gathered after the flux phase
+      hipLaunchKernelGGL((gg_fused_split_kernel<false, false, 5, 4, 4, 4, false>), dim3(ntiles), dim3(block), split_lds,
+                         stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown,
+                         gnew.a, gnew.b, gg_debug_flags, pa);
+      return hipGetLastError();
+    }
     if (refmode) { if (nt) LAUNCH_SPLIT(true, true); else LAUNCH_SPLIT(true, false); }
     else { if (nt) LAUNCH_SPLIT(false, true); else LAUNCH_SPLIT(false, false); }
 #undef LAUNCH_SPLIT
@@ -1277,6 +1300,7 @@ hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
   SET_LDS((gg_fused_dma_kernel<true, false, CB, KV, KG>), all)   \
   SET_LDS((gg_fused_dma_kernel<true, true, CB, KV, KG>), all)
   SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4>), all)
+  SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4, false>), all)
   SET_LDS((gg_fused_split_kernel<false, true, 5, 4, 4, 4>), all)
   SET_LDS((gg_fused_split_kernel<true, false, 5, 4, 4, 4>), all)
   SET_LDS((gg_fused_split_kernel<true, true, 5, 4, 4, 4>), all)
