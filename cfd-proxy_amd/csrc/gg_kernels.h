@@ -40,6 +40,10 @@ struct gg_args {
   const cfdp_tile_desc *tiles;  // device copies
   const uint4 *blob;
   const int *halo_idx;
+  // optional (nullptr = absent): the rows a tile stages (own rows, then halo rows, then padding that
+  // repeats the last one), GG_ROW_STRIDE entries per tile -- a list whose address needs nothing but
+  // the tile number, so the gathers of the fused pass do not wait for the tile descriptor first
+  const int *rowlist;
   const double *var;            // [nall][8]: 7 variables + the dual volume in slot 7
   gg_grad_view grad;
   double *flux;                 // [nown][3]
@@ -69,6 +73,7 @@ hipError_t gg_launch_pack(const int *send_idx, int nsend, const gg_grad_view &gr
 hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view &grad,
                             hipStream_t stream);
 // xGMI write + notify exchange (see gg_kernels.hip): header words of a rank's IPC block
+enum { GG_ROW_STRIDE = 208 };  // >= 1024 / 5 + 1 rows: every piece index of the 256-thread fused pass
 enum { GG_IPC_MAXSLOTS = 48, GG_IPC_ITER = 48, GG_IPC_ERR = 49, GG_IPC_DONE = 56, GG_IPC_HDR_BYTES = 256 };
 hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row, const int *send_off,
                           const gg_grad_view &grad, double *const *dst, hipStream_t stream);

@@ -839,7 +839,7 @@ template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, bool EARLY = tr
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
-    const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
+    const int *__restrict__ halo_idx, const int *__restrict__ rowlist, const double *__restrict__ var /*[nall][8]*/,
     const double *__restrict__ gradA_old /*[nown][10]*/, const double *__restrict__ ghost_old /*[nghost][21]*/,
     double *__restrict__ flux /*[nown][3]*/, int nown,
     double *__restrict__ gradA_new /*[nown][10]*/, double *__restrict__ gradB_new /*[nown][11]*/, int dbg,
@@ -848,26 +848,46 @@ void gg_fused_split_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LPP = 4;
   const int t = tile_begin + xcd_tile_bfirst(blockIdx.x, gridDim.x, pa.tile_off && tile_begin == 0 ? pa.nbtiles : 0);
-  const cfdp_tile_desc td = tiles[t];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
+  int hv[KV], hg[KG], part[KG], rloc[KG];
+  // with a fixed-stride row list the row numbers are requested before the descriptor is even here:
+  // descriptor -> blob and row list -> rows are two chains of two round trips instead of one of three
+  const bool listed = rowlist != nullptr;
+  if (listed) {
+    const int *rl = rowlist + (size_t)t * GG_ROW_STRIDE;
+#pragma unroll
+    for (int k = 0; k < KV; k++) {
+      const int r = (tid + k * nthr) >> 2;
+      hv[k] = ld_i32_nowait(rl + (r < GG_ROW_STRIDE - 1 ? r : GG_ROW_STRIDE - 1));
+    }
+#pragma unroll
+    for (int k = 0; k < KG; k++) {
+      const int q = tid + k * nthr;
+      rloc[k] = q / 5;
+      part[k] = q - 5 * rloc[k];
+      hg[k] = ld_i32_nowait(rl + (rloc[k] < GG_ROW_STRIDE - 1 ? rloc[k] : GG_ROW_STRIDE - 1));
+    }
+  }
+  const cfdp_tile_desc td = tiles[t];
   const int *hid = halo_idx + td.halo_off;
   const int hmax = td.nhalo > 0 ? td.nhalo - 1 : 0;
-  int hv[KV], hg[KG], part[KG], rloc[KG];
+  if (!listed) {
 #pragma unroll
-  for (int k = 0; k < KV; k++) {
-    int h = ((tid + k * nthr) >> 2) - td.npts;
-    h = h < 0 ? 0 : (h > hmax ? hmax : h);
-    hv[k] = ld_i32_nowait(hid + h);
-  }
+    for (int k = 0; k < KV; k++) {
+      int h = ((tid + k * nthr) >> 2) - td.npts;
+      h = h < 0 ? 0 : (h > hmax ? hmax : h);
+      hv[k] = ld_i32_nowait(hid + h);
+    }
 #pragma unroll
-  for (int k = 0; k < KG; k++) {
-    const int q = tid + k * nthr;
-    rloc[k] = q / 5;
-    part[k] = q - 5 * rloc[k];
-    int h = rloc[k] - td.npts;
-    h = h < 0 ? 0 : (h > hmax ? hmax : h);
-    hg[k] = ld_i32_nowait(hid + h);
+    for (int k = 0; k < KG; k++) {
+      const int q = tid + k * nthr;
+      rloc[k] = q / 5;
+      part[k] = q - 5 * rloc[k];
+      int h = rloc[k] - td.npts;
+      h = h < 0 ? 0 : (h > hmax ? hmax : h);
+      hg[k] = ld_i32_nowait(hid + h);
+    }
   }
   const uint4 *b4 = blob + td.blob_off;
   const int qmax = td.blob_qw - 1;
@@ -888,7 +908,7 @@ void gg_fused_split_kernel(
   const unsigned char *hbytes = reinterpret_cast<const unsigned char *>(ghost_old);
 #pragma unroll
   for (int k = 0; k < KG; k++) {
-    const int row = rloc[k] < td.npts ? td.pstart + rloc[k] : hg[k];
+    const int row = !listed && rloc[k] < td.npts ? td.pstart + rloc[k] : hg[k];
     if (row < nown)
       glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * 80 + part[k] * 16), xbuf + (size_t)(w0 + k * nthr) * 16);
     else
@@ -904,7 +924,7 @@ void gg_fused_split_kernel(
 #pragma unroll
     for (int k = 0; k < KV; k++) {
       const int q = tid + k * nthr, r = q >> 2;
-      const int row = r < td.npts ? td.pstart + r : hv[k];
+      const int row = !listed && r < td.npts ? td.pstart + r : hv[k];
       vr[k] = *reinterpret_cast<const u32x4 *>(gv4 + (size_t)row * 4 + (q & 3));
     }
   }
@@ -919,7 +939,7 @@ void gg_fused_split_kernel(
 #pragma unroll
     for (int k = 0; k < KV; k++) {
       const int q = tid + k * nthr, r = q >> 2;
-      const int row = r < td.npts ? td.pstart + r : hv[k];
+      const int row = !listed && r < td.npts ? td.pstart + r : hv[k];
       glds16(gv4 + (size_t)row * 4 + (q & 3), xbuf + (size_t)(w0 + k * nthr) * 16);
     }
   }
@@ -1187,11 +1207,11 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
     const size_t split_lds = (size_t)(5 + 4) * block * 16;
 #define LAUNCH_SPLIT(R, N)                                                                        \
   hipLaunchKernelGGL((gg_fused_split_kernel<R, N, 5, 4, 4, 4>), dim3(ntiles), dim3(block), split_lds, stream, a.tiles, \
-                     tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, \
+                     tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, \
                      gg_debug_flags, pa)
     if (gg_debug_flags & 1024) {  // timing experiment: the var rows gathered after the flux phase
       hipLaunchKernelGGL((gg_fused_split_kernel<false, false, 5, 4, 4, 4, false>), dim3(ntiles), dim3(block), split_lds,
-                         stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown,
+                         stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown,
                          gnew.a, gnew.b, gg_debug_flags, pa);
       return hipGetLastError();
     }

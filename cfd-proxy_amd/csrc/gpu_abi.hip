@@ -48,6 +48,7 @@ struct cfdp_gpu {
   cfdp_tile_desc *d_tiles = nullptr;
   uint4 *d_blob = nullptr;
   int *d_halo = nullptr, *d_sendidx = nullptr;
+  int *d_rowlist = nullptr;     // fixed-stride row lists of the fused pass (gg_args::rowlist), or null
   double *d_var = nullptr, *d_grad = nullptr, *d_flux = nullptr,
          *d_sendbuf = nullptr;
   bool own_grad = true, own_sendbuf = true;
@@ -142,7 +143,7 @@ struct cfdp_gpu {
   }
   gg_args args() const {
     gg_args a;
-    a.tiles = d_tiles; a.blob = d_blob; a.halo_idx = d_halo; a.var = d_var;
+    a.tiles = d_tiles; a.blob = d_blob; a.halo_idx = d_halo; a.rowlist = d_rowlist; a.var = d_var;
     a.grad = grad_view(); a.flux = d_flux; a.nown = nown;
     return a;
   }
@@ -197,13 +198,13 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
 
 static void free_device(cfdp_gpu *g) {
   if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
-  (void)hipFree(g->d_tiles); (void)hipFree(g->d_blob); (void)hipFree(g->d_halo); (void)hipFree(g->d_sendidx);
+  (void)hipFree(g->d_tiles); (void)hipFree(g->d_blob); (void)hipFree(g->d_halo); (void)hipFree(g->d_sendidx); (void)hipFree(g->d_rowlist);
   (void)hipFree(g->d_var); (void)hipFree(g->d_flux);
   if (g->own_grad) (void)hipFree(g->d_grad);
   if (g->own_grad_alt) (void)hipFree(g->d_grad_alt);
   if (g->own_sendbuf) (void)hipFree(g->d_sendbuf);
   g->d_grad_alt = nullptr; g->own_grad_alt = true; g->flux_pending = -1; g->iter = 0;
-  g->d_tiles = nullptr; g->d_blob = nullptr; g->d_halo = g->d_sendidx = nullptr;
+  g->d_tiles = nullptr; g->d_blob = nullptr; g->d_halo = g->d_sendidx = nullptr; g->d_rowlist = nullptr;
   g->d_var = g->d_grad = g->d_flux = g->d_sendbuf = nullptr;
   g->own_grad = g->own_sendbuf = true;
   g->uploaded = false;
@@ -274,6 +275,24 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   HIP_TRY(hipMemset(g->d_halo, 0, sizeof(int) * (size_t)(p->nhalo_total + 1)));
   if (p->nhalo_total)
     HIP_TRY(hipMemcpy(g->d_halo, p->halo_idx, sizeof(int) * (size_t)p->nhalo_total, hipMemcpyHostToDevice));
+  {  // row lists at a fixed stride, when every tile fits one (the 256-thread fused pass: <= 204 rows)
+    bool fits = p->ntiles > 0 && p->tile_points <= 64;
+    for (int t = 0; t < p->ntiles && fits; t++) fits = p->tiles[t].npts + p->tiles[t].nhalo <= 204 && p->tiles[t].npts > 0;
+    if (const char *e = getenv("CFDP_ROWLIST")) fits = fits && atoi(e) != 0;
+    if (fits) {
+      std::vector<int> rl((size_t)p->ntiles * GG_ROW_STRIDE);
+      for (int t = 0; t < p->ntiles; t++) {
+        const cfdp_tile_desc &td = p->tiles[t];
+        int *r = rl.data() + (size_t)t * GG_ROW_STRIDE;
+        const int n = td.npts + td.nhalo;
+        for (int i = 0; i < td.npts; i++) r[i] = td.pstart + i;
+        for (int i = 0; i < td.nhalo; i++) r[td.npts + i] = p->halo_idx[td.halo_off + i];
+        for (int i = n; i < GG_ROW_STRIDE; i++) r[i] = r[n - 1];
+      }
+      HIP_TRY(hipMalloc(&g->d_rowlist, rl.size() * sizeof(int)));
+      HIP_TRY(hipMemcpy(g->d_rowlist, rl.data(), rl.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+  }
   g->vol.assign(p->vol, p->vol + p->nown);
   {  // blob + var rows + grad rows streamed per iteration vs the 256 MiB Infinity Cache
     const double per_iter = (double)p->blob_bytes + (double)p->nall * (64.0 + 168.0);
