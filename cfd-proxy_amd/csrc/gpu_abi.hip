@@ -115,10 +115,24 @@ struct cfdp_gpu {
   }
   gg_grad_view alt_view() const { return gg_grad_view::of(d_grad_alt, nown, nall); }
   bool will_fuse() const { return fusion && flux_pending >= 0 && d_grad_alt; }
+  // pinned staging image of the field transfers (file numbering <-> device numbering happens on the
+  // host, in parallel); grown on demand, freed with the context
+  double *h_stage = nullptr;
+  size_t h_stage_len = 0;
+  double *stage(size_t n) {
+    if (n > h_stage_len) {
+      if (h_stage) (void)hipHostFree(h_stage);
+      h_stage = nullptr;
+      h_stage_len = 0;
+      if (hipHostMalloc((void **)&h_stage, n * sizeof(double), hipHostMallocDefault) != hipSuccess) return nullptr;
+      h_stage_len = n;
+    }
+    return h_stage;
+  }
   // device image <-> rows in FILE numbering
-  void rows_to_device(const double *rows, std::vector<double> &img) const {
-    img.resize((size_t)nall * 21);
-    double *a = img.data(), *gh = a + (size_t)nown * 10, *b = gh + (size_t)(nall - nown) * 21;
+  void rows_to_device(const double *rows, double *img) const {
+    double *a = img, *gh = a + (size_t)nown * 10, *b = gh + (size_t)(nall - nown) * 21;
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < nall; i++) {
       const double *r = rows + (size_t)new2old[i] * 21;
       if (i < nown) {
@@ -129,8 +143,9 @@ struct cfdp_gpu {
       }
     }
   }
-  void device_to_rows(const std::vector<double> &img, double *rows) const {
-    const double *a = img.data(), *gh = a + (size_t)nown * 10, *b = gh + (size_t)(nall - nown) * 21;
+  void device_to_rows(const double *img, double *rows) const {
+    const double *a = img, *gh = a + (size_t)nown * 10, *b = gh + (size_t)(nall - nown) * 21;
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < nall; i++) {
       double *r = rows + (size_t)new2old[i] * 21;
       if (i < nown) {
@@ -217,6 +232,7 @@ void cfdp_gpu_destroy(cfdp_gpu *g) {
   (void)cfdp_gpu_rccl_finalize(g);
   ipc_release(g);
   free_device(g);
+  if (g->h_stage) (void)hipHostFree(g->h_stage);
   if (!g->streams_exported) {  // exported streams may still be referenced by the caller's runtime
     if (g->s_main) (void)hipStreamDestroy(g->s_main);
     if (g->s_comm) (void)hipStreamDestroy(g->s_comm);
@@ -391,27 +407,36 @@ int cfdp_gpu_bind_grad_alt(cfdp_gpu *g, void *dev_grad) {
 
 int cfdp_gpu_set_var(cfdp_gpu *g, const double *var) {
   NEED_UPLOAD(g);
-  std::vector<double> tmp((size_t)g->nall * 8, 0.0);
-  for (int i = 0; i < g->nall; i++)
-    memcpy(&tmp[(size_t)i * 8], var + (size_t)g->new2old[i] * 7, 7 * sizeof(double));
-  for (int i = 0; i < g->nown; i++) tmp[(size_t)i * 8 + 7] = g->vol[i];  // pvolume rides in the row's pad
+  const size_t len = (size_t)g->nall * 8;
+  double *tmp = g->stage(len);
+  if (!tmp) return fail("no pinned host memory for the staging image");
+  const int nall = g->nall, nown = g->nown;
+  const int *new2old = g->new2old.data();
+  const double *vol = g->vol.data();
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < nall; i++) {
+    memcpy(tmp + (size_t)i * 8, var + (size_t)new2old[i] * 7, 7 * sizeof(double));
+    tmp[(size_t)i * 8 + 7] = i < nown ? vol[i] : 0.0;  // pvolume rides in the row's pad
+  }
   HIP_TRY(hipDeviceSynchronize());  // the context's streams are non-blocking: nothing may still read var
-  HIP_TRY(hipMemcpy(g->d_var, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(g->d_var, tmp, len * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
 
 int cfdp_gpu_set_grad(cfdp_gpu *g, const double *grad) {
   NEED_UPLOAD(g);
   if (flush_flux(g)) return 1;
-  std::vector<double> tmp;
+  const size_t len = (size_t)g->nall * 21;
+  double *tmp = g->stage(len);
+  if (!tmp) return fail("no pinned host memory for the staging image");
   g->rows_to_device(grad, tmp);
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(g->d_grad, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(g->d_grad, tmp, len * sizeof(double), hipMemcpyHostToDevice));
   if (g->d_grad_alt)  // rows no kernel writes (ghosts without an exchange, faceless points) read the same from either buffer
-    HIP_TRY(hipMemcpy(g->d_grad_alt, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g->d_grad_alt, tmp, len * sizeof(double), hipMemcpyHostToDevice));
   if (g->ipc.on && g->nall > g->nown)
     for (int par = 0; par < 2; par++)
-      HIP_TRY(hipMemcpy(g->land(par), tmp.data() + (size_t)g->nown * 10,
+      HIP_TRY(hipMemcpy(g->land(par), tmp + (size_t)g->nown * 10,
                         sizeof(double) * 21 * (size_t)(g->nall - g->nown), hipMemcpyHostToDevice));
   return 0;
 }
@@ -420,10 +445,12 @@ int cfdp_gpu_set_flux(cfdp_gpu *g, const double *flux) {
   NEED_UPLOAD(g);
   if (flush_flux(g)) return 1;
   HIP_TRY(hipDeviceSynchronize());
-  std::vector<double> tmp((size_t)g->nown * 3);
+  const size_t len = (size_t)g->nown * 3;
+  double *tmp = g->stage(len);
+  if (!tmp) return fail("no pinned host memory for the staging image");
   for (int i = 0; i < g->nown; i++)
-    memcpy(&tmp[(size_t)i * 3], flux + (size_t)g->new2old[i] * 3, 3 * sizeof(double));
-  HIP_TRY(hipMemcpy(g->d_flux, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    memcpy(tmp + (size_t)i * 3, flux + (size_t)g->new2old[i] * 3, 3 * sizeof(double));
+  HIP_TRY(hipMemcpy(g->d_flux, tmp, len * sizeof(double), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -431,10 +458,12 @@ int cfdp_gpu_get_grad(cfdp_gpu *g, double *grad) {
   NEED_UPLOAD(g);
   if (flush_flux(g)) return 1;
   HIP_TRY(hipDeviceSynchronize());
-  std::vector<double> tmp((size_t)g->nall * 21);
-  HIP_TRY(hipMemcpy(tmp.data(), g->d_grad, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  const size_t len = (size_t)g->nall * 21;
+  double *tmp = g->stage(len);
+  if (!tmp) return fail("no pinned host memory for the staging image");
+  HIP_TRY(hipMemcpy(tmp, g->d_grad, len * sizeof(double), hipMemcpyDeviceToHost));
   if (g->ipc.on && g->nall > g->nown)  // the ghost rows live in the landing arena of the latest exchange
-    HIP_TRY(hipMemcpy(tmp.data() + (size_t)g->nown * 10, g->grad_view().ghost,
+    HIP_TRY(hipMemcpy(tmp + (size_t)g->nown * 10, g->grad_view().ghost,
                       sizeof(double) * 21 * (size_t)(g->nall - g->nown), hipMemcpyDeviceToHost));
   g->device_to_rows(tmp, grad);
   return 0;
@@ -444,10 +473,12 @@ int cfdp_gpu_get_flux(cfdp_gpu *g, double *flux) {
   NEED_UPLOAD(g);
   if (flush_flux(g)) return 1;
   HIP_TRY(hipDeviceSynchronize());
-  std::vector<double> tmp((size_t)g->nown * 3);
-  HIP_TRY(hipMemcpy(tmp.data(), g->d_flux, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  const size_t len = (size_t)g->nown * 3;
+  double *tmp = g->stage(len);
+  if (!tmp) return fail("no pinned host memory for the staging image");
+  HIP_TRY(hipMemcpy(tmp, g->d_flux, len * sizeof(double), hipMemcpyDeviceToHost));
   for (int i = 0; i < g->nown; i++) /* ghost rows of psd_flux are left untouched */
-    memcpy(flux + (size_t)g->new2old[i] * 3, &tmp[(size_t)i * 3], 3 * sizeof(double));
+    memcpy(flux + (size_t)g->new2old[i] * 3, tmp + (size_t)i * 3, 3 * sizeof(double));
   return 0;
 }
 
