@@ -273,6 +273,30 @@ class RankSolver:
             self.transport = "torch"  # nothing device-side is left: torch.distributed P2P ops
         return self.transport
 
+    def fallback(self) -> bool:
+        """collective (every rank takes the same decision from the same all-reduced evidence): give up
+        the current transport for the next best one; False when nothing is left to fall back to"""
+        cur = self.transport
+        last = "torch" if self.dist.get_backend() == "nccl" else "staged"
+        if cur == last or self.world == 1:
+            return False
+        self.synchronize()
+        if cur in self.available:
+            self.available.remove(cur)
+        self.probe.pop(cur, None)
+        if cur == "ipc":
+            self.gpu.ipc_enable(False)
+        if self.available:
+            self.use_transport(min(self.available, key=lambda n: self.probe.get(n, float("inf"))))
+            return True
+        if last == "staged" and not hasattr(self, "h_send"):
+            torch = self.torch
+            self.h_send = [torch.empty(v.numel(), dtype=torch.float64).pin_memory() for v in self.send_views]
+            self.h_recv = [torch.empty(v[0].numel(), dtype=torch.float64).pin_memory() for v in self.recv_views]
+        self.transport = last
+        self.dist.barrier()
+        return True
+
     def _ipc_off(self) -> None:
         try:
             self.gpu.sync()

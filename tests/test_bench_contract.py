@@ -27,7 +27,7 @@ def test_bench_line(gpu):
     assert out["value"] > 0 and out["ms_per_step"] > 0
 
 
-def _bench_two_ranks(transport):
+def _bench_two_ranks(transport, extra_env=None, expect=None):
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -36,7 +36,7 @@ def _bench_two_ranks(transport):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), CFDP_SHARED_GPU="1")
+                   MASTER_PORT=str(port), CFDP_SHARED_GPU="1", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
                                        "--warmup", "3", "--transport", transport, "--no-files"], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -49,7 +49,8 @@ def _bench_two_ranks(transport):
     assert out["config"]["ghost_points_per_gpu"] > 0 and "overlap" in out
     assert 0 < out["overlap"]["efficiency_async"] <= 1.5
     assert out["exchange_check"]["ok"], out["exchange_check"]
-    assert out["config"]["transport"] == ("ipc" if transport == "auto" else transport) and out["config"]["fused_iterations"]
+    assert out["config"]["transport"] == (expect or ("ipc" if transport == "auto" else transport))
+    assert out["config"]["fused_iterations"]
     assert "cpu_baseline" not in out
     return out
 
@@ -67,3 +68,12 @@ def test_bench_two_ranks_xgmi_write_notify(gpu):
     replayed from hipGraphs), the two ranks sharing this GPU; every sent row must have arrived"""
     out = _bench_two_ranks("auto")  # on a shared GPU only the ipc transport can be set up (RCCL needs one device per rank)
     assert out["exchange_check"]["wait_timeouts"] == 0 and "ipc" in out["config"]["transport_probe_us_per_iteration"]
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_when_the_exchange_check_fails(gpu):
+    """a transport whose exchange check fails after the timed region is dropped and the measurement is
+    repeated on the next one (here: injected failure of the first check; ipc -> host-staged, the only
+    other transport two ranks sharing one GPU have)"""
+    out = _bench_two_ranks("auto", extra_env={"CFDP_BENCH_REJECT_FIRST": "1"}, expect="staged")
+    assert out["exchange_check"]["transports_rejected"] == ["ipc"]
