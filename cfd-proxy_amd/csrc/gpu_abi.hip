@@ -1250,7 +1250,11 @@ int cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes) {
   auto &I = g->ipc;
   I.land_bytes = (((size_t)(g->nall - g->nown) * 21 * sizeof(double)) + 255) & ~(size_t)255;
   const size_t bytes = GG_IPC_HDR_BYTES + 2 * I.land_bytes;
-  HIP_TRY(hipMalloc(&I.block, bytes));
+  // CFDP_IPC_FINEGRAINED=1: a fine-grained block (coherent at system scope without cache maintenance);
+  // the default coarse-grained block relies on the system-scope loads / fences of the kernels
+  const char *fg = getenv("CFDP_IPC_FINEGRAINED");
+  if (fg && atoi(fg) != 0) HIP_TRY(hipExtMallocWithFlags((void **)&I.block, bytes, hipDeviceMallocFinegrained));
+  else HIP_TRY(hipMalloc(&I.block, bytes));
   HIP_TRY(hipMemset(I.block, 0, bytes));
   hipIpcMemHandle_t h;
   HIP_TRY(hipIpcGetMemHandle(&h, I.block));

@@ -156,14 +156,22 @@ class RankSolver:
         self.available: List[str] = []
         self.probe: Dict[str, float] = {}
         if transport in ("ipc", "auto") and world > 1:
-            try:
-                self._init_ipc()
-                self.available.append("ipc")
-            except Exception as e:
-                import sys
-                print(f"[rank {rank}] xGMI write+notify setup failed ({e}); using RCCL", file=sys.stderr)
-                if transport == "ipc":
-                    transport = "rccl"
+            import sys
+            # a second attempt with a fine-grained landing block (every rank fails or passes alike:
+            # _init_ipc raises from all-reduced evidence only)
+            for attempt in ("as configured", "fine-grained block"):
+                if attempt == "fine-grained block":
+                    if os.environ.get("CFDP_IPC_FINEGRAINED", "0") not in ("", "0"):
+                        break
+                    os.environ["CFDP_IPC_FINEGRAINED"] = "1"
+                try:
+                    self._init_ipc()
+                    self.available.append("ipc")
+                    break
+                except Exception as e:
+                    print(f"[rank {rank}] xGMI write+notify setup failed ({attempt}: {e})", file=sys.stderr)
+            if "ipc" not in self.available and transport == "ipc":
+                transport = "rccl"
         elif transport in ("ipc", "auto"):
             transport = "rccl"  # one rank: no exchange at all
         if transport == "rccl" and world > 1 and dist.get_backend() != "nccl":
