@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--ndomains", type=int, default=12)
     ap.add_argument("--files", action="store_true")
     ap.add_argument("--transport", default="staged")
+    ap.add_argument("--fail-first-validation", action="store_true",
+                    help="the first exchange validation reports failure: the set-up must be torn down and retried")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -57,6 +59,26 @@ def main():
 
     if args.gpu:
         ftruth = orc.np_flux(whole.fpoint, whole.fnormal, truth, whole.nown, mode=0)
+        if args.fail_first_validation:
+            real, calls = mg.RankSolver.validate_exchange, []
+
+            def flaky(self):
+                calls.append(os.environ.get("CFDP_IPC_FINEGRAINED", "0"))
+                return real(self) and len(calls) > 1
+            mg.RankSolver.validate_exchange = flaky
+            os.environ.pop("CFDP_IPC_FINEGRAINED", None)
+            solver = mg.RankSolver(part, rank, world, 0, dist, transport="ipc", tile_points=32)
+            assert solver.transport == "ipc" and calls == ["0", "1"], (solver.transport, calls)
+            solver.run_steps(60, with_exchange=True, overlap=True)
+            g = solver.grad_host()
+            assert np.abs(g - truth[gid]).max() / np.abs(truth).max() <= 1e-12
+            assert solver.gpu.ipc_error() == 0
+            solver.close()
+            mg.RankSolver.validate_exchange = real
+            os.environ.pop("CFDP_IPC_FINEGRAINED", None)
+            print(f"RANK_OK {rank}", flush=True)
+            dist.destroy_process_group()
+            return
         for fusion in (False, True):
             solver = mg.RankSolver(part, rank, world, 0, dist, transport=args.transport, tile_points=32, fusion=fusion)
             assert solver.transport == args.transport, solver.transport  # no silent fallback in the tests

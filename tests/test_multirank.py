@@ -61,6 +61,13 @@ def test_multirank_xgmi_write_notify_between_processes_on_one_gpu(gpu):
     _launch(4, ["--gpu", "--transport", "ipc", "--dims", "16,16,12", "--ndomains", "8"])
 
 
+@pytest.mark.gpu
+def test_write_notify_setup_is_retried_with_a_fine_grained_block(gpu):
+    """a failed exchange validation tears the IPC mappings down on every rank and the set-up is retried
+    once with a fine-grained landing block (CFDP_IPC_FINEGRAINED=1) before any other transport is tried"""
+    _launch(2, ["--gpu", "--fail-first-validation"])
+
+
 MPIEXEC = "/opt/conda/bin/mpiexec"
 MPI_DRIVER = os.path.join(ROOT, "cfd-proxy_amd", "bin", "hybrid.f6.hip.mpi")
 
