@@ -680,3 +680,36 @@ def test_baseline_multi_rank_configs_match_whole_mesh_oracle(gpu, orc, label, n,
         assert np.abs(p.psd_flux[: p.nown] - ftruth[gid[: p.nown]]).max() <= TOL * fscale, (label, r)
         gpart.close()
     whole.free()
+
+
+def test_degenerate_partitions(gpu, orc):
+    """the smallest inputs the C ABI accepts (the loader itself refuses files without faces or owned
+    points, like the reference: src/solver_data.c:104-107): one face between two owned points; one
+    owned point whose only neighbour is a ghost; owned points without any face -- separate kernels
+    and the fused pass, values against the numpy statement, untouched rows left alone"""
+    pkg = gpu
+    cases = [
+        (np.array([[0, 1]], np.int32), 2, 2),            # one face, two owned points
+        (np.array([[0, 1]], np.int32), 1, 2),            # one owned point, its neighbour a ghost
+        (np.array([[1, 3]], np.int32), 5, 5),            # points 0, 2, 4 have no face at all
+    ]
+    for fp, nown, nall in cases:
+        fn = np.array([[0.5, -1.25, 2.0]])
+        vol = np.arange(nall, dtype=float) + 1.5
+        var = np.arange(nall * 7, dtype=float).reshape(nall, 7) * 0.25 + 1
+        for fusion in (False, True):
+            dom = pkg.domain_from_arrays(fp, fn, vol, nown, var=var)
+            part = pkg.GpuPartition(dom, tile_points=64)
+            part.set_fusion(fusion)
+            part.run_iterations(3, True, 0, use_graph=False)
+            part.pull_fields()
+            ref = orc.np_gradients(fp, fn, vol, var, nown)
+            touched = np.zeros(nall, bool)
+            touched[fp.ravel()] = True
+            touched[nown:] = False
+            assert np.allclose(dom.grad[touched], ref[touched], rtol=1e-13, atol=0), (fp, nown, fusion)
+            assert np.all(dom.grad[~touched] == 1.0) and np.all(dom.psd_flux[~touched] == 1.0), (fp, nown, fusion)
+            fref = orc.np_flux(fp, fn, dom.grad, nown, mode=0)
+            assert np.allclose(dom.psd_flux[touched], fref[touched], rtol=1e-12, atol=1e-300), (fp, nown, fusion)
+            part.close()
+            dom.free()
