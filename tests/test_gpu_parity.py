@@ -713,3 +713,39 @@ def test_degenerate_partitions(gpu, orc):
             assert np.allclose(dom.psd_flux[touched], fref[touched], rtol=1e-12, atol=1e-300), (fp, nown, fusion)
             part.close()
             dom.free()
+
+
+@pytest.mark.parametrize("nleaf", [300, 1000, 4000])
+def test_hub_point_with_hundreds_of_faces(gpu, orc, nleaf):
+    """a point of very high degree (a star: one hub, `nleaf` leaves, plus a chain through the leaves):
+    its tile fits none of the fixed-capacity LDS-DMA forms, so the general kernels run -- same values.
+    A point whose neighbours do not fit the 160 KiB of LDS at all (4000) is refused loudly at upload."""
+    pkg = gpu
+    rng = np.random.default_rng(nleaf)
+    n = nleaf + 1
+    star = np.stack([np.zeros(nleaf, np.int32), np.arange(1, n, dtype=np.int32)], 1)
+    chain = np.stack([np.arange(1, n - 1, dtype=np.int32), np.arange(2, n, dtype=np.int32)], 1)
+    fp = np.concatenate([star, chain]).astype(np.int32)
+    flip = rng.random(len(fp)) < 0.5
+    fp[flip] = fp[flip][:, ::-1]
+    fn = rng.standard_normal((len(fp), 3))
+    vol = rng.uniform(0.5, 2.0, n)
+    var = rng.standard_normal((n, 7)) + 3.0
+    ref = orc.np_gradients(fp, fn, vol, var, n)
+    if nleaf >= 4000:
+        dom = pkg.domain_from_arrays(fp, fn, vol, n, var=var)
+        with pytest.raises(pkg.GpuError, match="LDS"):
+            pkg.GpuPartition(dom)
+        dom.free()
+        return
+    for fusion in (False, True):
+        dom = pkg.domain_from_arrays(fp, fn, vol, n, var=var)
+        part = pkg.GpuPartition(dom)
+        part.set_fusion(fusion)
+        part.run_iterations(2, True, 0, use_graph=False)
+        part.pull_fields()
+        assert rel_err(orc, dom.grad, ref, fp, fn, vol, var, n) <= TOL, fusion
+        fref = orc.np_flux(fp, fn, dom.grad, n, mode=0)
+        assert np.abs(dom.psd_flux - fref).max() <= 1e-11 * np.abs(fref).max(), fusion
+        part.close()
+        dom.free()
