@@ -57,8 +57,8 @@ def usable_cores() -> int:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--tile-points", type=int, default=0)
     ap.add_argument("--grad-lanes", type=int, default=0)
     ap.add_argument("--flux-lanes", type=int, default=0)
@@ -219,7 +219,7 @@ def main() -> None:
     # ---- roofline of the dominant kernel (gradient face loop), HIP events on its own stream ----
     bg = pkg.algo_bytes_grad(nfaces_part, nown, nadd)
     bf = pkg.algo_bytes_flux(nfaces_part, nown, nadd)
-    ms_g, ms_f = solver.gpu.time_kernels(200)
+    ms_g, ms_f = solver.gpu.time_kernels(500)
     # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes,
     # gfx950 corrections: tools/measure_traffic.py) of the same workload, committed under profiles/
     traffic = None
@@ -243,7 +243,7 @@ def main() -> None:
     else:
         # the timed loop runs the fused pass (flux(i) + gradients(i+1), tile data streamed once):
         # one launch does the work of one gradient launch and one flux launch
-        ms_fu = solver.gpu.time_fused(200)
+        ms_fu = solver.gpu.time_fused(1000)
         ftraffic = None
         if world == 1:
             try:

@@ -5,7 +5,7 @@ tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 5000 --warmup 200 --no-cpu --no-finest > $R/gpurun_out/prof_${tag}_bench.json 2> $R/gpurun_out/prof_${tag}_bench.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 20000 --warmup 2000 --no-cpu --no-finest > $R/gpurun_out/prof_${tag}_bench.json 2> $R/gpurun_out/prof_${tag}_bench.err || exit 1
 cd $R && python3 tools/measure_traffic.py $tag > gpurun_out/traffic_$tag.log 2>&1
 # one unambiguous copy of this run's summary (gpurun merges, it never deletes older runs' files)
 cp "$(ls -t gpurun_out/prof_$tag/*/*_kernel_stats.csv | sed -n 1p)" gpurun_out/prof_${tag}_kernel_stats.csv
