@@ -47,7 +47,7 @@ def _bench_two_ranks(transport, extra_env=None, expect=None):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["points_per_gpu"] == 262144
     assert out["config"]["ghost_points_per_gpu"] > 0 and "overlap" in out
-    assert 0 < out["overlap"]["efficiency_async"] <= 1.5
+    assert out["overlap"]["efficiency_async"] > 0  # (its size means nothing between ranks time-slicing one GPU)
     assert out["exchange_check"]["ok"], out["exchange_check"]
     assert out["config"]["transport"] == (expect or ("ipc" if transport == "auto" else transport))
     assert out["config"]["fused_iterations"]
