@@ -85,3 +85,22 @@ def test_gpu_entry_points_fail_loudly_without_a_device(pkg):
     with pytest.raises(pkg.GpuError):
         pkg.GpuPartition(dom)
     dom.free()
+
+
+def test_integration_md_host_program_compiles_and_links(tmp_path):
+    """the reference's main() as INTEGRATION.md section 2 shows it against the drop-in header: compiled
+    and linked with gcc against libcfdproxy_hip.so (no GPU call is made here)"""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```c\n(#include \"cfdproxy_dropin.h\".*?)```", text, re.S).group(1)
+    src = tmp_path / "main.c"
+    first, rest = block.split("\n", 1)  # (NTHREADS is a variable of the reference's main(): src/hybrid.f6.c:29-52)
+    src.write_text("#include <stdio.h>\n#include <stdlib.h>\n" + first + "\nstatic const int NTHREADS = 1;\n" + rest)
+    exe = tmp_path / "host"
+    r = subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", str(src), "-I" + os.path.join(root, "include"),
+                        "-L" + os.path.join(root, "cfd-proxy_amd", "lib"), "-lcfdproxy_hip", "-fopenmp",
+                        "-Wl,-rpath," + os.path.join(root, "cfd-proxy_amd", "lib"), "-Wl,--allow-shlib-undefined",
+                        "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
