@@ -604,15 +604,16 @@ def test_randomized_partitions_match_the_unpartitioned_mesh(gpu, orc):
         whole.free()
 
 
-@pytest.mark.parametrize("n", [64, 128])
-def test_full_size_fused_iterations_match_separate_kernels(gpu, n):
+@pytest.mark.parametrize("n,flux_mode", [(64, 0), (64, 1), (128, 0)])
+def test_full_size_fused_iterations_match_separate_kernels(gpu, n, flux_mode):
     """BASELINE.json sizes: the fused pass (the kernel the benchmark runs) against the two separate
-    kernels on the same partition -- gradients bit for bit, flux bit for bit (shared flux code)"""
+    kernels on the same partition -- gradients bit for bit, flux bit for bit (shared flux code), in
+    both flux modes"""
     pkg = gpu
     dom = pkg.gen_domain(pkg.gen_params(n, ndomains=1), 0)
     pkg.fill_var(dom, None, pkg.VAR_HASH)
     part = pkg.GpuPartition(dom)
-    part.run_iterations(2, True, 0, use_graph=False)
+    part.run_iterations(2, True, flux_mode, use_graph=False)
     part.pull_fields()
     g0, f0 = dom.grad.copy(), dom.psd_flux.copy()
     assert np.abs(g0).max() > 0 and np.abs(f0[: dom.nown]).max() > 0
@@ -620,7 +621,7 @@ def test_full_size_fused_iterations_match_separate_kernels(gpu, n):
     dom.grad[:] = 0.0
     dom.psd_flux[:] = 0.0
     part.push_fields()
-    part.run_iterations(103, True, 0, use_graph=True)
+    part.run_iterations(103, True, flux_mode, use_graph=True)
     part.pull_fields()
     assert np.array_equal(dom.grad, g0)
     assert np.array_equal(dom.psd_flux[: dom.nown], f0[: dom.nown])
