@@ -19,7 +19,10 @@
 #include "cfdproxy_hip.h"
 #include "host_util.h"
 
+#include <pthread.h>
 #include <string.h>
+#include <sys/time.h>
+#include <unistd.h>
 
 typedef struct cfdp_group {
   int G;
@@ -34,7 +37,49 @@ typedef struct cfdp_solver { /* what solver_data.gpu points to */
   cfdp_group *group;
   int rank;
   int external; /* partners live in other processes: 1 = RCCL (cfdp_attach_rccl), 2 = xGMI write + notify */
+  /* the reference calls compute_gradients_gg_* / compute_psd_flux from EVERY thread of one
+   * `omp parallel` region (src/solver.c:45-55); one of them must enqueue -- see call_begin()   */
+  pthread_mutex_t mtx;
+  unsigned long id;          /* unique per init_threads(): keys the callers' thread-local call counts */
+  unsigned long calls_done;  /* entry-point calls already performed for this partition            */
+  int final_pending;         /* the last compute_gradients_gg_* carried final = 1                 */
 } cfdp_solver;
+
+/* ---- one enqueue per entry-point call, whichever threads make it ---------------------------
+ * Every calling thread makes the same sequence of entry-point calls on a solver_data (the
+ * reference's harness: gradients, flux, barrier, per iteration).  The FIRST thread to make its
+ * k-th call performs call k (the reference elects its first/last thread the same way,
+ * src/threads.c:142-179); the others find it done and return.  Calls are serialised by the
+ * solver's mutex, so call k+1 is enqueued after call k whichever threads perform them.  No
+ * OpenMP runtime is consulted: pthreads, any OpenMP implementation and plain serial callers all
+ * work; the one requirement is the reference's own -- every thread of the team makes every
+ * call (a thread that joins later only ever finds its calls done).                            */
+#define CFDP_TLS_SLOTS 16
+static __thread struct { unsigned long id, n; } tls_calls[CFDP_TLS_SLOTS];
+static unsigned long g_solver_ids = 0;
+
+static int call_begin(cfdp_solver *sv) { /* 1: this thread performs the call and holds sv->mtx */
+  int slot = -1, spare = 0;
+  unsigned long oldest = ~0ul;
+  for (int i = 0; i < CFDP_TLS_SLOTS && slot < 0; i++) {
+    if (tls_calls[i].id == sv->id) slot = i;
+    else if (tls_calls[i].id < oldest) { oldest = tls_calls[i].id; spare = i; }
+  }
+  if (slot < 0) { /* first call of this thread on this solver; recycle the oldest solver's slot */
+    slot = spare;
+    tls_calls[slot].id = sv->id;
+    tls_calls[slot].n = 0;
+  }
+  const unsigned long k = ++tls_calls[slot].n;
+  pthread_mutex_lock(&sv->mtx);
+  if (k <= sv->calls_done) {
+    pthread_mutex_unlock(&sv->mtx);
+    return 0;
+  }
+  sv->calls_done = k;
+  return 1;
+}
+static void call_end(cfdp_solver *sv) { pthread_mutex_unlock(&sv->mtx); }
 
 #define GPU_OK(call)                                                                       \
   do {                                                                                     \
@@ -83,7 +128,11 @@ void cfdp_group_destroy(cfdp_group *grp) {
   if (!grp) return;
   for (int r = 0; r < grp->G; r++) {
     if (grp->gpus[r]) cfdp_gpu_destroy(grp->gpus[r]);
-    if (grp->sds[r]) { free(grp->sds[r]->gpu); grp->sds[r]->gpu = NULL; }
+    if (grp->sds[r] && grp->sds[r]->gpu) {
+      pthread_mutex_destroy(&((cfdp_solver *)grp->sds[r]->gpu)->mtx);
+      free(grp->sds[r]->gpu);
+      grp->sds[r]->gpu = NULL;
+    }
     if (grp->cds[r]) grp->cds[r]->group = NULL;
   }
   free(grp->gpus); free(grp->sds); free(grp->cds);
@@ -132,6 +181,8 @@ void init_threads(comm_data *cd, solver_data *sd, int NTHREADS) {
   grp->gpus[rank] = gpu;
   cfdp_solver *sv = cfdp_calloc(1, sizeof(*sv));
   sv->gpu = gpu; sv->group = grp; sv->rank = rank;
+  pthread_mutex_init(&sv->mtx, NULL);
+  sv->id = __atomic_add_fetch(&g_solver_ids, 1, __ATOMIC_RELAXED);
   sd->gpu = sv;
   cfdp_sync_fields_to_device(sd);
 }
@@ -170,43 +221,51 @@ void cfdp_attach_ipc(solver_data *sd) { solver_of(sd)->external = 2; }
 cfdp_gpu *cfdp_dropin_context(solver_data *sd) { return solver_of(sd)->gpu; }
 
 /* --------------------------------------------------------------- gradients (10 variants) */
-static void gradients(solver_data *sd, int with_exchange, int overlap) {
+/* `final` = last iteration of a timed sample (src/solver.c:49: the reference uses it to stop
+ * re-posting receives).  Here it makes the compute_psd_flux() of that iteration run the deferred
+ * flux and wait for the device, so a harness that reads the host clock after its loop -- as the
+ * reference's does (src/solver.c:43,57) -- times finished work, not enqueue calls.           */
+static void gradients(solver_data *sd, int with_exchange, int overlap, int final) {
   cfdp_solver *sv = solver_of(sd);
+  if (!call_begin(sv)) return;
+  sv->final_pending = final != 0;
   if (sv->external == 2) { /* gradients, push, notify, wait; compute_psd_flux closes the step */
     GPU_OK(cfdp_gpu_step_ipc_pre(sv->gpu, with_exchange, overlap));
-    return;
-  }
-  if (sv->external) { /* step bracket + this iteration's RCCL group; compute_psd_flux closes the step */
+  } else if (sv->external) { /* step bracket + this iteration's RCCL group; compute_psd_flux closes the step */
     GPU_OK(cfdp_gpu_step_pre(sv->gpu, with_exchange, overlap));
     if (with_exchange) GPU_OK(cfdp_gpu_exchange_rccl(sv->gpu));
-    return;
+  } else {
+    GPU_OK(cfdp_gpu_rank_gradients(sv->group->gpus, sv->group->G, sv->rank, with_exchange, overlap));
   }
-  GPU_OK(cfdp_gpu_rank_gradients(sv->group->gpus, sv->group->G, sv->rank, with_exchange, overlap));
+  call_end(sv);
 }
 
 void compute_gradients_gg_comm_free(comm_data *cd, solver_data *sd, int final) {
-  (void)cd; (void)final;
-  gradients(sd, 0, 0);
+  (void)cd;
+  gradients(sd, 0, 0, final);
 }
 /* bulk-synchronous family: full gradient, then pack, then exchange (src/gradients.c:167,
- * 226,264,301; src/exchange_data_mpi.c:199-284)                                          */
+ * 226,264,301; src/exchange_data_mpi.c:199-284).  mpi_early_recv belongs here: its sends start
+ * after the last thread has finished computing, only its receives are posted early
+ * (src/exchange_data_mpi.c:287-373) -- and a GPU partner's ghost rows are always "posted".     */
 #define BULK(name)                                                              \
   void name(comm_data *cd, solver_data *sd, int final) {                        \
-    (void)cd; (void)final;                                                      \
-    gradients(sd, 1, 0);                                                        \
+    (void)cd;                                                                   \
+    gradients(sd, 1, 0, final);                                                 \
   }
 /* asynchronous family: sent points first, exchange overlapped with the interior
- * (src/gradients.c:188,208,246,284,321; src/exchange_data_gaspi.c:307-502)               */
+ * (src/gradients.c:208,246,284,321; src/exchange_data_mpi.c:375-543,
+ * src/exchange_data_gaspi.c:307-502)                                                     */
 #define ASYNC(name)                                                             \
   void name(comm_data *cd, solver_data *sd, int final) {                        \
-    (void)cd; (void)final;                                                      \
-    gradients(sd, 1, 1);                                                        \
+    (void)cd;                                                                   \
+    gradients(sd, 1, 1, final);                                                 \
   }
 BULK(compute_gradients_gg_mpi_bulk_sync)
+BULK(compute_gradients_gg_mpi_early_recv)
 BULK(compute_gradients_gg_gaspi_bulk_sync)
 BULK(compute_gradients_gg_mpifence_bulk_sync)
 BULK(compute_gradients_gg_mpipscw_bulk_sync)
-ASYNC(compute_gradients_gg_mpi_early_recv)
 ASYNC(compute_gradients_gg_mpi_async)
 ASYNC(compute_gradients_gg_gaspi_async)
 ASYNC(compute_gradients_gg_mpifence_async)
@@ -214,21 +273,35 @@ ASYNC(compute_gradients_gg_mpipscw_async)
 
 void compute_psd_flux(solver_data *sd) {
   cfdp_solver *sv = solver_of(sd);
-  if (sv->external == 2) {
-    GPU_OK(cfdp_gpu_step_ipc_post(sv->gpu, 1, sv->group->flux_mode));
-    return;
-  }
-  if (sv->external) {
-    GPU_OK(cfdp_gpu_step_post(sv->gpu, 1, sv->group->flux_mode));
-    return;
-  }
-  GPU_OK(cfdp_gpu_rank_flux(sv->group->gpus, sv->group->G, sv->rank, 1, sv->group->flux_mode));
+  if (!call_begin(sv)) return;
+  if (sv->external == 2) GPU_OK(cfdp_gpu_step_ipc_post(sv->gpu, 1, sv->group->flux_mode));
+  else if (sv->external) GPU_OK(cfdp_gpu_step_post(sv->gpu, 1, sv->group->flux_mode));
+  else GPU_OK(cfdp_gpu_rank_flux(sv->group->gpus, sv->group->G, sv->rank, 1, sv->group->flux_mode));
+  /* end of a timed sample: the work is done when this returns.  In-process rank groups are
+   * driven rank after rank by one caller, which syncs the whole group itself (test_solver):
+   * a rank waiting here for partners whose flux is not enqueued yet would gain nothing.       */
+  if (sv->final_pending && sv->group->G == 1) GPU_OK(cfdp_gpu_sync(sv->gpu));
+  sv->final_pending = 0;
+  call_end(sv);
+}
+
+/* ------------------------------------------------ helpers of the reference's main / harness */
+int f_exist(char *fname) { return fname && access(fname, F_OK) == 0; } /* src/error_handling.c:18-22 */
+
+double now(void) { /* src/util.c:216-222: wall-clock seconds */
+  struct timeval tv;
+  gettimeofday(&tv, NULL);
+  return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec;
+}
+
+static int cmp_double(const void *a, const void *b);
+void sort_median(double *begin, double *end) { /* [begin, end): `end` is exclusive (src/util.c:61-78) */
+  if (begin && end > begin) qsort(begin, (size_t)(end - begin), sizeof(double), cmp_double);
 }
 
 /* -------------------------------------------------------------------------- test_solver */
 #define N_MEDIAN 25
 
-static int cmp_double(const void *a, const void *b);
 
 /* ------------------------------------------------------------------------ cfdp_test_vcycle
  * The published experiment (documentation/CFD-Proxy.pdf p.3) is a "3V multigrid cycle": SWEEPS
@@ -280,7 +353,7 @@ void cfdp_test_vcycle(int nlevels, cfdp_group **levels, int sweeps, int ncycles)
   printf("%38s: %10.6f\n", single ? "v_cycle_hipgraph" : "v_cycle_xgmi_async", median[(N_MEDIAN - 1) / 2]);
 }
 
-#define N_SOLVER 3
+#define N_SOLVER 10
 
 static int cmp_double(const void *a, const void *b) {
   double x = *(const double *)a, y = *(const double *)b;
@@ -291,18 +364,31 @@ typedef void (*grad_fn)(comm_data *, solver_data *, int);
 
 /* Times every in-process rank of the group `cd` belongs to (the reference times one MPI
  * rank between barriers, src/solver.c:42-58; here the barrier is a device sync of the
- * whole group).  Prints the reference's TIMINGS block: median seconds per NITER
- * iterations.                                                                            */
+ * whole group).  Prints the reference's TIMINGS block (src/solver.c:288-311): the same ten
+ * rows under the same labels, median seconds per NITER iterations.  Every row runs the entry
+ * point of its name; on the GPU the ten entry points have three behaviours (comm_free; bulk:
+ * all tiles -> pack -> exchange; async: send-point tiles first, exchange beside the interior
+ * tiles), so rows of one family differ by run-to-run noise only.  With one domain only
+ * comm_free is measured, as in the reference (src/solver.c:61-64) -- which then prints nine
+ * uninitialised medians; here they are 0.                                                   */
 void test_solver(comm_data *cd, solver_data *sd, int NTHREADS) {
   cfdp_solver *sv = solver_of(sd);
   cfdp_group *grp = sv->group;
   const int G = grp->G;
-  static const char *names[N_SOLVER] = {"comm_free", "exchange_dbl_xgmi_bulk_sync",
-                                        "exchange_dbl_xgmi_async"};
-  grad_fn fns[N_SOLVER] = {compute_gradients_gg_comm_free, compute_gradients_gg_mpi_bulk_sync,
-                           compute_gradients_gg_gaspi_async};
-  double median[N_SOLVER][N_MEDIAN];
-  int nvar = (cd->ndomains == 1 || G == 1) ? 1 : N_SOLVER;
+  static const char *names[N_SOLVER] = {
+      "comm_free", "exchange_dbl_mpi_bulk_sync", "exchange_dbl_mpi_early_recv", "exchange_dbl_mpi_async",
+      "exchange_dbl_gaspi_bulk_sync", "exchange_dbl_gaspi_async", "exchange_dbl_mpi_fence_bulk_sync",
+      "exchange_dbl_mpi_fence_async", "exchange_dbl_mpi_pscw_bulk_sync", "exchange_dbl_mpi_pscw_async"};
+  static const char *how[N_SOLVER] = {"no exchange", "bulk", "bulk", "async", "bulk", "async", "bulk", "async", "bulk", "async"};
+  grad_fn fns[N_SOLVER] = {
+      compute_gradients_gg_comm_free, compute_gradients_gg_mpi_bulk_sync, compute_gradients_gg_mpi_early_recv,
+      compute_gradients_gg_mpi_async, compute_gradients_gg_gaspi_bulk_sync, compute_gradients_gg_gaspi_async,
+      compute_gradients_gg_mpifence_bulk_sync, compute_gradients_gg_mpifence_async,
+      compute_gradients_gg_mpipscw_bulk_sync, compute_gradients_gg_mpipscw_async};
+  static double median[N_SOLVER][N_MEDIAN];
+  memset(median, 0, sizeof median);
+  const int single = cd->ndomains == 1 || (G == 1 && !sv->external);
+  int nvar = single ? 1 : N_SOLVER;
   for (int k = 0; k < N_MEDIAN; k++) {
     for (int v = 0; v < nvar; v++) {
       GPU_OK(cfdp_gpu_sync_group(grp->gpus, G));
@@ -325,9 +411,11 @@ void test_solver(comm_data *cd, solver_data *sd, int NTHREADS) {
   printf("                                 NITER: %d\n", sd->niter);
   printf("                              N_MEDIAN: %d\n", N_MEDIAN);
   printf("\n*** TIMINGS\n");
-  for (int v = 0; v < nvar; v++) {
+  for (int v = 0; v < N_SOLVER; v++) {
     qsort(median[v], N_MEDIAN, sizeof(double), cmp_double);
     printf("%38s: %10.6f\n", names[v], median[v][N_MEDIAN / 2]);
   }
+  printf("\n*** GPU SCHEDULE OF EACH ROW (xGMI exchange in place of MPI / GASPI)\n");
+  for (int v = 0; v < N_SOLVER; v++) printf("%38s: %s%s\n", names[v], how[v], v && single ? " (not run: one domain)" : "");
   fflush(stdout);
 }

@@ -222,6 +222,24 @@ int cfdp_ncfile_dimlen(const cfdp_ncfile *f, const char *name, size_t *len) {
   return CFDP_NC_ENOTFOUND;
 }
 
+/* id-based access for the nc_inq_* entry points (ids = positions in the header lists, as in libnetcdf) */
+int cfdp_ncfile_dimid(const cfdp_ncfile *f, const char *name) {
+  for (int i = 0; i < f->ndims; i++)
+    if (strcmp(f->dims[i].name, name) == 0) return i;
+  return CFDP_NC_ENOTFOUND;
+}
+int cfdp_ncfile_varid(const cfdp_ncfile *f, const char *name) {
+  for (int i = 0; i < f->nvars; i++)
+    if (strcmp(f->vars[i].name, name) == 0) return i;
+  return CFDP_NC_ENOTFOUND;
+}
+const char *cfdp_ncfile_dimname(const cfdp_ncfile *f, int dimid) {
+  return dimid >= 0 && dimid < f->ndims ? f->dims[dimid].name : NULL;
+}
+const char *cfdp_ncfile_varname(const cfdp_ncfile *f, int varid) {
+  return varid >= 0 && varid < f->nvars ? f->vars[varid].name : NULL;
+}
+
 static const ncvar *find_var(const cfdp_ncfile *f, const char *name) {
   for (int i = 0; i < f->nvars; i++)
     if (strcmp(f->vars[i].name, name) == 0) return &f->vars[i];

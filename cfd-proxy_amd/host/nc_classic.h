@@ -35,6 +35,11 @@ void cfdp_ncfile_close(cfdp_ncfile *f);
 const char *cfdp_nc_strerror(int code);
 int  cfdp_ncfile_dimlen(const cfdp_ncfile *f, const char *name, size_t *len);
 int  cfdp_ncfile_varinfo(const cfdp_ncfile *f, const char *name, int *type, size_t *nelems);
+/* ids = positions in the header's dimension / variable lists; negative = CFDP_NC_ENOTFOUND */
+int  cfdp_ncfile_dimid(const cfdp_ncfile *f, const char *name);
+int  cfdp_ncfile_varid(const cfdp_ncfile *f, const char *name);
+const char *cfdp_ncfile_dimname(const cfdp_ncfile *f, int dimid);
+const char *cfdp_ncfile_varname(const cfdp_ncfile *f, int varid);
 /* read a whole variable, converting to the requested C type (int32 / double) */
 int  cfdp_ncfile_get_int(cfdp_ncfile *f, const char *name, int *out);
 int  cfdp_ncfile_get_double(cfdp_ncfile *f, const char *name, double *out);

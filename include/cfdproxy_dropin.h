@@ -118,11 +118,33 @@ typedef struct {
   void *group;                 /* cfdp_group* shared by the G comm_data of a process    */
 } comm_data;
 
-/* ---- loader: reference src/read_netcdf.h:4-6 (libnetcdf replaced by our own reader).
- * `ncid` is a handle from cfdp_nc_open().  Failure: message + exit(2), like ERR()
- * in reference src/error_handling.h:4-10.                                              */
-int  cfdp_nc_open(const char *path);              /* replaces nc_open  (hybrid.f6.c:65) */
-void cfdp_nc_close(int ncid);                     /* replaces nc_close (hybrid.f6.c:91) */
+/* ---- loader, libnetcdf's own entry points: the eight calls the reference makes
+ * (src/hybrid.f6.c:65,91 + ERR() of src/error_handling.h:4-10: nc_open, nc_close, nc_strerror;
+ * src/read_netcdf.c:25,28,38,41,53,56: nc_inq_dimid, nc_inq_dimlen, nc_inq_varid, nc_get_var_int,
+ * nc_get_var_double), with libnetcdf's signatures and return convention (0 = NC_NOERR, else a code
+ * nc_strerror() explains), backed by our own NetCDF-classic reader.  The reference's hybrid.f6.c
+ * and read_netcdf.c link against this library unchanged (include/compat/ holds forwarding headers
+ * under the reference's header names).  Read-only: `mode` is ignored.                          */
+#ifndef NC_NOWRITE
+#define NC_NOWRITE 0
+#endif
+#ifndef NC_NOERR
+#define NC_NOERR 0
+#endif
+int nc_open(const char *path, int mode, int *ncidp);
+int nc_close(int ncid);
+const char *nc_strerror(int ncerr);
+int nc_inq_dimid(int ncid, const char *name, int *idp);
+int nc_inq_dimlen(int ncid, int dimid, size_t *lenp);
+int nc_inq_varid(int ncid, const char *name, int *varidp);
+int nc_get_var_int(int ncid, int varid, int *ip);
+int nc_get_var_double(int ncid, int varid, double *ip);
+
+/* ---- loader: reference src/read_netcdf.h:4-6.  `ncid` is a handle from nc_open() /
+ * cfdp_nc_open().  Failure: message + exit(2), like ERR() in reference
+ * src/error_handling.h:4-10.  cfdp_nc_open/_close = nc_open/nc_close with that ERR() built in. */
+int  cfdp_nc_open(const char *path);
+void cfdp_nc_close(int ncid);
 void get_nc_double(int ncid, const char *name, double *array);
 void get_nc_int(int ncid, const char *name, int *array);
 int  get_nc_val(int ncid, const char *name);      /* value = a DIMENSION length         */
@@ -167,6 +189,14 @@ void compute_psd_flux(solver_data *sd);
 /* ---- reference src/solver.h:7: the timing harness (25 samples x NITER iterations,
  * median in seconds per NITER iterations, reference src/solver.c:32-33,302-311).       */
 void test_solver(comm_data *cd, solver_data *sd, int NTHREADS);
+
+/* ---- the helpers the reference's main() and harness take from its util/error modules:
+ * f_exist (src/error_handling.h:52, used at src/hybrid.f6.c:64), now (src/util.h:27: wall-clock
+ * seconds, src/solver.c:43), sort_median (src/util.h:19; `end` is EXCLUSIVE as in src/util.c:61-78,
+ * so test_solver's call sorts samples 0..23 -- kept, it is what the reference prints).         */
+int f_exist(char *fname);
+double now(void);
+void sort_median(double *begin, double *end);
 
 /* ---- ext: moving results across the boundary (the reference never reads a value back;
  * parity needs it).  Copies device grad / psd_flux into sd->grad / sd->psd_flux in FILE

@@ -1,0 +1,4 @@
+/* include/compat/gradients.h -- forwarding header: lets host code written against the reference's
+ * header names (src/gradients.h) compile unchanged against the drop-in boundary.
+ * Use: cc -Iinclude/compat -Iinclude ... -lcfdproxy_hip */
+#include "../cfdproxy_dropin.h"

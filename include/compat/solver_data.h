@@ -1,0 +1,4 @@
+/* include/compat/solver_data.h -- forwarding header: lets host code written against the reference's
+ * header names (src/solver_data.h) compile unchanged against the drop-in boundary.
+ * Use: cc -Iinclude/compat -Iinclude ... -lcfdproxy_hip */
+#include "../cfdproxy_dropin.h"

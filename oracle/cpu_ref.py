@@ -3,9 +3,10 @@
 ORACLE = TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
 `cpu_baseline` leg may import this module; the product (cfd-proxy_amd/) never does.
 
-Parity pin: cpu_ref.c is validated against the COMPILED reference (oracle/_ref/ref_dump,
-built by oracle/Makefile from /root/reference/src) through tests/golden/*.npz
-(tests/test_oracle_golden.py).  The reference has no tests or golden vectors of its own.
+Parity pin: cpu_ref.c is validated against the COMPILED reference (oracle/_ref/ref_dump_raw,
+built by oracle/Makefile from /root/reference/src + our raw-array driver, no product code on
+its link line) through tests/golden/*.npz (tests/test_oracle_golden.py).  The reference has
+no tests or golden vectors of its own.
 """
 from __future__ import annotations
 
@@ -55,7 +56,36 @@ def lib() -> C.CDLL:
 
 
 def ref_dump_path() -> str:
-    return os.path.join(_HERE, "_ref", "ref_dump")
+    return os.path.join(_HERE, "_ref", "ref_dump_raw")
+
+
+def write_raw_domain(prefix, domain, fpoint, fnormal, pvolume, nown, var=None, ndomains=1, commpartner=None,
+                     sendcount=None, recvcount=None, addpoint_owner=None, addpoint_id=None) -> str:
+    """One domain as the raw array file oracle/ref_dump_raw.c reads (layout in its header): the
+    arrays the reference's loaders would have taken from the NetCDF file, nothing else."""
+    fpoint = np.ascontiguousarray(fpoint, np.int32)
+    nall = len(pvolume)
+    multi = ndomains > 1
+    nadd = nall - int(nown) if multi else 0
+    ncomm = len(commpartner) if multi else 0
+    path = f"{prefix}_{domain}.raw"
+    with open(path, "wb") as fp:
+        np.array([0x43464450, len(fpoint), int(nown), nall, ndomains, nadd, ncomm, int(var is not None)],
+                 np.int32).tofile(fp)
+        fpoint.tofile(fp)
+        np.ascontiguousarray(fnormal, np.float64).tofile(fp)
+        np.ascontiguousarray(pvolume, np.float64).tofile(fp)
+        if var is not None:
+            v = np.ascontiguousarray(var, np.float64)
+            assert v.shape == (nall, 7)
+            v.tofile(fp)
+        if multi:
+            for a, n in ((commpartner, ncomm), (sendcount, ndomains), (recvcount, ndomains),
+                         (addpoint_owner, nadd), (addpoint_id, nadd)):
+                a = np.ascontiguousarray(a, np.int32)
+                assert len(a) == n, (len(a), n)
+                a.tofile(fp)
+    return path
 
 
 class CpuRef:

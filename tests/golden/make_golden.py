@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/*.npz with the COMPILED reference (oracle/_ref/ref_dump).
+"""Generate tests/golden/*.npz with the COMPILED reference (oracle/_ref/ref_dump_raw).
 
 Runs only where /root/reference exists (the build container).  Inputs are meshes from our
 own deterministic generator (the reference ships no meshes and no tests); the expected
 outputs are what the reference's own compute_gradients_gg_* / compute_psd_flux write into
-sd->grad / sd->psd_flux, dumped by oracle/ref_dump_main.c.  Each fixture stores inputs AND
-outputs, so tests never need the reference or the generator to agree with today's code.
+sd->grad / sd->psd_flux, dumped by oracle/ref_dump_raw.c -- a binary whose link line holds the
+reference's translation units, that driver, MPICH and libm, and nothing of the product: the
+input arrays reach it as raw files written below from the numpy arrays the fixture stores.
+Each fixture stores inputs AND outputs, so tests never need the reference or the generator to
+agree with today's code.
 
     python tests/golden/make_golden.py
 """
@@ -18,11 +21,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from __graft_entry__ import build, load_package  # noqa: E402
+from __graft_entry__ import build, load_oracle, load_package  # noqa: E402
 
 MPIEXEC = "/opt/conda/bin/mpiexec"
-REF = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
-OUT = os.path.dirname(os.path.abspath(__file__))
+REF = os.path.join(ROOT, "oracle", "_ref", "ref_dump_raw")
+OUT = os.environ.get("GOLDEN_OUT", os.path.dirname(os.path.abspath(__file__)))
 
 CASES = [
     # name, dims, ndomains, ghost_faces, connectivity, var kind, [(variant, ranks, threads)]
@@ -39,8 +42,9 @@ CASES = [
 def main():
     build()
     pkg = load_package()
+    orc = load_oracle()
     if not os.path.exists(REF):
-        raise SystemExit("oracle/_ref/ref_dump missing (needs /root/reference)")
+        raise SystemExit("oracle/_ref/ref_dump_raw missing (needs /root/reference)")
     for name, dims, nd, gf, conn, vk, runs in CASES:
         gp = pkg.gen_params(*dims, ndomains=nd, ghost_faces=gf, connectivity=conn,
                             normals=0 if conn == 3 else 1, volumes=0 if conn == 3 else 1)
@@ -54,7 +58,6 @@ def main():
                 dom = pkg.load_domain(prefix, d, 2)
                 gid = pkg.gen_global_ids(gp, d, dom.nall)
                 pkg.fill_var(dom, gid, kind, *dims)
-                dom.var.tofile(os.path.join(tmp, f"var_{d}.bin"))
                 fx[f"d{d}_fpoint"] = dom.fpoint.copy()
                 fx[f"d{d}_fnormal"] = dom.fnormal.copy()
                 fx[f"d{d}_pvolume"] = dom.pvolume.copy()
@@ -68,20 +71,29 @@ def main():
                     fx[f"d{d}_sendcount"] = np.array([dom.cd.sendcount[k] for k in range(nd)], np.int32)
                     fx[f"d{d}_recvcount"] = np.array([dom.cd.recvcount[k] for k in range(nd)], np.int32)
                 doms.append(dom)
+            # the reference binary sees these arrays and nothing else (no dualgrid file, no loader of ours)
+            for d in range(nd):
+                comm = {} if nd == 1 else dict(
+                    commpartner=fx[f"d{d}_commpartner"], sendcount=fx[f"d{d}_sendcount"],
+                    recvcount=fx[f"d{d}_recvcount"], addpoint_owner=fx[f"d{d}_addpoint_owner"],
+                    addpoint_id=fx[f"d{d}_addpoint_idx"])
+                orc.write_raw_domain(os.path.join(tmp, "raw"), d, fx[f"d{d}_fpoint"], fx[f"d{d}_fnormal"],
+                                     fx[f"d{d}_pvolume"], fx[f"d{d}_nown"],
+                                     var=None if vk == "one" else fx[f"d{d}_var"], ndomains=nd, **comm)
+            raw = os.path.join(tmp, "raw")
             for variant, ranks, threads in runs:
                 env = dict(os.environ, OMP_NUM_THREADS=str(threads))
                 outp = os.path.join(tmp, f"out_{variant.replace(':', '_')}_{threads}")
-                var_arg = os.path.join(tmp, "var") if vk != "one" else "-"
                 if variant.startswith("alone:"):
                     d0 = int(variant.split(":")[1])
                     env["REF_DUMP_DOMAIN"] = str(d0)
-                    cmd = [REF, "dump", prefix, "2", "comm_free", var_arg, outp]
+                    cmd = [REF, "dump", raw, "comm_free", outp]
                     which = [d0]
                 elif ranks == 1:
-                    cmd = [REF, "dump", prefix, "2", variant, var_arg, outp]
+                    cmd = [REF, "dump", raw, variant, outp]
                     which = [0]
                 else:
-                    cmd = [MPIEXEC, "-n", str(ranks), REF, "dump", prefix, "2", variant, var_arg, outp]
+                    cmd = [MPIEXEC, "-n", str(ranks), REF, "dump", raw, variant, outp]
                     which = list(range(ranks))
                 r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
                 if r.returncode:

@@ -104,3 +104,37 @@ def test_integration_md_host_program_compiles_and_links(tmp_path):
                         "-Wl,-rpath," + os.path.join(root, "cfd-proxy_amd", "lib"), "-Wl,--allow-shlib-undefined",
                         "-o", str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_omp_test_host_compiles_and_links(tmp_path):
+    """tests/host_omp_driver.c (every OpenMP thread calls the entry points, src/solver.c:45-55) builds against
+    the drop-in header and library with -Wall -Werror; it runs in the GPU suite"""
+    import subprocess
+    lib = os.path.join(ROOT, "cfd-proxy_amd", "lib")
+    r = subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror", "-fopenmp", os.path.join(ROOT, "tests", "host_omp_driver.c"),
+                        "-I" + os.path.join(ROOT, "include"), "-L" + lib, "-lcfdproxy_hip", "-Wl,-rpath," + lib,
+                        "-Wl,--allow-shlib-undefined", "-o", str(tmp_path / "host")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/hybrid.f6.c"), reason="needs the reference checkout")
+def test_reference_main_links_unchanged_against_the_dropin(tmp_path):
+    """src/hybrid.f6.c:54-91 -- nc_open(fname, NC_NOWRITE, &ncid), ERR() -> nc_strerror, f_exist, nc_close -- is
+    compiled where it lies (stdin, so its #include "..." lines find include/compat/) and linked against the product
+    library; without a GPU it gets as far as init_threads and stops with the library's message"""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "hybrid.f6.dropin")
+    assert os.path.exists(exe), "make -C oracle builds it"
+    nm = subprocess.run(["nm", "-u", exe], capture_output=True, text=True).stdout
+    for sym in ("nc_open", "nc_close", "nc_strerror", "f_exist", "read_solver_data", "init_threads", "test_solver"):
+        assert sym in nm, sym
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    if pkg.hip_lib().cfdp_gpu_device_count() > 0:
+        pytest.skip("a GPU is present: the GPU suite runs the binary to the end")
+    gp = pkg.gen_params(6, 6, 6, ndomains=1)
+    pkg.write_mesh(gp, str(tmp_path / "dualgrid"), 2)
+    # (relative prefix: the reference's main() builds the file name in a char[80], src/hybrid.f6.c:57-62)
+    r = subprocess.run([exe, "-lvl", "2", "dualgrid"], env=dict(os.environ, OMP_NUM_THREADS="2"), cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "no HIP device" in r.stderr, r.stdout + r.stderr

@@ -371,6 +371,74 @@ def test_dropin_entry_points_in_reference_call_order(gpu, orc, tmp_path):
     lib.cfdp_nc_close(ncid)
 
 
+def _build_omp_host(tmp_path):
+    exe = str(tmp_path / "host_omp_driver")
+    lib = os.path.join(ROOT, "cfd-proxy_amd", "lib")
+    r = subprocess.run(["gcc", "-std=gnu99", "-O1", "-Wall", "-Werror", "-fopenmp", os.path.join(ROOT, "tests", "host_omp_driver.c"),
+                        "-I" + os.path.join(ROOT, "include"), "-L" + lib, "-lcfdproxy_hip", "-Wl,-rpath," + lib,
+                        "-Wl,--allow-shlib-undefined", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.mark.parametrize("fusion", ["1", "0"])
+def test_entry_points_called_by_every_thread_of_an_omp_region(gpu, orc, tmp_path, fusion):
+    """the reference calls compute_gradients_gg_* / compute_psd_flux from EVERY thread of one omp parallel
+    region (src/solver.c:45-55).  A C host does exactly that with 4 threads, for all ten variant names; the
+    values of each must be those of the oracle -- once, not four times, and not zero times"""
+    pkg = gpu
+    gp = pkg.gen_params(14, 12, 10, ndomains=1)
+    prefix = str(tmp_path / "dualgrid")
+    pkg.write_mesh(gp, prefix, 2)
+    exe = _build_omp_host(tmp_path)
+    out = str(tmp_path / "out")
+    r = subprocess.run([exe, prefix, "2", "3", out], env=dict(os.environ, OMP_NUM_THREADS="4", CFDP_FUSION=fusion),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "*** SUCCESS" in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("threads 4") == 10, r.stdout
+    dom = pkg.load_domain(prefix, 0, 2)
+    fp, fn_, vol, nown, nall = dom.fpoint.copy(), dom.fnormal.copy(), dom.pvolume.copy(), dom.nown, dom.nall
+    dom.free()
+    var = 1.0 + 0.01 * ((7 * np.arange(nall)[:, None] + 13 * np.arange(7)[None, :]) % 101)
+    ref = orc.CpuRef(fp, fn_, vol, nown, nthreads=2)
+    g_ref = ref.gradients(var)
+    f_ref = ref.flux(g_ref, mode=0)
+    ref.close()
+    for v in ("comm_free", "mpi_bulk_sync", "mpi_early_recv", "mpi_async", "gaspi_bulk_sync", "gaspi_async",
+              "mpifence_bulk_sync", "mpifence_async", "mpipscw_bulk_sync", "mpipscw_async"):
+        g = np.fromfile(f"{out}_{v}_grad.bin").reshape(nall, 7, 3)
+        f = np.fromfile(f"{out}_{v}_flux.bin").reshape(nall, 3)
+        assert rel_err(orc, g, g_ref, fp, fn_, vol, var, nown) <= TOL, v
+        assert np.abs(f - f_ref)[:nown].max() <= TOL * np.abs(f_ref[:nown]).max(), v
+
+
+REF_MAIN = os.path.join(ROOT, "oracle", "_ref", "hybrid.f6.dropin")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="oracle/_ref/hybrid.f6.dropin is built where /root/reference exists")
+def test_reference_main_compiled_unchanged_runs_on_the_dropin(gpu, tmp_path):
+    """the reference's own main() (src/hybrid.f6.c, compiled unchanged against include/compat/) on the drop-in
+    library: loader through nc_open/nc_close, init_threads, test_solver's ten TIMINGS rows, *** SUCCESS"""
+    pkg = gpu
+    gp = pkg.gen_params(20, 16, 12, ndomains=1)
+    prefix = str(tmp_path / "dualgrid")
+    pkg.write_mesh(gp, prefix, 2)
+    # (relative prefix: the reference's main() builds the file name in a char[80], src/hybrid.f6.c:57-62)
+    r = subprocess.run([REF_MAIN, "-lvl", "2", "dualgrid"], env=dict(os.environ, OMP_NUM_THREADS="4"), cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "*** SUCCESS" in r.stdout, r.stdout + r.stderr
+    rows = [ln.split(":")[0].strip() for ln in r.stdout.split("*** TIMINGS")[1].split("***")[0].splitlines() if ":" in ln]
+    assert rows == ["comm_free", "exchange_dbl_mpi_bulk_sync", "exchange_dbl_mpi_early_recv", "exchange_dbl_mpi_async",
+                    "exchange_dbl_gaspi_bulk_sync", "exchange_dbl_gaspi_async", "exchange_dbl_mpi_fence_bulk_sync",
+                    "exchange_dbl_mpi_fence_async", "exchange_dbl_mpi_pscw_bulk_sync", "exchange_dbl_mpi_pscw_async"], rows
+    t = float(r.stdout.split("comm_free:")[1].split()[0])
+    assert 0.0 < t < 1.0, t
+    # and the loader's error path as the reference's ERR() prints it (src/error_handling.h:4-10)
+    r = subprocess.run([REF_MAIN, "-lvl", "3", "dualgrid"], capture_output=True, text=True, timeout=60, cwd=str(tmp_path),
+                       env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode != 0 and "f_exist" in r.stderr
+
+
 def test_driver_binary_with_reference_cli(gpu, tmp_path):
     """bin/hybrid.f6.hip -lvl L PREFIX: 4 domain files, 2 in-process ranks on this GPU"""
     pkg = gpu

@@ -128,21 +128,58 @@ def test_known_answer_linear_field_cartesian(orc):
         assert np.abs(g[interior, eq, :] - slope).max() <= 1e-11
 
 
-@pytest.mark.skipif(not (os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_dump")) and
-                         os.path.exists("/root/reference/src/gradients.c")),
-                    reason="compiled reference only exists in the build container")
-def test_live_reference_agrees_with_fixture(pkg):
-    """where the compiled reference is available, re-run it and compare with the committed fixture"""
+REF_RAW = os.path.join(ROOT, "oracle", "_ref", "ref_dump_raw")
+needs_ref = pytest.mark.skipif(not (os.path.exists(REF_RAW) and os.path.exists("/root/reference/src/gradients.c")),
+                               reason="compiled reference only exists in the build container")
+
+
+def test_reference_binary_links_no_product_code():
+    """the pin: oracle/_ref/ref_dump_raw = reference translation units + oracle/ref_dump_raw.c; the
+    recipe names nothing under cfd-proxy_amd/ and the binary holds no NetCDF reader of any kind"""
+    mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+    recipe = mk[mk.index("_ref/ref_dump_raw: "):mk.index("else\nref:")]
+    assert "cfd-proxy_amd" not in recipe and "nc_classic" not in recipe and "dropin" not in recipe
+    if os.path.exists(REF_RAW):
+        r = subprocess.run(["nm", REF_RAW], capture_output=True, text=True)
+        assert r.returncode == 0
+        names = [ln.split()[-1] for ln in r.stdout.splitlines() if ln.strip()]
+        bad = [n for n in names if n.startswith(("nc_", "cfdp_", "get_nc_")) or n in ("read_solver_data", "read_communication_data")]
+        assert not bad, bad
+
+
+@needs_ref
+def test_live_reference_agrees_with_fixture(orc):
+    """where the compiled reference is available, re-run it on the fixture's stored input arrays
+    (raw files: no dualgrid file, no loader of ours) and compare with the committed outputs"""
     fx = load_golden("g1_7x6x5")
-    dom = golden_domain(pkg, fx, 0)
     with tempfile.TemporaryDirectory() as tmp:
-        dom.write(os.path.join(tmp, "dualgrid_domain_0_lvl_2"))
-        fx["d0_var"].tofile(os.path.join(tmp, "var_0.bin"))
+        raw = os.path.join(tmp, "raw")
+        orc.write_raw_domain(raw, 0, fx["d0_fpoint"], fx["d0_fnormal"], fx["d0_pvolume"], int(fx["d0_nown"]), var=fx["d0_var"])
         env = dict(os.environ, OMP_NUM_THREADS="2")
-        r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_dump"), "dump", os.path.join(tmp, "dualgrid"),
-                            "2", "comm_free", os.path.join(tmp, "var"), os.path.join(tmp, "out")],
+        r = subprocess.run([REF_RAW, "dump", raw, "comm_free", os.path.join(tmp, "out")],
                            env=env, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr
         g = np.fromfile(os.path.join(tmp, "out_grad_0.bin")).reshape(-1, 7, 3)
     assert np.array_equal(g, fx["grad_comm_free_t2_d0"])
-    dom.free()
+
+
+@needs_ref
+@pytest.mark.skipif(not os.path.exists("/opt/conda/bin/mpiexec"), reason="no mpiexec")
+def test_live_reference_two_domains_agrees_with_fixture(orc):
+    """the same for the exchanged case: 2 MPI ranks, mpi_bulk_sync, ghost rows included"""
+    fx = load_golden("g2_10x8x6")
+    with tempfile.TemporaryDirectory() as tmp:
+        raw = os.path.join(tmp, "raw")
+        for d in range(2):
+            orc.write_raw_domain(raw, d, fx[f"d{d}_fpoint"], fx[f"d{d}_fnormal"], fx[f"d{d}_pvolume"],
+                                 int(fx[f"d{d}_nown"]), var=fx[f"d{d}_var"], ndomains=2,
+                                 commpartner=fx[f"d{d}_commpartner"], sendcount=fx[f"d{d}_sendcount"],
+                                 recvcount=fx[f"d{d}_recvcount"], addpoint_owner=fx[f"d{d}_addpoint_owner"],
+                                 addpoint_id=fx[f"d{d}_addpoint_idx"])
+        env = dict(os.environ, OMP_NUM_THREADS="3")
+        r = subprocess.run(["/opt/conda/bin/mpiexec", "-n", "2", REF_RAW, "dump", raw, "mpi_bulk_sync",
+                            os.path.join(tmp, "out")], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        for d in range(2):
+            g = np.fromfile(os.path.join(tmp, f"out_grad_{d}.bin")).reshape(-1, 7, 3)
+            assert np.array_equal(g, fx[f"grad_mpi_bulk_sync_t3_d{d}"])
