@@ -448,7 +448,7 @@ def test_driver_binary_with_reference_cli(gpu, tmp_path):
     exe = os.path.join(ROOT, "cfd-proxy_amd", "bin", "hybrid.f6.hip")
     r = subprocess.run([exe, "-lvl", "2", prefix, "--gpus", "2", "--var", "hash"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "*** SUCCESS" in r.stdout and "comm_free:" in r.stdout and "exchange_dbl_xgmi_async:" in r.stdout
+    assert "*** SUCCESS" in r.stdout and "comm_free:" in r.stdout and "exchange_dbl_gaspi_async:" in r.stdout and "exchange_dbl_mpi_pscw_async:" in r.stdout
     r = subprocess.run([exe, "-lvl", "2", prefix, "--gpus", "2", "--var", "hash", "--cluster"], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
