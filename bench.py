@@ -1,26 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- Green-Gauss gradient iterations/s on the F6-like dualgrid stand-ins.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config NAME]   (N>1: launched by torch.distributed.run)
 
 One "step" = one iteration of the hot path as the reference harness times it
 (reference src/solver.c:48-54): Green-Gauss gradients over all faces (+ halo exchange of the
 168-byte gradient rows when N>1) + the pseudo-flux face loop.  Inputs are resident in HBM
 before the timed region starts.
 
-Workload (BASELINE.json configs; the real f6/dualgrid.N files are stripped from the reference
+Workloads = the BASELINE.json configs (the real f6/dualgrid.N files are stripped from the reference
 checkout, so deterministic stand-ins with the same schema are generated):
-  N=1: dualgrid.12 level-2 stand-in: 64^3 lattice, 12 domain files -> loader -> merged on one GPU
-  N=8: dualgrid.384 finest-level stand-in: 128^3 lattice, 384 domains, 48 per GPU
-  N=2,4: the same 262,144 owned points per GPU (128x64x64 / 128x128x64, 12 domains per GPU)
-so per-GPU work is fixed ("scaling": "weak") and `value` counts 262,144-point partition
-iterations per second summed over GPUs (= iterations/s of the whole mesh x N).
+
+  --config        mesh          domains      default for   scaling
+  dualgrid.12     64^3  lvl 2   12           --gpus 1      (anchor of the strong series)
+  dualgrid.24     64^3  lvl 2   24           --gpus 2      strong (the same level-2 mesh, 12 domains per GPU)
+  dualgrid.48     64^3  lvl 2   48           --gpus 4      strong (BASELINE config 3)
+  dualgrid.192    64^3  lvl 2   192          (--gpus 8)    strong (BASELINE config 4: ~33 k points per GPU)
+  dualgrid.384    128^3 finest  384          --gpus 8      weak vs --gpus 1: 262,144 points per GPU (config 5)
+  weak            262,144 owned points per GPU at every N (128x64x64 / 128x128x64 for 2 / 4 GPUs)
+
+`value` is the whole-job rate in units of one level-2 mesh: iterations/s of the mesh x (mesh points /
+262,144) -- so the strong series (64^3 on 1, 2, 4 GPUs) and the weak point (128^3 on 8) read on one
+scale, and value(N) / (N x value(1)) is the scaling efficiency either way.  With --gpus 2 / 4 the line
+also carries the weak-scaling measurement of the same run under "weak_scaling".
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+UNIT_POINTS = 262144   # one level-2 mesh (64^3 stand-in of dualgrid.* lvl 2)
 
 
 def usable_cores() -> int:
@@ -54,11 +64,46 @@ def usable_cores() -> int:
     return min(n, 64)
 
 
+def kernel_source_tag() -> str:
+    """identifies the kernel build a committed PMC measurement belongs to"""
+    h = hashlib.sha256()
+    for f in ("cfd-proxy_amd/csrc/gg_kernels.hip", "cfd-proxy_amd/host/tiling.c"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(workload_key: str):
+    """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes
+    with the gfx950 corrections of MI355X_MICROARCH.md: tools/measure_traffic.py).  PMC passes cannot run
+    inside this process, so the figures are read from the newest committed profiles/rNN_traffic.json and
+    labelled with where they come from and whether the kernels have changed since."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return {}, None
+    path = files[-1]
+    try:
+        tr = json.load(open(path))
+    except Exception:
+        return {}, None
+    src = {"file": os.path.relpath(path, ROOT), "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE, separate passes",
+           "kernel_source_tag": tr.get("kernel_source_tag"),
+           "stale": tr.get("kernel_source_tag") != kernel_source_tag()}
+    out = {}
+    for k, v in tr.get(workload_key, {}).items():
+        for name in ("gg_gradient", "gg_flux", "gg_fused"):
+            if name in k:
+                out[name] = v["traffic_bytes"]
+    return out, src
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--config", default="", help="dualgrid.12 | dualgrid.24 | dualgrid.48 | dualgrid.192 | dualgrid.384 | weak "
+                                                 "(default by --gpus: 1 -> .12, 2 -> .24, 4 -> .48, 8 -> .384)")
     ap.add_argument("--tile-points", type=int, default=0)
     ap.add_argument("--grad-lanes", type=int, default=0)
     ap.add_argument("--flux-lanes", type=int, default=0)
@@ -67,6 +112,7 @@ def main() -> None:
     ap.add_argument("--no-files", action="store_true", help="generate domains in memory (skip the loader)")
     ap.add_argument("--no-finest", action="store_true", help="skip the finest-level single-GPU roofline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--no-weak", action="store_true", help="skip the extra weak-scaling measurement at --gpus 2 / 4")
     ap.add_argument("--cpu-samples", type=int, default=7)
     ap.add_argument("--transport", default="auto", choices=["auto", "ipc", "rccl", "torch", "staged"],
                     help="auto: set up ipc and rccl, time both briefly, keep the faster; ipc: xGMI write + notify "
@@ -100,162 +146,197 @@ def main() -> None:
         backend = "gloo" if args.transport == "staged" or os.environ.get("CFDP_SHARED_GPU") == "1" else "nccl"
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 device_id=torch.device("cuda", device) if backend == "nccl" else None)
+    coll_device = torch.device("cuda", device) if dist is not None and dist.get_backend() == "nccl" else "cpu"
 
-    dims, ndom = mg.bench_mesh(world)
-    gp = pkg.gen_params(*dims, ndomains=ndom)
-    t0 = time.time()
-    part, st = mg.build_rank_partition(gp, ndom, world, rank, via_files=not args.no_files)
-    mg.exchange_requests(part, rank, world, dist)
-    nfaces_part, nown, nadd = part.nfaces, part.nown, part.nall - part.nown
-    solver = mg.RankSolver(part, rank, world, device, dist, transport=args.transport,
-                           tile_points=args.tile_points, grad_lanes=args.grad_lanes, flux_lanes=args.flux_lanes,
-                           fusion=not args.no_fusion)
-    if world > 1 and args.transport == "auto":
-        solver.choose_transport()
-    t_setup = time.time() - t0
-    coll_device = solver.device if dist is not None and dist.get_backend() == "nccl" else "cpu"
+    def measure(cfg: dict, keep_solver: bool = False):
+        """set-up, W untimed + exactly K timed steps (max over ranks), exchange check, overlap report"""
+        dims, ndom = cfg["dims"], cfg["ndomains"]
+        gp = pkg.gen_params(*dims, ndomains=ndom)
+        t0 = time.time()
+        part, _ = mg.build_rank_partition(gp, ndom, world, rank, via_files=not args.no_files)
+        mg.exchange_requests(part, rank, world, dist)
+        nfaces_part, nown, nadd = part.nfaces, part.nown, part.nall - part.nown
+        solver = mg.RankSolver(part, rank, world, device, dist, transport=args.transport,
+                               tile_points=args.tile_points, grad_lanes=args.grad_lanes, flux_lanes=args.flux_lanes,
+                               fusion=not args.no_fusion)
+        if world > 1 and args.transport == "auto":
+            solver.choose_transport()
+        t_setup = time.time() - t0
 
-    def barrier():
-        solver.synchronize()
-        if dist is not None:
-            dist.barrier()
-        solver.synchronize()
+        def barrier():
+            solver.synchronize()
+            if dist is not None:
+                dist.barrier()
+            solver.synchronize()
 
-    def timed(steps: int, **kw) -> float:
-        """seconds for exactly `steps` steps, max over ranks"""
+        def timed(steps: int, **kw) -> float:
+            """seconds for exactly `steps` steps, max over ranks.  The hipGraphs the run replays are
+            built before the timed region: captured without executing (one partition), or by one untimed
+            rehearsal of the same schedule (several ranks: a capture there includes the exchange kernels)"""
+            if world == 1:
+                solver.gpu.prepare_iterations(steps, with_flux=True)
+            else:
+                solver.run_steps(steps if steps <= 5000 else 100 + steps % 50, **kw)
+            barrier()
+            t = time.perf_counter()
+            if world == 1:
+                solver.gpu.run_iterations(steps, with_flux=True, use_graph=True)
+            else:
+                solver.run_steps(steps, **kw)
+            solver.synchronize()
+            barrier()
+            dt = time.perf_counter() - t
+            if dist is not None:
+                tt = torch.tensor([dt], dtype=torch.float64, device=coll_device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            return dt
+
+        def exchange_check() -> dict:
+            """every row that was sent must have arrived in ITS slot: per partner slice, a position-weighted
+            checksum of the packed send rows must equal the partner's checksum of the ghost rows it received
+            from this rank (row j of a message weighs j+1, so permuted or mis-slotted rows do not cancel);
+            and something must have been sent at all"""
+            solver.synchronize()
+            g = solver.grad_host()
+            mine = {}
+            for k in part.partners:
+                sidx, ridx = part.sendindex(k), part.recvindex(k)
+                ws, wr = np.arange(1, len(sidx) + 1.0), np.arange(1, len(ridx) + 1.0)
+                mine[int(k)] = (float((np.abs(g[sidx]).sum(axis=(1, 2)) * ws).sum()), float(np.abs(g[sidx]).sum()),
+                                float((np.abs(g[ridx]).sum(axis=(1, 2)) * wr).sum()))
+            allc = [None] * world
+            dist.all_gather_object(allc, mine)
+            ok, sent_total, worst = True, 0.0, 0.0
+            for a in range(world):
+                for b, (ws_ab, s_ab, _) in allc[a].items():
+                    got = allc[b].get(a, (0.0, 0.0, float("nan")))[2]  # what b received from a
+                    sent_total += s_ab
+                    rel = abs(ws_ab - got) / max(abs(ws_ab), 1e-300)
+                    worst = max(worst, rel if rel == rel else float("inf"))
+                    ok = ok and rel <= 1e-9
+            chk = {"sum_abs_sent_rows": sent_total, "worst_partner_slice_mismatch": worst,
+                   "check": "position-weighted |row| sums per partner slice, sender vs receiver",
+                   "ok": bool(ok and sent_total > 0.0)}
+            if solver.transport == "ipc":
+                et = torch.tensor([float(solver.gpu.ipc_error() != 0)], dtype=torch.float64, device=coll_device)
+                dist.all_reduce(et)
+                chk["wait_timeouts"] = int(et.item())
+                chk["ok"] = chk["ok"] and int(et.item()) == 0
+            return chk
+
+        # warmup (untimed), then EXACTLY K timed steps; a transport whose rows did not all arrive is dropped
+        # and the measurement repeated on the next one (every rank sees the same gathered check)
+        rejected, chk = [], None
+        while True:
+            if world == 1:
+                solver.gpu.run_iterations(max(args.warmup, 1), with_flux=True, use_graph=True)
+            else:
+                solver.run_steps(max(args.warmup, 1), with_exchange=True, overlap=True)
+            dt = timed(args.steps, with_exchange=True, overlap=True)
+            if world == 1:
+                break
+            chk = exchange_check()
+            if os.environ.get("CFDP_BENCH_REJECT_FIRST") == "1" and not rejected:
+                chk["ok"] = False  # test hook: exercises the fall-back below
+            if chk["ok"]:
+                break
+            rejected.append(solver.transport)
+            if not solver.fallback():
+                break
+        its = args.steps / dt  # iterations/s of the whole mesh
+        mesh_points = dims[0] * dims[1] * dims[2]
+        res = {
+            "value": its * mesh_points / UNIT_POINTS, "ms_per_step": dt / args.steps * 1e3, "scaling": cfg["scaling"],
+            "config": {
+                "workload": cfg["workload"], "baseline_config": cfg["name"],
+                "mesh_points": mesh_points, "domains": ndom, "domains_per_gpu": ndom // world,
+                "points_per_gpu": nown, "faces_per_gpu": nfaces_part, "ghost_points_per_gpu": nadd,
+                "iteration": "gradients + halo exchange + pseudo flux",
+                "fused_iterations": not args.no_fusion,
+                "transport": solver.transport if world > 1 else "none (one partition)",
+                "transport_probe_us_per_iteration": solver.probe if world > 1 else {},
+                "mesh_iterations_per_s": its, "via_dualgrid_files": not args.no_files,
+                "tiles": solver.gpu.stats["ntiles"], "tile_points": solver.gpu.stats["tile_points"],
+                "setup_s": round(t_setup, 2),
+            },
+        }
         if world > 1:
-            solver.run_steps(56, **kw)  # untimed: the hipGraph of this schedule is captured here, not in the timed region
-        barrier()
-        t = time.perf_counter()
-        if world == 1:
-            solver.gpu.run_iterations(steps, with_flux=True, use_graph=True)  # hipGraph replay of 25-step chunks
-        else:
-            solver.run_steps(steps, **kw)
-        solver.synchronize()
-        barrier()
-        dt = time.perf_counter() - t
-        if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device=coll_device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt
+            res["exchange_check"] = chk
+            if rejected:
+                res["exchange_check"]["transports_rejected"] = rejected
+            # overlap efficiency (reference's own normalisation: comm_free / with exchange)
+            dt_free = timed(args.steps, with_exchange=False)
+            dt_bulk = timed(args.steps, with_exchange=True, overlap=False)
+            res["overlap"] = {"t_comm_free_ms": dt_free / args.steps * 1e3, "t_async_ms": res["ms_per_step"],
+                              "t_bulk_sync_ms": dt_bulk / args.steps * 1e3,
+                              "efficiency_async": dt_free / dt, "efficiency_bulk_sync": dt_free / dt_bulk}
+        if keep_solver:
+            return res, solver, part
+        solver.close()
+        part.free()
+        return res, None, None
 
-    def exchange_check() -> dict:
-        """every row that was sent must have arrived: sum over ranks of the ghost rows == sum over ranks
-        of the packed send rows (same doubles, so equal up to the order of the additions)"""
-        solver.synchronize()
-        g = solver.grad_host()
-        sidx = [part.sendindex(k) for k in part.partners]  # a point sent to two partners counts twice
-        sent = float(np.abs(g[np.concatenate(sidx)]).sum()) if sidx else 0.0
-        got = float(np.abs(g[part.nown:]).sum())
-        tt = torch.tensor([sent, got], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(tt)
-        chk = {"sum_abs_sent_rows": float(tt[0]), "sum_abs_ghost_rows": float(tt[1]),
-               "ok": bool(abs(float(tt[0]) - float(tt[1])) <= 1e-9 * max(float(tt[0]), 1e-300))}
-        if solver.transport == "ipc":
-            et = torch.tensor([float(solver.gpu.ipc_error() != 0)], dtype=torch.float64, device=coll_device)
-            dist.all_reduce(et)
-            chk["wait_timeouts"] = int(et.item())
-            chk["ok"] = chk["ok"] and int(et.item()) == 0
-        return chk
-
-    # warmup (untimed), then EXACTLY K timed steps; a transport whose rows did not all arrive is dropped
-    # and the measurement repeated on the next one (every rank sees the same all-reduced check)
-    rejected, chk = [], None
-    while True:
-        if world == 1:
-            solver.gpu.run_iterations(max(args.warmup, 1), with_flux=True, use_graph=True)
-        else:
-            solver.run_steps(max(args.warmup, 1), with_exchange=True, overlap=True)
-        dt = timed(args.steps, with_exchange=True, overlap=True)
-        if world == 1:
-            break
-        chk = exchange_check()
-        if os.environ.get("CFDP_BENCH_REJECT_FIRST") == "1" and not rejected:
-            chk["ok"] = False  # test hook: exercises the fall-back below
-        if chk["ok"]:
-            break
-        rejected.append(solver.transport)
-        if not solver.fallback():
-            break
-    ms_per_step = dt / args.steps * 1e3
-    its = args.steps / dt  # iterations/s of the whole mesh
+    cfg = mg.bench_config(args.config or mg.default_bench_config(world), world)
+    res, solver, part = measure(cfg, keep_solver=True)
+    nfaces_part, nown, nadd = part.nfaces, part.nown, part.nall - part.nown
 
     out = {
         "metric": "green_gauss_gradient_iterations_per_sec",
-        "value": its * world,
-        "unit": "iterations/s of one 262144-point (dualgrid.12 lvl-2 sized) partition, summed over GPUs",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "value": res["value"],
+        "unit": "iterations/s in units of one level-2 mesh (262144 points): mesh iterations/s x mesh points / 262144, whole job",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": res["scaling"], "vs_baseline": None, "dtype": "f64",
         "data": "synthetic (F6-like dualgrid stand-in; the f6/dualgrid.N files are not distributed)",
-        "config": {
-            "workload": {1: "dualgrid.12 lvl 2 stand-in (64^3, 12 domains merged on 1 GPU, no halo exchange)",
-                         8: "dualgrid.384 finest-level stand-in (128^3, 384 domains, 48 per GPU, halo exchange over xGMI)"}.get(
-                world, f"{dims[0]}x{dims[1]}x{dims[2]} lattice, {ndom} domains, {ndom // world} per GPU, halo exchange over xGMI"),
-            "mesh_points": dims[0] * dims[1] * dims[2], "points_per_gpu": nown, "faces_per_gpu": nfaces_part,
-            "ghost_points_per_gpu": nadd, "iteration": "gradients + halo exchange + pseudo flux",
-            "fused_iterations": not args.no_fusion,
-            "transport": solver.transport if world > 1 else "none (one partition)",
-            "transport_probe_us_per_iteration": solver.probe if world > 1 else {},
-            "mesh_iterations_per_s": its, "via_dualgrid_files": not args.no_files,
-            "tiles": solver.gpu.stats["ntiles"], "tile_points": solver.gpu.stats["tile_points"],
-            "setup_s": round(t_setup, 2),
-        },
+        "config": res["config"],
     }
+    for k in ("exchange_check", "overlap"):
+        if k in res:
+            out[k] = res[k]
 
-    if world > 1:
-        out["exchange_check"] = chk
-        if rejected:
-            out["exchange_check"]["transports_rejected"] = rejected
-
-    # ---- overlap efficiency (reference's own normalisation: comm_free / with exchange) ----
-    if world > 1:
-        dt_free = timed(args.steps, with_exchange=False)
-        dt_bulk = timed(args.steps, with_exchange=True, overlap=False)
-        out["overlap"] = {"t_comm_free_ms": dt_free / args.steps * 1e3, "t_async_ms": ms_per_step,
-                          "t_bulk_sync_ms": dt_bulk / args.steps * 1e3,
-                          "efficiency_async": dt_free / dt, "efficiency_bulk_sync": dt_free / dt_bulk}
-
-    # ---- roofline of the dominant kernel (gradient face loop), HIP events on its own stream ----
+    # ---- roofline of the dominant kernel, HIP events on the stream the kernels run on ----
+    # three fractions of the 8 TB/s peak side by side:
+    #   frac            SURVEY 8d algorithmic bytes (B_grad + B_flux for the fused pass: the reference streams the
+    #                   face data once per face loop) / launch time
+    #   frac_unique     the bytes one launch must move at least (the fused pass streams the face data ONCE:
+    #                   B_grad + B_flux - 32 F) / launch time
+    #   frac_traffic    HBM-side bytes from the PMC counters / launch time
     bg = pkg.algo_bytes_grad(nfaces_part, nown, nadd)
     bf = pkg.algo_bytes_flux(nfaces_part, nown, nadd)
     ms_g, ms_f = solver.gpu.time_kernels(500)
-    # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes,
-    # gfx950 corrections: tools/measure_traffic.py) of the same workload, committed under profiles/
-    traffic = None
-    if world == 1:
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            for k, v in tr["dualgrid.12 lvl 2 stand-in (64^3)"].items():
-                if "gg_gradient" in k:
-                    traffic = v["traffic_bytes"]
-        except Exception:
-            traffic = None
-    grad_k = {"kernel": "gg_gradient_dma_kernel", "achieved": bg / (ms_g * 1e-3) / 1e9,
-              "frac": bg / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-              "algorithmic_bytes_per_launch": bg, "us_per_launch": ms_g * 1e3}
-    flux_k = {"kernel": "gg_flux_dma_kernel", "achieved": bf / (ms_f * 1e-3) / 1e9, "us_per_launch": ms_f * 1e3,
-              "algorithmic_bytes_per_launch": bf}
+    traffic, traffic_src = ({}, None)
+    if world == 1 and cfg["name"] == "dualgrid.12":
+        traffic, traffic_src = committed_traffic("dualgrid.12 lvl 2 stand-in (64^3)")
+
+    def fracs(alg, uniq, tr, ms):
+        gbs = lambda b: b / (ms * 1e-3) / 1e9
+        return {"achieved": gbs(alg), "frac": gbs(alg) / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
+                "unique_bytes_per_launch": uniq, "frac_unique": gbs(uniq) / HBM_PEAK_GBS,
+                "traffic": tr, "frac_traffic": gbs(tr) / HBM_PEAK_GBS if tr else None, "us_per_launch": ms * 1e3}
+    grad_k = {"kernel": "gg_gradient_dma_kernel", **fracs(bg, bg, traffic.get("gg_gradient"), ms_g)}
+    flux_k = {"kernel": "gg_flux_dma_kernel", **fracs(bf, bf, traffic.get("gg_flux"), ms_f)}
     if args.no_fusion:
-        out["roofline"] = {"bound": "hbm", "kernel": grad_k["kernel"], "achieved": grad_k["achieved"],
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": grad_k["frac"], "traffic": traffic,
-                           "algorithmic_bytes_per_launch": bg, "us_per_launch": ms_g * 1e3, "flux_kernel": flux_k}
+        out["roofline"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", **grad_k, "flux_kernel": flux_k}
     else:
         # the timed loop runs the fused pass (flux(i) + gradients(i+1), tile data streamed once):
         # one launch does the work of one gradient launch and one flux launch
         ms_fu = solver.gpu.time_fused(1000)
-        ftraffic = None
-        if world == 1:
-            try:
-                for k, v in tr["dualgrid.12 lvl 2 stand-in (64^3)"].items():
-                    if "gg_fused" in k:
-                        ftraffic = v["traffic_bytes"]
-            except Exception:
-                ftraffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": "gg_fused_split_kernel", "achieved": (bg + bf) / (ms_fu * 1e-3) / 1e9,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (bg + bf) / (ms_fu * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "traffic": ftraffic, "algorithmic_bytes_per_launch": bg + bf, "us_per_launch": ms_fu * 1e3,
+        out["roofline"] = {"bound": "hbm", "kernel": "gg_fused_split_kernel", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           **fracs(bg + bf, bg + bf - 32.0 * nfaces_part, traffic.get("gg_fused"), ms_fu),
                            "gradient_kernel": grad_k, "flux_kernel": flux_k}
+    out["roofline"]["traffic_source"] = traffic_src
+
+    # ---- --gpus 2 / 4: the weak-scaling point of the same run (262,144 owned points per GPU) ----
+    if world in (2, 4) and cfg["name"] != "weak" and not args.no_weak:
+        solver.close()
+        part.free()
+        solver = part = None
+        try:
+            wres, _, _ = measure(mg.bench_config("weak", world))
+            out["weak_scaling"] = {k: wres[k] for k in ("value", "ms_per_step", "scaling", "config", "exchange_check", "overlap")
+                                   if k in wres}
+        except Exception as e:  # the extra must never cost the line
+            out["weak_scaling"] = {"error": repr(e)[:300]}
 
     if rank == 0 and world == 1:
         # ---- the truly HBM-bound single-GPU case: finest level (2.1 M points, 0.95 GB per pass) ----
@@ -274,19 +355,18 @@ def main() -> None:
                 fu1 = p1.time_fused(50)
             b1 = pkg.algo_bytes_grad(d1.nfaces, d1.nown, 0)
             b1f = pkg.algo_bytes_flux(d1.nfaces, d1.nown, 0)
-            out["finest_level"] = {"workload": "dualgrid.384 finest-level stand-in merged on 1 GPU (128^3)",
-                                   "points": d1.nown, "faces": d1.nfaces, "algorithmic_bytes_per_launch": b1,
-                                   "us_per_launch": g1 * 1e3, "achieved": b1 / (g1 * 1e-3) / 1e9,
-                                   "frac": b1 / (g1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "iterations_per_s": 1e3 / (fu1 if fu1 else g1 + f1), "flux_us_per_launch": f1 * 1e3,
-                                   "flux_achieved": b1f / (f1 * 1e-3) / 1e9}
+            tr1, _ = committed_traffic("dualgrid.384 finest-level stand-in (128^3)")
+            fl = {"workload": "dualgrid.384 finest-level stand-in merged on 1 GPU (128^3)", "points": d1.nown, "faces": d1.nfaces,
+                  "iterations_per_s": 1e3 / (fu1 if fu1 else g1 + f1),
+                  "gradient_kernel": fracs(b1, b1, tr1.get("gg_gradient"), g1), "flux_kernel": fracs(b1f, b1f, tr1.get("gg_flux"), f1)}
             if fu1:
-                out["finest_level"]["fused"] = {"us_per_launch": fu1 * 1e3, "algorithmic_bytes_per_launch": b1 + b1f,
-                                                "achieved": (b1 + b1f) / (fu1 * 1e-3) / 1e9,
-                                                "frac": (b1 + b1f) / (fu1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                fl["fused"] = fracs(b1 + b1f, b1 + b1f - 32.0 * d1.nfaces, tr1.get("gg_fused"), fu1)
+            out["finest_level"] = fl
             p1.close()
             d1.free()
-        # ---- CPU baseline: the oracle (a port of the reference's algorithm class) on the host cores ----
+        # ---- CPU baseline on the host cores: the COMPILED REFERENCE (oracle/_ref/ref_dump_raw: the
+        # reference's own OpenMP path, src/solver.c:42-58 comm_free loop + flux) when the binary is there,
+        # with the oracle's port of the same algorithm class beside it ----
         if not args.no_cpu:
             from __graft_entry__ import load_oracle
             orc = load_oracle()
@@ -296,35 +376,49 @@ def main() -> None:
             gsamples = sorted(ref.timed(part.var, niter=25, with_flux=False) for _ in range(3))
             ref.close()
             med = samples[len(samples) // 2]
-            out["cpu_baseline"] = {"value": 25.0 / med, "unit": "iterations/s", "cores": cores, "kind": "port",
-                                   "sample": f"same 64^3 merged mesh, {args.cpu_samples} samples x 25 iterations "
-                                             f"(gradients+flux), median; oracle/cpu_ref.c OpenMP",
-                                   "gradient_only_iterations_per_s": 25.0 / gsamples[len(gsamples) // 2]}
-            # the compiled reference itself (oracle/_ref/ref_dump, built in the build container from the
-            # reference's own sources, see oracle/Makefile), timed on the same mesh written as ONE
-            # dualgrid file; reported next to the port so that the two can be compared
-            ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+            port = {"value": 25.0 / med, "unit": "iterations/s", "cores": cores, "kind": "port",
+                    "sample": f"same 64^3 merged mesh, {args.cpu_samples} samples x 25 iterations "
+                              f"(gradients+flux), median; oracle/cpu_ref.c OpenMP, threads not bound",
+                    "gradient_only_iterations_per_s": 25.0 / gsamples[len(gsamples) // 2]}
+            out["cpu_baseline"] = port
+            ref_bin = orc.ref_dump_path()
             if os.path.exists(ref_bin):
                 import re
                 import subprocess
                 import tempfile
                 try:
+                    best = None
                     with tempfile.TemporaryDirectory() as tmp:
-                        part.write(os.path.join(tmp, "merged_domain_0_lvl_2"))
-                        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="true")
-                        r = subprocess.run([ref_bin, "time", os.path.join(tmp, "merged"), "2", str(args.cpu_samples), "1"],
-                                           env=env, capture_output=True, text=True, timeout=300)
-                    m = re.search(r"median_s=([0-9.]+)", r.stdout)
-                    if r.returncode == 0 and m:
-                        out["cpu_baseline"]["reference_binary"] = {
-                            "value": 25.0 / float(m.group(1)), "unit": "iterations/s", "cores": cores, "kind": "reference",
-                            "sample": f"compiled reference (comm_free, gradients+flux), {args.cpu_samples} samples x 25 "
-                                      f"iterations, median, same mesh as one dualgrid file"}
+                        raw = os.path.join(tmp, "merged")
+                        orc.write_raw_domain(raw, 0, part.fpoint, part.fnormal, part.pvolume, part.nown, var=part.var)
+                        # the reference spin-waits between its threads: where they are pinned matters on a box
+                        # that grants a share of a bigger host, so both placements are timed and the faster kept
+                        for bind in ("false", "true"):
+                            env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND=bind)
+                            for wf in (1, 0):
+                                r = subprocess.run([ref_bin, "time", raw, str(args.cpu_samples), str(wf)],
+                                                   env=env, capture_output=True, text=True, timeout=300)
+                                m = re.search(r"median_s=([0-9.]+)", r.stdout)
+                                if r.returncode == 0 and m:
+                                    v = 25.0 / float(m.group(1))
+                                    if wf and (best is None or v > best["value"]):
+                                        best = {"value": v, "omp_proc_bind": bind}
+                                    elif not wf and best is not None and best["omp_proc_bind"] == bind:
+                                        best["gradient_only_iterations_per_s"] = v
+                    if best:
+                        out["cpu_baseline"] = {
+                            "value": best["value"], "unit": "iterations/s", "cores": cores, "kind": "reference",
+                            "sample": f"compiled reference (oracle/_ref/ref_dump_raw: src/solver.c:42-58 comm_free loop + "
+                                      f"compute_psd_flux), same 64^3 merged mesh as one domain, {args.cpu_samples} samples x 25 "
+                                      f"iterations, median; OMP_PROC_BIND={best['omp_proc_bind']} (faster of false/true)",
+                            "gradient_only_iterations_per_s": best.get("gradient_only_iterations_per_s"),
+                            "port": port}
                 except Exception as e:  # the baseline is optional; the bench line must still print
                     out["cpu_baseline"]["reference_binary_error"] = str(e)[:200]
     if rank == 0:
         print(json.dumps(out))
-    solver.close()
+    if solver is not None:
+        solver.close()
     if dist is not None:
         dist.destroy_process_group()
 

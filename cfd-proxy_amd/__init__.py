@@ -239,6 +239,7 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_step_post.argtypes = [vp, C.c_int, C.c_int]
     lib.cfdp_gpu_time_kernels.argtypes = [vp, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]
     lib.cfdp_gpu_run_iterations.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]
+    lib.cfdp_gpu_prepare_iterations.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.cfdp_rccl_load.argtypes = [C.c_char_p]
     lib.cfdp_rccl_unique_id.argtypes = [vp]
     lib.cfdp_gpu_rccl_init.argtypes = [vp, vp, C.c_int, C.c_int, P(C.c_int)]
@@ -789,6 +790,10 @@ class GpuPartition:
         self._ck(self.lib.cfdp_gpu_run_iterations(self.h, iters, int(with_flux), flux_mode, int(use_graph),
                                                   C.byref(ms)))
         return ms.value
+
+    def prepare_iterations(self, iters: int, with_flux: bool = True, flux_mode: int = FLUX_CONSISTENT) -> None:
+        """capture the hipGraphs run_iterations(iters) replays, without executing anything"""
+        self._ck(self.lib.cfdp_gpu_prepare_iterations(self.h, iters, int(with_flux), flux_mode))
 
     def close(self) -> None:
         if self.h:

@@ -65,7 +65,8 @@ hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_be
 // workgroup then frees too little LDS for it (measured: 56 vs 52 us per overlapped iteration)
 hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refmode, int tile_begin,
                            int ntiles, int tile_points, int max_halo, int max_blob_qw, bool nt,
-                           bool allow_split, hipStream_t stream, const gg_push_args *push = nullptr);
+                           bool allow_split, hipStream_t stream, const gg_push_args *push = nullptr,
+                           bool reverse = false);
 // would gg_launch_fused run a fused kernel (not hipErrorNotSupported) for these tile sizes?
 bool gg_fused_fits(int tile_points, int max_halo, int max_blob_qw);
 hipError_t gg_launch_pack(const int *send_idx, int nsend, const gg_grad_view &grad, double *sendbuf,

@@ -43,11 +43,16 @@
 
 namespace {
 
-__device__ __forceinline__ int xcd_tile(int b, int nb) {
+__device__ __forceinline__ int xcd_tile(int b, int nb, bool rev = false) {
   // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one).  Give each
   // XCD a CONTIGUOUS run of tiles: tiles are numbered in growth order, so neighbours in
   // space share halo rows and duplicated faces through the same 4 MiB L2.  Speed only.
-  const int x = b & 7, i = b >> 3, base = nb >> 3, rem = nb & 7;
+  // rev: the XCD walks its run backwards.  Passes that alternate the direction start on the
+  // tiles the previous pass finished with, whose rows and blobs are the most recent content of
+  // the 256 MiB Infinity Cache -- on meshes that stream more than it holds per pass.
+  const int x = b & 7, base = nb >> 3, rem = nb & 7;
+  int i = b >> 3;
+  if (rev) i = base + (x < rem ? 1 : 0) - 1 - i;
   return x * base + (x < rem ? x : rem) + i;
 }
 
@@ -55,8 +60,8 @@ __device__ __forceinline__ int xcd_tile(int b, int nb) {
 // whose results the partners wait for): those are dealt round-robin over ALL XCDs, first in the
 // grid -- one round instead of three on a single XCD, and no XCD left with a chunk of half-size
 // tiles -- and each XCD owns a contiguous chunk of the remaining tiles.
-__device__ __forceinline__ int xcd_tile_bfirst(int b, int nb, int nbt) {
-  if (nbt <= 0) return xcd_tile(b, nb);
+__device__ __forceinline__ int xcd_tile_bfirst(int b, int nb, int nbt, bool rev = false) {
+  if (nbt <= 0) return xcd_tile(b, nb, rev);
   if (b < nbt) return b;
   const int x = b & 7;
   int start = 0, mine = 0;
@@ -91,6 +96,8 @@ template <bool NT> __device__ __forceinline__ void st_row(double v, double *p) {
   else *p = v;
 }
 
+// bit of the kernels' `dbg` argument that is not a timing experiment: walk the tiles backwards
+#define GG_DBG_REVERSE 0x10000
 #ifndef GG_DEEP_BATCH
 #define GG_DEEP_BATCH 7
 #endif
@@ -741,7 +748,8 @@ void gg_fused_dma_kernel(
     gg_push_args pa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LPP = 4;
-  const int t = tile_begin + xcd_tile_bfirst(blockIdx.x, gridDim.x, pa.tile_off && tile_begin == 0 ? pa.nbtiles : 0);
+  const int t = tile_begin + xcd_tile_bfirst(blockIdx.x, gridDim.x, pa.tile_off && tile_begin == 0 ? pa.nbtiles : 0,
+                                            (dbg & GG_DBG_REVERSE) != 0);
   const cfdp_tile_desc td = tiles[t];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
@@ -847,7 +855,8 @@ void gg_fused_split_kernel(
   static_assert(KX >= KV && KX >= KG, "the shared row region must hold either set of rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LPP = 4;
-  const int t = tile_begin + xcd_tile_bfirst(blockIdx.x, gridDim.x, pa.tile_off && tile_begin == 0 ? pa.nbtiles : 0);
+  const int t = tile_begin + xcd_tile_bfirst(blockIdx.x, gridDim.x, pa.tile_off && tile_begin == 0 ? pa.nbtiles : 0,
+                                            (dbg & GG_DBG_REVERSE) != 0);
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
   int hv[KV], hg[KG], part[KG], rloc[KG];
@@ -1192,8 +1201,9 @@ bool gg_fused_fits(int tile_points, int max_halo, int max_blob_qw) {
 
 hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refmode, int tile_begin,
                            int ntiles, int tile_points, int max_halo, int max_blob_qw, bool nt,
-                           bool allow_split, hipStream_t stream, const gg_push_args *push) {
+                           bool allow_split, hipStream_t stream, const gg_push_args *push, bool reverse) {
   if (ntiles <= 0) return hipSuccess;
+  const int dbgf = gg_debug_flags | (reverse ? GG_DBG_REVERSE : 0);
   gg_push_args pa;
   memset(&pa, 0, sizeof pa);
   if (push) pa = *push;
@@ -1208,11 +1218,11 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
 #define LAUNCH_SPLIT(R, N)                                                                        \
   hipLaunchKernelGGL((gg_fused_split_kernel<R, N, 5, 4, 4, 4>), dim3(ntiles), dim3(block), split_lds, stream, a.tiles, \
                      tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, \
-                     gg_debug_flags, pa)
+                     dbgf, pa)
     if (gg_debug_flags & 1024) {  // timing experiment: the var rows gathered after the flux phase
       hipLaunchKernelGGL((gg_fused_split_kernel<false, false, 5, 4, 4, 4, false>), dim3(ntiles), dim3(block), split_lds,
                          stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown,
-                         gnew.a, gnew.b, gg_debug_flags, pa);
+                         gnew.a, gnew.b, dbgf, pa);
       return hipGetLastError();
     }
     if (refmode) { if (nt) LAUNCH_SPLIT(true, true); else LAUNCH_SPLIT(true, false); }
@@ -1223,7 +1233,7 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
 #define LAUNCH_FUSED_RN(R, N, CB, KV, KG)                                                         \
   hipLaunchKernelGGL((gg_fused_dma_kernel<R, N, CB, KV, KG>), dim3(ntiles), dim3(block), fused_lds, \
                      stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, \
-                     a.flux, a.nown, gnew.a, gnew.b, gg_debug_flags, pa)
+                     a.flux, a.nown, gnew.a, gnew.b, dbgf, pa)
 #define LAUNCH_FUSED(CB, KV, KG)                                                                  \
   do {                                                                                            \
     const size_t fused_lds = (size_t)((CB) + (KV) + (KG)) * block * 16;                           \

@@ -84,7 +84,8 @@ struct cfdp_gpu {
     int *d_slot_of_row = nullptr, *d_send_off = nullptr;
     int *d_tile_off = nullptr, *d_ent = nullptr, *d_ent_row = nullptr;  // send rows per boundary tile
     bool inkernel = false;   // the fused pass pushes and notifies by itself
-    hipGraphExec_t graph = nullptr;
+    hipGraphExec_t graph = nullptr, graph_rem = nullptr;  // main chunk; what is left after whole chunks
+    int graph_n = 0, graph_rem_n = 0;
     int g_exch = -1, g_overlap = -1, g_flux = -1, g_mode = -1, g_xpar = -1;
     const double *g_cur = nullptr;
   } ipc;
@@ -99,13 +100,27 @@ struct cfdp_gpu {
   std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
   int max_halo[2] = {0, 0}, max_blob[2] = {0, 0};  // per tile class: halo rows, blob 16-byte units
   bool streaming = false;      // per-iteration bytes exceed the Infinity Cache: non-temporal blobs/rows
+  // fused passes over ALL tiles alternate the direction in which every XCD walks its run of tiles, so
+  // that a pass starts on what the previous one left in the Infinity Cache (only worth it when a pass
+  // streams more than the cache holds; the values do not depend on the order)
+  bool alternate = false;
+  unsigned fused_passes = 0;
   int pipeline = -1;           // -1: auto; 0: one workgroup per tile; k: persistent LDS-DMA kernel, <= k WG/CU
   int grad_lanes = 4, flux_lanes = 8;
   bool pending_exchange = false;
   bool streams_exported = false;  // handed to the caller: not destroyed with the context
-  hipGraphExec_t graph = nullptr;
-  int graph_iters = 0, graph_flux = -1, graph_mode = -1, graph_gl = 0, graph_fl = 0, graph_fuse = -1;
-  const double *graph_cur = nullptr;  // d_grad at capture: the graph's pointers are baked in
+  // hipGraphs of cfdp_gpu_run_iterations: [0] the main chunk (50 fused passes / 25 iterations), [1] what
+  // is left of a run after whole chunks -- so that ANY iteration count is replayed, not stream-launched
+  hipGraphExec_t graph = nullptr, graph_rem = nullptr;
+  int graph_iters = 0, graph_rem_iters = 0, graph_flux = -1, graph_mode = -1, graph_gl = 0, graph_fl = 0, graph_fuse = -1;
+  const double *graph_cur = nullptr;  // d_grad at the last capture: the graphs' pointers are baked in
+  const double *graph_cur_slot[2] = {nullptr, nullptr};  // ... per slot ([0] graph, [1] graph_rem)
+  const double *graph_whole_final = nullptr;  // whole-run graph: the buffer holding its last gradients
+  void drop_graphs() {
+    if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
+    if (graph_rem) { (void)hipGraphExecDestroy(graph_rem); graph_rem = nullptr; }
+    graph_iters = graph_rem_iters = 0;
+  }
 
   // d_grad: nall*21 doubles laid out [A: nown x 10][ghost rows: nghost x 21][B: nown x 11]
   gg_grad_view grad_view() const {
@@ -212,7 +227,7 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
 }
 
 static void free_device(cfdp_gpu *g) {
-  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  g->drop_graphs();
   (void)hipFree(g->d_tiles); (void)hipFree(g->d_blob); (void)hipFree(g->d_halo); (void)hipFree(g->d_sendidx); (void)hipFree(g->d_rowlist);
   (void)hipFree(g->d_var); (void)hipFree(g->d_flux);
   if (g->own_grad) (void)hipFree(g->d_grad);
@@ -314,6 +329,8 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
     const double per_iter = (double)p->blob_bytes + (double)p->nall * (64.0 + 168.0);
     g->streaming = per_iter > 192.0 * 1024 * 1024;
     if (const char *e = getenv("CFDP_STREAMING")) g->streaming = atoi(e) != 0;
+    g->alternate = g->streaming;
+    if (const char *e = getenv("CFDP_ALTERNATE")) g->alternate = atoi(e) != 0;
   }
   g->send_idx_host.assign(p->send_idx, p->send_idx + nsend);
   if (nsend)
@@ -342,7 +359,7 @@ int cfdp_gpu_bind_grad(cfdp_gpu *g, void *dev_grad) {
   if (g->own_grad) (void)hipFree(g->d_grad);
   g->d_grad = static_cast<double *>(dev_grad);
   g->own_grad = false;
-  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  g->drop_graphs();
   return 0;
 }
 
@@ -387,7 +404,7 @@ int cfdp_gpu_set_fusion(cfdp_gpu *g, int on) {
     g->own_grad_alt = true;
   }
   g->fusion = 1;
-  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  g->drop_graphs();
   return 0;
 }
 
@@ -401,7 +418,7 @@ int cfdp_gpu_bind_grad_alt(cfdp_gpu *g, void *dev_grad) {
   if (g->d_grad_alt && g->own_grad_alt) (void)hipFree(g->d_grad_alt);
   g->d_grad_alt = static_cast<double *>(dev_grad);
   g->own_grad_alt = false;
-  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  g->drop_graphs();
   return 0;
 }
 
@@ -486,7 +503,7 @@ int cfdp_gpu_set_pipeline(cfdp_gpu *g, int max_wg_per_cu) {
   if (!g) return fail("null context");
   if (max_wg_per_cu < -1 || max_wg_per_cu > 16) return fail("pipeline depth must be in [-1,16]");
   g->pipeline = max_wg_per_cu;
-  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  g->drop_graphs();
   return 0;
 }
 
@@ -580,8 +597,9 @@ static int launch_fused(cfdp_gpu *g, int which, hipStream_t st, const gg_push_ar
   const int mode = g->flux_pending;
   const tile_range r = range_of(g, which);
   if (push && !gg_fused_fits(r.tp, r.max_halo, r.max_blob)) return 2;
+  const bool reverse = g->alternate && which == CFDP_TILES_ALL && !push && (g->fused_passes++ & 1u);
   const hipError_t e = gg_launch_fused(a, gnew, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.max_halo, r.max_blob,
-                                       g->streaming, !g->beside_rccl, st, push);
+                                       g->streaming, !g->beside_rccl, st, push, reverse);
   if (e == hipErrorNotSupported && push) return 2;
   if (e == hipErrorNotSupported) {
     if (launch_flux_tiles(g, mode, which, st)) return 1;
@@ -908,80 +926,120 @@ int cfdp_gpu_time_fused(cfdp_gpu *g, int iters, int flux_mode, float *ms_fused) 
   return flush_flux(g);
 }
 
-int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode, int use_graph,
-                            float *ms_total) {
-  NEED_UPLOAD(g);
+// K iterations of one partition, replayed from hipGraphs whatever K is.
+// Fused mode: gradients(1), K-1 fused passes (flux(i) + gradients(i+1)), flux(K).  The passes are cut
+// into whole chunks of 50 (one graph, replayed), a remainder graph with the even part of what is left
+// (an even count leaves the two grad buffers in place -- the graph's pointers are baked in) and at most
+// one stream-launched pass.  Separate kernels: chunks of 25 iterations = NITER of the reference harness
+// (src/hybrid.f6.c:72), a remainder graph for the rest.  run = false: capture and instantiate only
+// (cfdp_gpu_prepare_iterations) -- nothing executes, so a timed region need not contain a capture.
+static int run_or_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode, int use_graph, bool run,
+                                     float *ms_total) {
   if (iters < 1) return fail("iters must be >= 1");
   if (with_flux && flux_mode != CFDP_FLUX_CONSISTENT && flux_mode != CFDP_FLUX_REFERENCE)
     return fail("bad flux mode %d", flux_mode);
   if (flush_flux(g)) return 1;
   hipStream_t st = g->s_main;
   const bool fuse = g->fusion && g->d_grad_alt && with_flux;
-  // graph chunk: 25 iterations = NITER of the reference harness (src/hybrid.f6.c:72) for the two
-  // kernels per iteration; in fused mode 50 fused passes (flux(i) + gradients(i+1)) with a flux
-  // pending at entry and at exit, so that chunks chain without an un-fused seam -- the iterations
-  // are then: gradients(1), iters-1 fused passes, flux(iters).  Even counts leave the two grad
-  // buffers where they were.
-  const int chunk = fuse ? 50 : 25;
+  // units: fused passes (after the leading gradient launch) or whole iterations
+  const int units = fuse ? iters - 1 : iters;
+  const int full = fuse ? 50 : 25;
+  // a SHORT fused run is one graph from its first gradient launch to its last flux launch: the two
+  // un-fused launches at its ends and a graph's start-up latency (~20 us before its first kernel runs)
+  // are a tenth of a 20-iteration run when they sit between stream launches and replays
+  const bool whole = use_graph && fuse && iters >= 2 && iters <= 64;
+  int chunk = 0, nchunk = 0, rem = 0;
+  if (use_graph && !whole) {
+    chunk = units >= full ? full : 0;
+    nchunk = chunk ? units / chunk : 0;
+    rem = units - nchunk * chunk;
+    if (fuse) rem &= ~1;
+    if (rem < 2) rem = 0;
+  }
+  const int eager = whole ? 0 : units - nchunk * chunk - rem;
   auto one_pass = [&]() -> int {  // fused mode, a flux pending
     if (launch_fused(g, CFDP_TILES_ALL, st)) return 1;
     fused_done(g);
     g->flux_pending = flux_mode;
     return 0;
   };
-  auto capture = [&](auto &&body) -> int {  // 0 ok, 1 error
-    if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
-    hipGraph_t gr = nullptr;
-    const double *cur0 = g->d_grad;
-    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    const int rc = body();
-    hipError_t ec = hipStreamEndCapture(st, &gr);
-    if (rc) { if (gr) (void)hipGraphDestroy(gr); return 1; }
-    HIP_TRY(ec);
-    if (g->d_grad != cur0) { (void)hipGraphDestroy(gr); return fail("graph chunk must leave the grad buffers in place"); }
-    HIP_TRY(hipGraphInstantiate(&g->graph, gr, nullptr, nullptr, 0));
-    HIP_TRY(hipGraphDestroy(gr));
-    g->graph_iters = chunk; g->graph_flux = with_flux; g->graph_mode = flux_mode;
-    g->graph_gl = g->grad_lanes; g->graph_fl = g->flux_lanes;
-    g->graph_fuse = (int)fuse; g->graph_cur = g->d_grad;
+  auto body = [&](int n) -> int {
+    if (!fuse) return enqueue_iterations(g, n, with_flux, flux_mode, st);
+    for (int i = 0; i < n; i++)
+      if (one_pass()) return 1;
     return 0;
   };
-  auto stale = [&]() {
-    return !g->graph || g->graph_flux != with_flux || g->graph_mode != flux_mode || g->graph_gl != g->grad_lanes ||
-           g->graph_fl != g->flux_lanes || g->graph_fuse != (int)fuse || g->graph_cur != g->d_grad;
-  };
-  HIP_TRY(hipEventRecord(g->ev_a, st));
-  int done = 0;
-  if (fuse) {
-    if (launch_grad(g, CFDP_TILES_ALL, st)) return 1;  // iteration 1's gradients; its flux rides with iteration 2
+  auto whole_run = [&]() -> int {  // gradients(1), iters-1 fused passes, flux(iters)
+    if (launch_grad(g, CFDP_TILES_ALL, st)) return 1;
     g->flux_pending = flux_mode;
-    done = 1;
-    if (use_graph && iters - done >= chunk) {
-      if (stale() && capture([&]() -> int {
-            for (int i = 0; i < chunk; i++)
-              if (one_pass()) return 1;
-            return 0;
-          }))
-        return 1;
-      while (iters - done >= chunk) {
-        g->main_marked = false;
-        HIP_TRY(hipGraphLaunch(g->graph, st));
-        done += chunk;
-      }
+    if (body(iters - 1)) return 1;
+    return flush_flux(g, false, st);
+  };
+  if (g->graph_flux != with_flux || g->graph_mode != flux_mode || g->graph_gl != g->grad_lanes ||
+      g->graph_fl != g->flux_lanes || g->graph_fuse != (int)fuse ||
+      (g->graph_cur != g->d_grad && g->graph_cur != g->d_grad_alt))
+    g->drop_graphs();  // every cached graph was captured for another configuration
+  // slot_n > 0: n units that leave the grad buffers in place; slot_n < 0: a whole run of -n iterations, which
+  // starts by recomputing every gradient and may end in either buffer (graph_whole_final says which)
+  auto capture = [&](hipGraphExec_t &slot, int &slot_n, int n) -> int {  // 0 ok, 1 error
+    const double *&slot_cur = g->graph_cur_slot[&slot == &g->graph ? 0 : 1];
+    if (slot && slot_n == n && (n < 0 || slot_cur == g->d_grad)) return 0;
+    if (slot) { (void)hipGraphExecDestroy(slot); slot = nullptr; }
+    slot_n = 0;
+    hipGraph_t gr = nullptr;
+    const double *cur0 = g->d_grad;
+    const int pend0 = g->flux_pending;
+    const unsigned passes0 = g->fused_passes;
+    if (fuse && n > 0) g->flux_pending = flux_mode;  // the state every pass of the run starts in
+    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = n < 0 ? whole_run() : body(n);
+    hipError_t ec = hipStreamEndCapture(st, &gr);
+    g->flux_pending = pend0;  // nothing of the capture has run
+    g->fused_passes = passes0;
+    const bool swapped = g->d_grad != cur0;
+    if (swapped) { std::swap(g->d_grad, g->d_grad_alt); std::swap(g->own_grad, g->own_grad_alt); }
+    if (rc) { if (gr) (void)hipGraphDestroy(gr); return 1; }
+    HIP_TRY(ec);
+    if (swapped && n > 0) { (void)hipGraphDestroy(gr); return fail("graph chunk must leave the grad buffers in place"); }
+    HIP_TRY(hipGraphInstantiate(&slot, gr, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphDestroy(gr));
+    slot_n = n;
+    if (n < 0) g->graph_whole_final = swapped ? g->d_grad_alt : g->d_grad;
+    g->graph_flux = with_flux; g->graph_mode = flux_mode;
+    g->graph_gl = g->grad_lanes; g->graph_fl = g->flux_lanes;
+    g->graph_fuse = (int)fuse; g->graph_cur = g->d_grad;
+    slot_cur = g->d_grad;
+    return 0;
+  };
+  // (an even number of alternating-direction passes per graph: a replay continues the alternation)
+  if (whole && capture(g->graph_rem, g->graph_rem_iters, -iters)) return 1;
+  if (chunk && capture(g->graph, g->graph_iters, chunk)) return 1;
+  if (rem && capture(g->graph_rem, g->graph_rem_iters, rem)) return 1;
+  if (!run) return 0;
+  HIP_TRY(hipEventRecord(g->ev_a, st));
+  if (whole) {
+    g->main_marked = false;
+    HIP_TRY(hipGraphLaunch(g->graph_rem, st));
+    if (g->d_grad != g->graph_whole_final) {  // the run's last gradients are where the graph put them
+      std::swap(g->d_grad, g->d_grad_alt);
+      std::swap(g->own_grad, g->own_grad_alt);
     }
-    for (; done < iters; done++)
-      if (one_pass()) return 1;
-    if (flush_flux(g, false, st)) return 1;  // flux of the last iteration
+    g->graph_cur = g->d_grad;
   } else {
-    if (use_graph && iters >= chunk) {
-      if (stale() && capture([&]() -> int { return enqueue_iterations(g, chunk, with_flux, flux_mode, st); })) return 1;
-      while (iters - done >= chunk) {
-        g->main_marked = false;
-        HIP_TRY(hipGraphLaunch(g->graph, st));
-        done += chunk;
-      }
+    if (fuse) {
+      if (launch_grad(g, CFDP_TILES_ALL, st)) return 1;  // iteration 1's gradients; its flux rides with iteration 2
+      g->flux_pending = flux_mode;
     }
-    if (done < iters && enqueue_iterations(g, iters - done, with_flux, flux_mode, st)) return 1;
+    for (int c = 0; c < nchunk; c++) {
+      g->main_marked = false;
+      HIP_TRY(hipGraphLaunch(g->graph, st));
+    }
+    if (rem) {
+      g->main_marked = false;
+      HIP_TRY(hipGraphLaunch(g->graph_rem, st));
+    }
+    if (eager && body(eager)) return 1;
+    if (fuse && flush_flux(g, false, st)) return 1;  // flux of the last iteration
   }
   HIP_TRY(hipEventRecord(g->ev_b, st));
   HIP_TRY(hipEventSynchronize(g->ev_b));
@@ -989,6 +1047,17 @@ int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode
   HIP_TRY(hipEventElapsedTime(&ms, g->ev_a, g->ev_b));
   if (ms_total) *ms_total = ms;
   return 0;
+}
+
+int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode, int use_graph,
+                            float *ms_total) {
+  NEED_UPLOAD(g);
+  return run_or_prepare_iterations(g, iters, with_flux, flux_mode, use_graph, true, ms_total);
+}
+
+int cfdp_gpu_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode) {
+  NEED_UPLOAD(g);
+  return run_or_prepare_iterations(g, iters, with_flux, flux_mode, 1, false, nullptr);
 }
 
 // ------------------------------------------------------- one process per GPU: RCCL from C
@@ -1150,6 +1219,8 @@ long ipc_max_polls() {
 void ipc_release(cfdp_gpu *g) {
   auto &I = g->ipc;
   if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
+  if (I.graph_rem) { (void)hipGraphExecDestroy(I.graph_rem); I.graph_rem = nullptr; }
+  I.graph_n = I.graph_rem_n = 0;
   for (void *p : I.opened) (void)hipIpcCloseMemHandle(p);
   I.opened.clear(); I.opened_handle.clear();
   for (int par = 0; par < 2; par++) { (void)hipFree(I.d_dst[par]); I.d_dst[par] = nullptr; I.dst[par].clear(); }
@@ -1353,7 +1424,7 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
                         hipMemcpyDeviceToDevice));
   I.xiter = 0;
   I.on = true;
-  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  g->drop_graphs();
   return 0;
 }
 
@@ -1366,7 +1437,7 @@ int cfdp_gpu_ipc_enable(cfdp_gpu *g, int on) {
   if (flush_flux(g)) return 1;
   HIP_TRY(hipDeviceSynchronize());
   I.on = on != 0;
-  if (g->graph) { (void)hipGraphExecDestroy(g->graph); g->graph = nullptr; }
+  g->drop_graphs();
   return 0;
 }
 
@@ -1420,18 +1491,20 @@ int cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux
   return one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode);
 }
 
-// `steps` iterations.  use_graph: after two lead-in steps, 50 steps at a time are replayed from a
-// hipGraph (both streams, the push / notify / wait kernels included; an even count restores the
-// parity of the landing arenas and of the two grad buffers).
+// `steps` iterations.  use_graph: after two lead-in steps (the first iteration of a run has no flux to
+// fuse with), the steps are replayed from hipGraphs -- both streams, the push / notify / wait kernels
+// included: whole chunks of 50 from one graph, the even part of the remainder from a second one (an
+// even count restores the parity of the landing arenas and of the two grad buffers, which the kernels'
+// arguments bake in), at most one step launched from the streams -- so short runs replay as well.
 int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
                            int flux_mode, int use_graph) {
   NEED_UPLOAD(g);
   if (!g->ipc.on) return fail("cfdp_gpu_ipc_ready() has not been called");
   if (steps < 1) return fail("steps must be >= 1");
   auto &I = g->ipc;
-  const int chunk = 50;  // steps per graph replay (2 kernels each with the in-kernel push)
+  const int full = 50;  // steps per replay of the main graph (2 kernels each with the in-kernel push)
   int done = 0;
-  if (use_graph && steps >= chunk + 2) {
+  if (use_graph && steps >= 4) {
     for (; done < 2; done++)
       if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
     if (I.xiter & 1) {  // a graph is tied to the arena parity it was captured at: even
@@ -1439,46 +1512,61 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       done++;
     }
     // (the arena the ghost rows are read from is baked into the kernels' arguments too)
-    const bool stale = !I.graph || I.g_exch != with_exchange || I.g_overlap != overlap || I.g_flux != with_flux ||
-                       I.g_mode != flux_mode || I.g_cur != g->d_grad || I.g_xpar != (int)(I.xiter & 1);
-    if (stale) {
+    if (I.g_exch != with_exchange || I.g_overlap != overlap || I.g_flux != with_flux || I.g_mode != flux_mode ||
+        I.g_cur != g->d_grad || I.g_xpar != (int)(I.xiter & 1)) {
       if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
+      if (I.graph_rem) { (void)hipGraphExecDestroy(I.graph_rem); I.graph_rem = nullptr; }
+      I.graph_n = I.graph_rem_n = 0;
+    }
+    auto capture = [&](hipGraphExec_t &slot, int &slot_n, int n) -> bool {  // false: run from the streams instead
+      if (slot && slot_n == n) return true;
+      if (slot) { (void)hipGraphExecDestroy(slot); slot = nullptr; }
+      slot_n = 0;
       const double *cur0 = g->d_grad;
       const int pend0 = g->flux_pending;
       const long iter0 = g->iter, x0 = I.xiter;
+      const unsigned passes0 = g->fused_passes;
       hipGraph_t gr = nullptr;
-      HIP_TRY(hipStreamBeginCapture(g->s_main, hipStreamCaptureModeThreadLocal));
+      if (hipStreamBeginCapture(g->s_main, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
       g->main_marked = false;  // the first captured step must fork off a record made INSIDE the capture
       int rc = 0;
-      for (int i = 0; i < chunk && !rc; i++) rc = one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode);
+      for (int i = 0; i < n && !rc; i++) rc = one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode);
       hipError_t ec = hipStreamEndCapture(g->s_main, &gr);
       (void)hipEventRecord(g->ev_fork, g->s_main);      // events last recorded inside a capture may not
       (void)hipEventRecord(g->ev_senddone, g->s_comm);  // be waited for outside it: re-arm them
       (void)mark_main(g);
       const bool ok = !rc && ec == hipSuccess && gr && g->d_grad == cur0 && g->flux_pending == pend0;
-      if (ok && hipGraphInstantiate(&I.graph, gr, nullptr, nullptr, 0) != hipSuccess) I.graph = nullptr;
+      if (ok && hipGraphInstantiate(&slot, gr, nullptr, nullptr, 0) != hipSuccess) slot = nullptr;
       if (gr) (void)hipGraphDestroy(gr);
       g->iter = iter0;
       I.xiter = x0;  // nothing of the capture has run
-      if (!ok || !I.graph) {
+      g->fused_passes = passes0;
+      if (!ok || !slot) {
         if (g->d_grad != cur0) { std::swap(g->d_grad, g->d_grad_alt); std::swap(g->own_grad, g->own_grad_alt); }
         g->flux_pending = pend0;
         (void)hipGetLastError();
-        use_graph = 0;
-      } else {
-        I.g_exch = with_exchange; I.g_overlap = overlap; I.g_flux = with_flux; I.g_mode = flux_mode; I.g_cur = g->d_grad;
-        I.g_xpar = (int)(I.xiter & 1);
+        return false;
       }
-    }
-    while (use_graph && steps - done >= chunk) {
-      HIP_TRY(hipGraphLaunch(I.graph, g->s_main));
+      slot_n = n;
+      I.g_exch = with_exchange; I.g_overlap = overlap; I.g_flux = with_flux; I.g_mode = flux_mode; I.g_cur = g->d_grad;
+      I.g_xpar = (int)(I.xiter & 1);
+      return true;
+    };
+    auto replay = [&](hipGraphExec_t ge, int n) -> int {
+      HIP_TRY(hipGraphLaunch(ge, g->s_main));
       // (a replay does not touch the event OBJECTS recorded inside the capture: whatever is ordered
       // after "the previous iteration" later needs a fresh record -- fork_comm makes one)
       g->main_marked = false;
-      g->iter += chunk;
-      if (with_exchange && !g->partner.empty()) I.xiter += chunk;
-      done += chunk;
-    }
+      g->iter += n;
+      if (with_exchange && !g->partner.empty()) I.xiter += n;
+      done += n;
+      return 0;
+    };
+    if (steps - done >= full && capture(I.graph, I.graph_n, full))
+      while (steps - done >= full)
+        if (replay(I.graph, full)) return 1;
+    const int rem = (steps - done) & ~1;
+    if (rem >= 2 && rem < full && capture(I.graph_rem, I.graph_rem_n, rem) && replay(I.graph_rem, rem)) return 1;
   }
   for (; done < steps; done++)
     if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;

@@ -60,6 +60,42 @@ def bench_mesh(n_ranks: int) -> Tuple[Tuple[int, int, int], int]:
     return (64 * n_ranks, 64, 64), 12 * n_ranks
 
 
+# the BASELINE.json workloads (stand-ins: the F6 files are not distributed).  dualgrid.12/.24/.48/.192 are the
+# SAME level-2 mesh cut into more domains -- the reference's strong-scaling regime, where a rank's share
+# shrinks to ~1 k points per core (reference README.txt:39-40) -- dualgrid.384 is the finest level.
+_BENCH = {
+    "dualgrid.12": ((64, 64, 64), 12, "lvl 2", "strong"),
+    "dualgrid.24": ((64, 64, 64), 24, "lvl 2", "strong"),
+    "dualgrid.48": ((64, 64, 64), 48, "lvl 2", "strong"),
+    "dualgrid.192": ((64, 64, 64), 192, "lvl 2", "strong"),
+    "dualgrid.384": ((128, 128, 128), 384, "finest level", "weak"),
+}
+
+
+def default_bench_config(n_ranks: int) -> str:
+    """BASELINE.json: config 2 on 1 GPU, config 3 on 4, config 5 on 8; 2 GPUs continue the strong series"""
+    return {1: "dualgrid.12", 2: "dualgrid.24", 4: "dualgrid.48", 8: "dualgrid.384"}.get(n_ranks, "weak")
+
+
+def bench_config(name: str, n_ranks: int) -> dict:
+    """one bench workload: lattice, number of domains (whole domains per GPU), the text of
+    config.workload and the scaling label of the series the run belongs to"""
+    if name == "weak":
+        dims, ndom = bench_mesh(n_ranks)
+        return dict(name="weak", dims=dims, ndomains=ndom, scaling="weak",
+                    workload=f"weak-scaling stand-in ({dims[0]}x{dims[1]}x{dims[2]}, {ndom} domains, {ndom // n_ranks} per GPU, "
+                             f"262144 owned points per GPU" + (", halo exchange over xGMI)" if n_ranks > 1 else ")"))
+    if name not in _BENCH:
+        raise ValueError(f"unknown bench config {name!r}: one of {sorted(_BENCH)} or 'weak'")
+    dims, ndom, level, scaling = _BENCH[name]
+    if ndom % n_ranks:
+        raise ValueError(f"{name}: {ndom} domains do not divide over {n_ranks} GPUs")
+    what = f"{dims[0]}^3, {ndom} domains, {ndom // n_ranks} per GPU"
+    how = "merged on 1 GPU, no halo exchange" if n_ranks == 1 else "halo exchange over xGMI with compute overlap"
+    return dict(name=name, dims=dims, ndomains=ndom, scaling=scaling,
+                workload=f"{name} {level} stand-in ({what}; {how})")
+
+
 def exchange_requests(part: Domain, rank: int, world: int, dist=None, all_requests=None) -> None:
     """Fill part's send lists from what the partners request (comm_data.c:203-249 analogue).
     `dist`: an initialised torch.distributed module, or None with `all_requests` given

@@ -192,9 +192,14 @@ int  cfdp_gpu_time_fused(cfdp_gpu *g, int iters, int flux_mode, float *ms_fused)
 /* the schedule of an exchange step without the exchange itself (the two brackets only), from one
  * hipGraph or from the streams: average milliseconds per step                             */
 int  cfdp_gpu_time_schedule(cfdp_gpu *g, int steps, int with_exchange, int overlap, int use_graph, float *ms_step);
-/* K full iterations (gradients [+flux]) captured in one hipGraph and replayed            */
+/* K full iterations (gradients [+flux]) replayed from hipGraphs -- whole chunks (50 fused passes
+ * / 25 iterations, the reference's NITER, src/hybrid.f6.c:72) plus one graph for the remainder, so
+ * any K runs without per-kernel stream launches; ms_total: device time of the K iterations      */
 int  cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode,
                              int use_graph, float *ms_total);
+/* capture + instantiate the graphs cfdp_gpu_run_iterations(g, iters, ...) will replay; nothing
+ * executes (keeps the capture out of a caller's timed region)                                  */
+int  cfdp_gpu_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode);
 
 /* multigrid "3V cycle" (documentation/CFD-Proxy.pdf p.3; levels = the -lvl files of
  * src/hybrid.f6.c:38-47, no transfer operators in the reference): `sweeps` iterations

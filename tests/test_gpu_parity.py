@@ -479,10 +479,17 @@ def test_fused_iterations_are_bit_identical_to_separate_kernels(gpu, orc, flux_m
     assert np.abs(g0 - g_ref).max() <= TOL * np.abs(g_ref).max()
     assert np.abs(f0[: dom.nown] - f_ref[: dom.nown]).max() <= TOL * np.abs(f_ref).max()
     part.set_fusion(True)
-    for iters, graph in ((1, False), (2, False), (4, False), (25, True), (51, True), (120, True), (152, True)):
+    # graph replay for ANY count: whole-run graphs (2..64 iterations, either buffer at entry: 3 and 21 leave the
+    # buffers swapped, the repeats start from that state), chunk + remainder graphs + one stream-launched pass
+    for iters, graph in ((1, False), (2, False), (4, False), (2, True), (3, True), (3, True), (20, True), (21, True), (20, True),
+                         (25, True), (51, True), (64, True), (65, True), (66, True), (120, True), (152, True), (21, True)):
         dom.grad[:] = -3.0
         dom.psd_flux[:] = 5.0
         part.push_fields()
+        if graph and iters % 2:
+            part.prepare_iterations(iters, True, flux_mode)  # capture only: nothing runs, the fields stay as pushed
+            part.pull_fields()
+            assert np.all(dom.grad[: dom.nown] == -3.0) and np.all(dom.psd_flux[: dom.nown] == 5.0)
         part.run_iterations(iters, True, flux_mode, use_graph=graph)
         part.pull_fields()
         assert np.array_equal(dom.grad[: dom.nown], g0[: dom.nown]), (iters, graph)

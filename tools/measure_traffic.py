@@ -53,9 +53,14 @@ for n, label in ((64, "dualgrid.12 lvl 2 stand-in (64^3)"), (128, "dualgrid.384 
         entry[k] = {"hbm_read_bytes": kb_read * 1024, "hbm_write_bytes": kb_write * 1024,
                     "traffic_bytes": (kb_read + kb_write) * 1024, "raw": c}
     result[label] = entry
+import hashlib
+h = hashlib.sha256()
+for f in ("cfd-proxy_amd/csrc/gg_kernels.hip", "cfd-proxy_amd/host/tiling.c"):  # = bench.py kernel_source_tag()
+    h.update(open(os.path.join(ROOT, f), "rb").read())
+result["kernel_source_tag"] = h.hexdigest()[:16]
 json.dump(result, open(os.path.join(out_dir, f"{tag}_traffic.json"), "w"), indent=1)
 with open(os.path.join(out_dir, f"{tag}_pmc_counters.csv"), "w") as fh:
     w = csv.writer(fh)
     w.writerow(["workload", "kernel", "counter", "average_per_dispatch", "dispatches"])
     w.writerows(rows_out)
-print(json.dumps({k: {kk: vv["traffic_bytes"] for kk, vv in v.items()} for k, v in result.items()}, indent=1))
+print(json.dumps({k: {kk: vv["traffic_bytes"] for kk, vv in v.items()} for k, v in result.items() if isinstance(v, dict)}, indent=1))
