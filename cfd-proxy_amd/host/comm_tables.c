@@ -12,6 +12,10 @@
 
 #include <string.h>
 
+static const cfdp_mpi_hooks *g_hooks = NULL;
+void cfdp_register_mpi_hooks(const cfdp_mpi_hooks *hooks) { g_hooks = hooks; }
+const cfdp_mpi_hooks *cfdp_get_mpi_hooks(void) { return g_hooks; }
+
 void compute_communication_tables(comm_data *cd) {
   /* reference: create_recvsend_index (MPI exchange of ghost ids) + offset tables + buffer
    * allocation (src/comm_data.c:446-502).  Merged partitions arrive with recvindex built
@@ -33,6 +37,12 @@ void compute_communication_tables(comm_data *cd) {
     }
   }
   if (!cd->sendindex) cd->sendindex = cfdp_calloc((size_t)cd->ndomains, sizeof(int *));
+  /* one rank per process: the partners tell each other which points they need (src/comm_data.c:203-249);
+   * only for raw single-file partitions -- merged ones get their send lists from the merger's requests */
+  int raw = 1;
+  for (int i = 0; i < cd->ncommdomains; i++)
+    if (cd->sendindex[cd->commpartner[i]]) raw = 0;
+  if (g_hooks && g_hooks->tables && raw && cd->nProc > 1) g_hooks->tables(cd);
 }
 
 

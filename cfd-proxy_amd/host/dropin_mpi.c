@@ -1,0 +1,270 @@
+/*
+ * dropin_mpi.c -- the MPI side of the drop-in boundary (lib/libcfdproxy_mpi.so, built when an MPI is
+ * installed; libcfdproxy_hip.so itself has no MPI dependency).
+ *
+ * The reference is one MPI rank per process (src/comm_data.c:257-307); its main() (src/hybrid.f6.c:54-91)
+ * and its harness (src/solver.c:35-314) call init_communication / compute_communication_tables /
+ * init_threads / compute_gradients_gg_<variant> / compute_psd_flux / free_communication_ressources and,
+ * in the harness, MPI_Barrier.  Linking this library next to libcfdproxy_hip.so gives those entry points
+ * their multi-process meaning -- a constructor registers the hooks below, no symbol is overridden:
+ *
+ *   init_communication            MPI_Init_thread, nProc / iProc            (src/comm_data.c:257-307)
+ *   compute_communication_tables  + the index exchange that builds sendindex: every rank sends each
+ *                                 partner the owner-local ids of the ghosts it needs from it
+ *                                                                           (src/comm_data.c:203-249)
+ *   init_threads                  + the data path between the ranks' GPUs: xGMI write + notify through
+ *                                 HIP IPC when all ranks share a node (VALIDATED before use: ghost rows
+ *                                 against owner rows for var and 2*var with a short wait bound; retried
+ *                                 with a fine-grained landing block; then RCCL), else RCCL send/recv
+ *                                 -- in place of src/exchange_data_{mpi,mpidma,gaspi}.c
+ *   test_solver                   MPI_Barrier around every sample, rank 0 prints  (src/solver.c:42-58)
+ *   free_communication_ressources unmap / tear down collectively, MPI_Finalize (when this library did
+ *                                 the MPI_Init)                             (src/comm_data.c:504-521)
+ *
+ * MPI is the control plane only: no ghost row ever travels through it.
+ */
+#define CFDP_WITH_MPI 1
+#include "cfdproxy_hip.h"
+#include "host_util.h"
+
+#include <math.h>
+#include <string.h>
+
+static int g_own_init = 0;   /* MPI_Init_thread was called here: finalize here too */
+static int g_use_ipc = 0;    /* data path chosen by attach(): 1 = xGMI write + notify, 0 = RCCL (or none) */
+static char g_path[160] = "none (one rank)";
+
+const char *cfdp_mpi_exchange_path(void) { return g_path; }
+
+static void hook_init(int *argc, char ***argv, comm_data *cd) {
+  int inited = 0, provided = 0;
+  MPI_Initialized(&inited);
+  if (!inited) {
+    /* every thread of the caller's omp region may call the entry points (src/solver.c:45-55); the
+     * library elects one per call, so SERIALIZED is all it needs -- ask for MULTIPLE like the reference
+     * (src/comm_data.c:264-272) and accept less */
+    MPI_Init_thread(argc, argv, MPI_THREAD_MULTIPLE, &provided);
+    CFDP_ASSERT(provided >= MPI_THREAD_SERIALIZED);
+    g_own_init = 1;
+  }
+  MPI_Comm_size(MPI_COMM_WORLD, &cd->nProc);
+  MPI_Comm_rank(MPI_COMM_WORLD, &cd->iProc);
+}
+
+/* the index exchange of src/comm_data.c:203-249: sendindex[k][j] = MY local id of the point that is
+ * partner k's j-th ghost owned by me (k sends the owner-local ids of its ghosts, in its file order) */
+static void hook_tables(comm_data *cd) {
+  if (cd->ndomains == 1 || cd->nProc == 1) return;
+  CFDP_ASSERT(cd->ndomains == cd->nProc); /* one domain file per rank, as in the reference (:94) */
+  const int nc = cd->ncommdomains;
+  MPI_Request *req = cfdp_malloc((size_t)(2 * nc + 1) * sizeof(MPI_Request));
+  int **out = cfdp_calloc((size_t)nc + 1, sizeof(int *));
+  int nreq = 0;
+  for (int i = 0; i < nc; i++) {
+    const int k = cd->commpartner[i];
+    if (cd->sendcount[k] > 0) {
+      free(cd->sendindex[k]);
+      cd->sendindex[k] = cfdp_malloc((size_t)cd->sendcount[k] * sizeof(int));
+      MPI_Irecv(cd->sendindex[k], cd->sendcount[k], MPI_INT, k, 4711, MPI_COMM_WORLD, &req[nreq++]);
+    }
+  }
+  for (int i = 0; i < nc; i++) {
+    const int k = cd->commpartner[i], n = cd->recvcount[k];
+    if (n <= 0) continue;
+    out[i] = cfdp_malloc((size_t)n * sizeof(int));
+    for (int j = 0; j < n; j++) out[i][j] = cd->addpoint_id[cd->recvindex[k][j] - cd->nownpoints];
+    MPI_Isend(out[i], n, MPI_INT, k, 4711, MPI_COMM_WORLD, &req[nreq++]);
+  }
+  MPI_Waitall(nreq, req, MPI_STATUSES_IGNORE);
+  for (int i = 0; i < nc; i++) {
+    const int k = cd->commpartner[i];
+    for (int j = 0; j < cd->sendcount[k]; j++) CFDP_ASSERT(cd->sendindex[k][j] >= 0 && cd->sendindex[k][j] < cd->nownpoints);
+    free(out[i]);
+  }
+  free(out);
+  free(req);
+}
+
+/* ---- the xGMI write + notify path: map the partners' landing arenas (handles travel in one allgather) */
+static int ipc_setup(cfdp_gpu *gpu, int r, int G) {
+  enum { MAXP = 48 };
+  typedef struct { unsigned char handle[64]; long land; int np, partner[MAXP], recv_off[MAXP + 1]; } ipc_info;
+  ipc_info mine, *all_info = cfdp_malloc((size_t)G * sizeof(ipc_info));
+  memset(&mine, 0, sizeof mine);
+  size_t land = 0;
+  int ok = cfdp_gpu_ipc_export(gpu, mine.handle, &land) == 0 && cfdp_gpu_npartners(gpu) <= MAXP;
+  mine.land = (long)land;
+  mine.np = ok ? cfdp_gpu_npartners(gpu) : -1;
+  for (int s = 0; s < mine.np; s++) {
+    size_t bytes = 0;
+    mine.partner[s] = cfdp_gpu_partner_rank(gpu, s);
+    (void)cfdp_gpu_recv_ptr(gpu, s, &bytes);
+    mine.recv_off[s + 1] = mine.recv_off[s] + (int)(bytes / (NGRAD * 3 * sizeof(double)));
+  }
+  MPI_Allgather(&mine, (int)sizeof mine, MPI_BYTE, all_info, (int)sizeof mine, MPI_BYTE, MPI_COMM_WORLD);
+  for (int p = 0; p < G; p++) ok = ok && all_info[p].np >= 0;
+  /* rank r's rows for its partner p land in p's block at header + parity*arena + recv_off_p[slot of r] rows */
+  for (int s = 0; ok && s < mine.np; s++) {
+    const ipc_info *pi = &all_info[mine.partner[s]];
+    int t = -1;
+    for (int i = 0; i < pi->np; i++)
+      if (pi->partner[i] == r) t = i;
+    const size_t base = 256 + (size_t)pi->recv_off[t < 0 ? 0 : t] * NGRAD * 3 * sizeof(double);
+    ok = t >= 0 && cfdp_gpu_ipc_connect(gpu, s, pi->handle, base, base + (size_t)pi->land, 4 * (size_t)t) == 0;
+  }
+  ok = ok && cfdp_gpu_ipc_ready(gpu) == 0;
+  int all_ok = 0;
+  MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD); /* also: nobody pushes before everybody is ready */
+  free(all_info);
+  return all_ok;
+}
+
+static void ipc_teardown(cfdp_gpu *gpu) {
+  (void)cfdp_gpu_sync(gpu);
+  MPI_Barrier(MPI_COMM_WORLD); /* nobody unmaps a block a partner may still write to */
+  (void)cfdp_gpu_ipc_disconnect(gpu);
+  MPI_Barrier(MPI_COMM_WORLD);
+}
+
+/* collective: Sigma |sent rows| (weighted by the position in the message) == Sigma |ghost rows| (same
+ * weights on the receiving side) over all ranks and no wait gave up, after 4 iterations each with var,
+ * 2*var, var -- a ghost row left over from an earlier round cannot satisfy the next.  Restores the
+ * host and device fields.                                                                    */
+static int exchange_valid(comm_data *cd, solver_data *sd, cfdp_gpu *gpu) {
+  const size_t nall = (size_t)sd->nallpoints;
+  double *var0 = cfdp_malloc(nall * NGRAD * sizeof(double));
+  double *grad0 = cfdp_malloc(nall * NGRAD * 3 * sizeof(double));
+  double *flux0 = cfdp_malloc(nall * NFLUX * sizeof(double));
+  memcpy(var0, sd->var, nall * NGRAD * sizeof(double));
+  memcpy(grad0, sd->grad, nall * NGRAD * 3 * sizeof(double));
+  memcpy(flux0, sd->psd_flux, nall * NFLUX * sizeof(double));
+  cfdp_ipc_set_wait_seconds(2.0); /* a broken mapping must not cost half a minute per iteration here */
+  int good = 1;
+  const double scales[3] = {1.0, 2.0, 1.0};
+  for (int round = 0; round < 3; round++) {
+    for (size_t i = 0; i < nall * NGRAD; i++) (&sd->var[0][0])[i] = var0[i] * scales[round];
+    cfdp_sync_fields_to_device(sd);
+    MPI_Barrier(MPI_COMM_WORLD);
+    for (int it = 0; it < 4; it++) {
+      compute_gradients_gg_gaspi_async(cd, sd, it == 3);
+      compute_psd_flux(sd);
+    }
+    cfdp_sync_fields_to_host(sd);
+    double s[3] = {0.0, 0.0, 0.0}, gs[3];
+    for (int i = 0; i < cd->ncommdomains; i++) {
+      const int p = cd->commpartner[i];
+      for (int j = 0; j < cd->sendcount[p]; j++)
+        for (int c = 0; c < NGRAD * 3; c++) s[0] += (j + 1.0) * fabs((&sd->grad[cd->sendindex[p][j]][0][0])[c]);
+      for (int j = 0; j < cd->recvcount[p]; j++)
+        for (int c = 0; c < NGRAD * 3; c++) s[1] += (j + 1.0) * fabs((&sd->grad[cd->recvindex[p][j]][0][0])[c]);
+    }
+    s[2] = g_use_ipc ? (double)(cfdp_gpu_ipc_error(gpu) != 0) : 0.0;
+    MPI_Allreduce(s, gs, 3, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
+    good = good && gs[2] == 0.0 && gs[0] > 0.0 && fabs(gs[0] - gs[1]) <= 1e-9 * gs[0];
+  }
+  const char *w = getenv("CFDP_IPC_WAIT_SECONDS");
+  cfdp_ipc_set_wait_seconds(w && atof(w) > 0 ? atof(w) : 30.0);
+  memcpy(sd->var, var0, nall * NGRAD * sizeof(double));
+  memcpy(sd->grad, grad0, nall * NGRAD * 3 * sizeof(double));
+  memcpy(sd->psd_flux, flux0, nall * NFLUX * sizeof(double));
+  cfdp_sync_fields_to_device(sd);
+  free(var0); free(grad0); free(flux0);
+  return good;
+}
+
+/* choose, set up and VALIDATE the data path between the ranks' GPUs (collective).  force_rccl: skip
+ * the IPC path.  Returns 1 = xGMI write + notify, 0 = RCCL; exits when neither works.          */
+int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
+  int G = 1, r = 0;
+  MPI_Comm_size(MPI_COMM_WORLD, &G);
+  MPI_Comm_rank(MPI_COMM_WORLD, &r);
+  g_use_ipc = 0;
+  if (G == 1 || cd->ndomains == 1) return 0;
+  cfdp_gpu *gpu = cfdp_dropin_context(sd);
+  int try_ipc = !force_rccl && !(getenv("CFDP_MPI_FORCE_RCCL") && atoi(getenv("CFDP_MPI_FORCE_RCCL")));
+  if (try_ipc) { /* one node?  then the ranks can map each other's memory */
+    MPI_Comm node;
+    int nsize = 0;
+    MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, r, MPI_INFO_NULL, &node);
+    MPI_Comm_size(node, &nsize);
+    MPI_Comm_free(&node);
+    int all_one_node = nsize == G, agreed = 0;
+    MPI_Allreduce(&all_one_node, &agreed, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
+    try_ipc = agreed;
+  }
+  const char *fg0 = getenv("CFDP_IPC_FINEGRAINED");
+  const int fg_preset = fg0 && atoi(fg0) != 0;
+  for (int attempt = 0; try_ipc && attempt < 2; attempt++) {
+    if (attempt == 1) {
+      if (fg_preset) break; /* the first attempt already used a fine-grained block */
+      setenv("CFDP_IPC_FINEGRAINED", "1", 1);
+    }
+    const char *what = attempt || fg_preset ? "fine-grained landing block" : "coarse-grained landing block";
+    if (!ipc_setup(gpu, r, G)) {
+      if (r == 0) printf("exchange: HIP IPC setup failed (%s): %s\n", what, cfdp_gpu_last_error());
+      ipc_teardown(gpu);
+      continue;
+    }
+    cfdp_attach_ipc(sd);
+    g_use_ipc = 1;
+    if (exchange_valid(cd, sd, gpu)) {
+      snprintf(g_path, sizeof g_path, "xGMI write + notify (HIP IPC, %s), validated", what);
+      if (r == 0) printf("exchange: %s\n", g_path);
+      return 1;
+    }
+    if (r == 0) printf("exchange: xGMI write + notify FAILED its validation (%s)\n", what);
+    g_use_ipc = 0;
+    cfdp_detach_external(sd);
+    ipc_teardown(gpu);
+  }
+  unsigned char id[128];
+  memset(id, 0, sizeof id);
+  int ok = cfdp_rccl_load(getenv("CFDP_RCCL_LIB")) == 0;
+  if (ok && r == 0) ok = cfdp_rccl_unique_id(id) == 0;
+  int all_ok = 0;
+  MPI_Bcast(&ok, 1, MPI_INT, 0, MPI_COMM_WORLD);
+  MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
+  if (!all_ok) {
+    if (r == 0) fprintf(stderr, "Error: no data path between the ranks' GPUs: RCCL unavailable (%s)\n", cfdp_gpu_last_error());
+    MPI_Abort(MPI_COMM_WORLD, EXIT_FAILURE);
+  }
+  MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
+  cfdp_attach_rccl(sd, id, G, r);
+  if (!exchange_valid(cd, sd, gpu)) {
+    if (r == 0) fprintf(stderr, "Error: the RCCL exchange failed its validation\n");
+    MPI_Abort(MPI_COMM_WORLD, EXIT_FAILURE);
+  }
+  snprintf(g_path, sizeof g_path, "RCCL send/recv, validated");
+  if (r == 0) printf("exchange: %s\n", g_path);
+  return 0;
+}
+
+static void hook_attach(comm_data *cd, solver_data *sd) { (void)cfdp_mpi_attach(cd, sd, 0); }
+
+static void hook_barrier(void) { MPI_Barrier(MPI_COMM_WORLD); }
+
+/* 1 if a device-side wait gave up on ANY rank since the exchange was set up (collective) */
+int cfdp_mpi_exchange_failed(solver_data *sd) {
+  int e = g_use_ipc ? cfdp_gpu_ipc_error(cfdp_dropin_context(sd)) != 0 : 0, any = 0;
+  MPI_Allreduce(&e, &any, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
+  return any;
+}
+
+static void hook_finalize(comm_data *cd) {
+  int inited = 0, finalized = 0;
+  MPI_Initialized(&inited);
+  MPI_Finalized(&finalized);
+  if (!inited || finalized) return;
+  if (g_use_ipc && cd && cd->group) {
+    cfdp_gpu *gpu = cfdp_group_context(cd);
+    if (gpu) ipc_teardown(gpu);
+    g_use_ipc = 0;
+  }
+  MPI_Barrier(MPI_COMM_WORLD);
+  if (g_own_init) MPI_Finalize();
+}
+
+__attribute__((constructor)) static void cfdp_mpi_register(void) {
+  static const cfdp_mpi_hooks hooks = {hook_init, hook_tables, hook_attach, hook_barrier, hook_finalize};
+  cfdp_register_mpi_hooks(&hooks);
+}

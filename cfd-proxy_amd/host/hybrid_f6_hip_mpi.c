@@ -3,8 +3,8 @@
  * process (reference src/hybrid.f6.c:27-101, init_communication src/comm_data.c:257-307),
  * here one rank per GPU:
  *
- *     mpiexec -n G hybrid.f6.hip.mpi -lvl [1-4] GRID_PREFIX [--flux-ref] [--var one|hash]
- *                                    [--cluster] [--rccl] [--dry-run]
+ *     mpiexec -n G hybrid.f6.hip.mpi -lvl [1-4] GRID_PREFIX [--flux-ref] [--var one|hash|volume]
+ *                                    [--cluster] [--rccl] [--dry-run] [--dump OUTPREFIX]
  *
  * MPI is the control plane only: rank/size, the broadcast of the ncclUniqueId and the exchange
  * of the (domain, idx) request lists -- what create_recvsend_index does with MPI_Send/Recv
@@ -12,10 +12,11 @@
  * the HIP IPC handles of the landing arenas.  The data path of an iteration is then xGMI write +
  * notify from kernels (cfdp_attach_ipc), otherwise RCCL over xGMI issued by the library
  * (cfdp_attach_rccl); compute_gradients_gg_* / compute_psd_flux are the reference's entry
- * points.  Rank r merges the N/G domain files that fall to it and times the same three
- * variants as test_solver, with MPI_Barrier + device sync around every sample
- * (src/solver.c:42-58).  --dry-run stops before the GPU is touched and checks the halo tables
- * (usable on a machine without GPUs).
+ * points.  Rank r merges the N/G domain files that fall to it and runs test_solver -- the
+ * reference's ten TIMINGS rows, MPI_Barrier + device sync around every sample (src/solver.c:42-58).
+ * The data path is set up and VALIDATED by the hooks of libcfdproxy_mpi.so (host/dropin_mpi.c) at the
+ * end of init_threads().  --dry-run stops before the GPU is touched and checks the halo tables
+ * (usable on a machine without GPUs); --dump writes every rank's grad / psd_flux for value tests.
  */
 #define CFDP_WITH_MPI 1
 #include "cfdproxy_hip.h"
@@ -25,13 +26,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define N_MEDIAN 25
-#define N_VARIANT 3
-
-static int cmp_double(const void *a, const void *b) {
-  double x = *(const double *)a, y = *(const double *)b;
-  return (x > y) - (x < y);
-}
+int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl); /* host/dropin_mpi.c */
+int cfdp_mpi_exchange_failed(solver_data *sd);
 
 int main(int argc, char *argv[]) {
   int provided = 0;
@@ -48,13 +44,19 @@ int main(int argc, char *argv[]) {
   }
   const int lvl = atoi(argv[2]);
   const char *prefix = argv[3];
-  int flux_ref = 0, var_hash = 0, cluster = 0, dry = 0, force_rccl = 0;
+  int flux_ref = 0, var_hash = 0, var_volume = 0, cluster = 0, dry = 0, force_rccl = 0;
+  const char *dump = NULL;
   for (int i = 4; i < argc; i++) {
     if (!strcmp(argv[i], "--flux-ref")) flux_ref = 1;
-    else if (!strcmp(argv[i], "--var") && i + 1 < argc) var_hash = !strcmp(argv[++i], "hash");
+    else if (!strcmp(argv[i], "--var") && i + 1 < argc) {
+      i++;
+      var_hash = !strcmp(argv[i], "hash");
+      var_volume = !strcmp(argv[i], "volume");
+    }
     else if (!strcmp(argv[i], "--cluster")) cluster = 1;
     else if (!strcmp(argv[i], "--dry-run")) dry = 1;
     else if (!strcmp(argv[i], "--rccl")) force_rccl = 1;
+    else if (!strcmp(argv[i], "--dump") && i + 1 < argc) dump = argv[++i];
   }
   char fname[4096];
   snprintf(fname, sizeof fname, "%s_domain_%d_lvl_%d", prefix, 0, lvl);
@@ -141,128 +143,66 @@ int main(int argc, char *argv[]) {
     return 0;
   }
 
-  /* ---- GPU side: plan, upload, communicator ---- */
+  /* ---- GPU side: plan, upload, data path ----
+   * init_threads() ends in the hook of libcfdproxy_mpi.so (host/dropin_mpi.c): xGMI write + notify through
+   * HIP IPC when all ranks share a node -- validated against the owners' rows with a short wait bound,
+   * retried with a fine-grained landing block -- else RCCL, validated the same way                    */
   if (var_hash) cfdp_fill_var(sd.var, NULL, sd.nallpoints, CFDP_VAR_HASH, 1, 1, 1);
+  /* a field every rank computes alike for a point it owns or sees as a ghost, without global ids (the
+   * dualgrid files carry none): a function of the point's dual volume, which the files store for both */
+  if (var_volume)
+    for (int p = 0; p < sd.nallpoints; p++)
+      for (int e = 0; e < NGRAD; e++) sd.var[p][e] = 1.0 + 0.01 * (e + 1) * fmod(sd.pvolume[p] * 1e9, 97.0);
+  if (force_rccl) setenv("CFDP_MPI_FORCE_RCCL", "1", 1);
   compute_communication_tables(&cd);
   init_threads(&cd, &sd, 0);
-  cfdp_gpu *gpu = cfdp_dropin_context(&sd);
   if (flux_ref) cfdp_group_set_flux_mode((cfdp_group *)cd.group, CFDP_FLUX_REFERENCE);
-  int use_ipc = 0;
-  if (G > 1 && !force_rccl) { /* one node? then the ranks can map each other's memory */
-    MPI_Comm node;
-    int nsize = 0;
-    MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, r, MPI_INFO_NULL, &node);
-    MPI_Comm_size(node, &nsize);
-    MPI_Comm_free(&node);
-    use_ipc = nsize == G;
-  }
-  if (use_ipc) {
-    /* every rank publishes {handle, arena size, partner list, receive offsets}; rank r's rows for
-     * its partner p land in p's block at header + parity*arena + recv_off_p[slot of r] rows */
-    enum { MAXP = 48 };
-    typedef struct { unsigned char handle[64]; long land; int np, partner[MAXP], recv_off[MAXP + 1]; } ipc_info;
-    ipc_info mine, *all_info = malloc((size_t)G * sizeof(ipc_info));
-    memset(&mine, 0, sizeof mine);
-    size_t land = 0;
-    int ok = cfdp_gpu_ipc_export(gpu, mine.handle, &land) == 0 && cfdp_gpu_npartners(gpu) <= MAXP;
-    mine.land = (long)land;
-    mine.np = ok ? cfdp_gpu_npartners(gpu) : -1;
-    for (int s = 0; s < mine.np; s++) {
-      size_t bytes = 0;
-      mine.partner[s] = cfdp_gpu_partner_rank(gpu, s);
-      (void)cfdp_gpu_recv_ptr(gpu, s, &bytes);
-      mine.recv_off[s + 1] = mine.recv_off[s] + (int)(bytes / (NGRAD * 3 * sizeof(double)));
-    }
-    MPI_Allgather(&mine, (int)sizeof mine, MPI_BYTE, all_info, (int)sizeof mine, MPI_BYTE, MPI_COMM_WORLD);
-    for (int p = 0; p < G; p++) ok = ok && all_info[p].np >= 0;
-    for (int s = 0; ok && s < mine.np; s++) {
-      const ipc_info *pi = &all_info[mine.partner[s]];
-      int t = -1;
-      for (int i = 0; i < pi->np; i++)
-        if (pi->partner[i] == r) t = i;
-      const size_t base = 256 + (size_t)pi->recv_off[t < 0 ? 0 : t] * NGRAD * 3 * sizeof(double);
-      ok = t >= 0 && cfdp_gpu_ipc_connect(gpu, s, pi->handle, base, base + (size_t)pi->land, 4 * (size_t)t) == 0;
-    }
-    ok = ok && cfdp_gpu_ipc_ready(gpu) == 0;
-    int all_ok = 0;
-    MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD); /* also: nobody pushes before everybody is ready */
-    free(all_info);
-    if (all_ok) {
-      cfdp_attach_ipc(&sd);
-      if (r == 0) printf("exchange: xGMI write + notify (HIP IPC)\n");
-    } else {
-      if (r == 0) printf("exchange: HIP IPC setup failed (%s), using RCCL\n", ok ? "another rank" : cfdp_gpu_last_error());
-      MPI_Barrier(MPI_COMM_WORLD);
-      cfdp_gpu_ipc_disconnect(gpu);
-      use_ipc = 0;
-    }
-  }
-  if (G > 1 && !use_ipc) {
-    unsigned char id[128];
-    if (cfdp_rccl_load(getenv("CFDP_RCCL_LIB"))) { fprintf(stderr, "Error: %s\n", cfdp_gpu_last_error()); MPI_Abort(MPI_COMM_WORLD, 1); }
-    if (r == 0 && cfdp_rccl_unique_id(id)) { fprintf(stderr, "Error: %s\n", cfdp_gpu_last_error()); MPI_Abort(MPI_COMM_WORLD, 1); }
-    MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
-    cfdp_attach_rccl(&sd, id, G, r);
-    if (r == 0) printf("exchange: RCCL send/recv\n");
-  }
 
-  /* ---- test_solver across processes ---- */
-  typedef void (*grad_fn)(comm_data *, solver_data *, int);
-  const char *names[N_VARIANT] = {"comm_free", use_ipc ? "exchange_dbl_xgmi_notify_bulk_sync" : "exchange_dbl_rccl_bulk_sync",
-                                  use_ipc ? "exchange_dbl_xgmi_notify_async" : "exchange_dbl_rccl_async"};
-  grad_fn fns[N_VARIANT] = {compute_gradients_gg_comm_free, compute_gradients_gg_mpi_bulk_sync,
-                            compute_gradients_gg_gaspi_async};
-  const int nvar = G == 1 ? 1 : N_VARIANT;
-  double median[N_VARIANT][N_MEDIAN];
-  for (int k = 0; k < N_MEDIAN; k++) {
-    for (int v = 0; v < nvar; v++) {
-      cfdp_gpu_sync(gpu);
-      MPI_Barrier(MPI_COMM_WORLD);
-      double t = -MPI_Wtime();
-      for (int i = 0; i < sd.niter; i++) {
-        fns[v](&cd, &sd, i == sd.niter - 1);
-        compute_psd_flux(&sd);
-      }
-      cfdp_gpu_sync(gpu);
-      MPI_Barrier(MPI_COMM_WORLD);
-      t += MPI_Wtime();
-      median[v][k] = t;
-    }
-    if (r == 0) { printf("."); fflush(stdout); }
-  }
-  if (r == 0) {
-    printf("\n\n*** SETUP\n");
-    printf("                                 nProc: %d\n", G);
-    printf("                                 NITER: %d\n", sd.niter);
-    printf("                              N_MEDIAN: %d\n", N_MEDIAN);
-    printf("\n*** TIMINGS\n");
-    for (int v = 0; v < nvar; v++) {
-      qsort(median[v], N_MEDIAN, sizeof(double), cmp_double);
-      printf("%38s: %10.6f\n", names[v], median[v][(N_MEDIAN - 1) / 2]);
-    }
-  }
-  /* every sent row must have arrived: sum of |ghost rows| == sum of |packed send rows| */
+  /* ---- the reference's harness: ten rows, MPI_Barrier + device sync around every sample ---- */
+  test_solver(&cd, &sd, 0);
+
+  /* every sent row must have arrived in its slot: position-weighted sums of |rows|, sender vs receiver */
   cfdp_sync_fields_to_host(&sd);
   double sums[2] = {0.0, 0.0}, gs[2] = {0.0, 0.0};
   for (int i = 0; i < cd.ncommdomains; i++) {
     const int p = cd.commpartner[i];
     for (int j = 0; j < cd.sendcount[p]; j++)
-      for (int c = 0; c < NGRAD * 3; c++) sums[0] += fabs((&sd.grad[cd.sendindex[p][j]][0][0])[c]);
+      for (int c = 0; c < NGRAD * 3; c++) sums[0] += (j + 1.0) * fabs((&sd.grad[cd.sendindex[p][j]][0][0])[c]);
+    for (int j = 0; j < cd.recvcount[p]; j++)
+      for (int c = 0; c < NGRAD * 3; c++) sums[1] += (j + 1.0) * fabs((&sd.grad[cd.recvindex[p][j]][0][0])[c]);
   }
-  for (int q = sd.nownpoints; q < sd.nallpoints; q++)
-    for (int c = 0; c < NGRAD * 3; c++) sums[1] += fabs((&sd.grad[q][0][0])[c]);
   MPI_Allreduce(sums, gs, 2, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
-  const int ok = G == 1 || fabs(gs[0] - gs[1]) <= 1e-9 * (gs[0] > 1e-300 ? gs[0] : 1e-300);
+  int ok = G == 1 || (gs[0] > 0.0 && fabs(gs[0] - gs[1]) <= 1e-9 * gs[0]);
   if (r == 0) printf("\nexchange check: sent %.12e received %.12e %s\n", gs[0], gs[1], ok ? "ok" : "MISMATCH");
-  if (use_ipc) {
-    int e = cfdp_gpu_ipc_error(gpu), any = 0;
-    MPI_Allreduce(&e, &any, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
-    if (any && r == 0) printf("exchange: a device-side wait for a partner timed out\n");
-    MPI_Barrier(MPI_COMM_WORLD); /* nobody unmaps a block a partner may still write to */
-    cfdp_gpu_ipc_disconnect(gpu);
-    MPI_Barrier(MPI_COMM_WORLD);
+  if (G > 1 && cfdp_mpi_exchange_failed(&sd)) { /* a wait that gave up voids the run, whatever the sums say */
+    if (r == 0) printf("exchange: a device-side wait for a partner timed out\n");
+    ok = 0;
   }
-  free_communication_ressources(&cd);
+  if (dump) { /* per rank: (domain, index in that domain's file) of every merged point + grad + psd_flux */
+    char out[4096];
+    snprintf(out, sizeof out, "%s_rank_%d.bin", dump, r);
+    FILE *fp = fopen(out, "wb");
+    if (!fp) { fprintf(stderr, "Error: cannot write %s\n", out); MPI_Abort(MPI_COMM_WORLD, EXIT_FAILURE); }
+    int hdr[2] = {sd.nownpoints, sd.nallpoints};
+    fwrite(hdr, sizeof(int), 2, fp);
+    for (int m = 0; m < sd.nallpoints; m++) {
+      int pair[2];
+      if (m < sd.nownpoints) {
+        int dl = 0;
+        while (dl + 1 < info->ndom_local && info->own_offset[dl + 1] <= m) dl++;
+        pair[0] = info->domain_ids[dl];
+        pair[1] = m - info->own_offset[dl];
+      } else {
+        pair[0] = info->ghost_domain[m - sd.nownpoints];
+        pair[1] = info->ghost_idx[m - sd.nownpoints];
+      }
+      fwrite(pair, sizeof(int), 2, fp);
+    }
+    fwrite(&sd.grad[0][0][0], sizeof(double), (size_t)sd.nallpoints * NGRAD * 3, fp);
+    fwrite(&sd.psd_flux[0][0], sizeof(double), (size_t)sd.nallpoints * NFLUX, fp);
+    fclose(fp);
+  }
+  free_communication_ressources(&cd); /* collective teardown of the data path */
   MPI_Barrier(MPI_COMM_WORLD);
   if (r == 0) printf(ok ? "*** SUCCESS\n" : "*** FAILURE\n");
   MPI_Finalize();

@@ -183,6 +183,15 @@ void compute_gradients_gg_mpifence_async(comm_data *cd, solver_data *sd, int fin
 void compute_gradients_gg_mpipscw_bulk_sync(comm_data *cd, solver_data *sd, int final);
 void compute_gradients_gg_mpipscw_async(comm_data *cd, solver_data *sd, int final);
 
+/* ---- the three priming calls the reference's harness makes before a sample of the early-receive /
+ * one-sided variants (src/solver.c:87,106,183,220; src/exchange_data_mpi.h:37,
+ * src/exchange_data_mpidma.h:40-42): pre-posting receives, opening a fence / PSCW epoch.  Here a partner
+ * writes into this rank's ghost block (or landing arena) at any time -- it is always "posted" and there is
+ * no window to open -- so they are no-ops, kept so that src/solver.c links unchanged.             */
+void exchange_dbl_mpi_post_recv(comm_data *cd, int dim2);
+void mpidma_async_win_fence(int assertion);
+void mpidma_async_post_start(void);
+
 /* ---- reference src/flux.h:12 -------------------------------------------------------- */
 void compute_psd_flux(solver_data *sd);
 
@@ -220,6 +229,25 @@ void cfdp_group_destroy(cfdp_group *grp);
  * up; prints median seconds per cycle in the style of test_solver's TIMINGS block
  * (src/solver.c:296-311).  Every level must have been through init_threads().              */
 void cfdp_test_vcycle(int nlevels, cfdp_group **levels, int sweeps, int ncycles);
+
+/* ---- ext: multi-process hooks.  The reference is one MPI rank per process; the library itself has no
+ * MPI dependency.  lib/libcfdproxy_mpi.so (host/dropin_mpi.c, built when an MPI is installed) registers
+ * these from a constructor, which gives the kept entry points their MPI meaning -- so the reference's
+ * main() AND its harness run unchanged under mpiexec, one rank per GPU:
+ *   init      in init_communication: MPI_Init_thread, nProc/iProc      (src/comm_data.c:257-307)
+ *   tables    in compute_communication_tables: the sendindex exchange  (src/comm_data.c:203-249)
+ *   attach    at the end of init_threads: the validated GPU-to-GPU data path (xGMI write + notify or RCCL)
+ *   barrier   around test_solver's samples                              (src/solver.c:44,56)
+ *   finalize  in free_communication_ressources                          (src/comm_data.c:504-521)    */
+typedef struct {
+  void (*init)(int *argc, char ***argv, comm_data *cd);
+  void (*tables)(comm_data *cd);
+  void (*attach)(comm_data *cd, solver_data *sd);
+  void (*barrier)(void);
+  void (*finalize)(comm_data *cd);
+} cfdp_mpi_hooks;
+void cfdp_register_mpi_hooks(const cfdp_mpi_hooks *hooks);
+const cfdp_mpi_hooks *cfdp_get_mpi_hooks(void);
 
 #ifdef __cplusplus
 }

@@ -152,6 +152,10 @@ void cfdp_attach_rccl(solver_data *sd, const void *unique_id128, int nranks, int
 /* the same for the xGMI write + notify exchange: call after cfdp_gpu_ipc_export / _connect /
  * _ready on cfdp_dropin_context(sd)                                                          */
 void cfdp_attach_ipc(solver_data *sd);
+/* undo cfdp_attach_rccl / cfdp_attach_ipc (a transport that failed its validation is being replaced);
+ * the context of the rank `cd` stands for in this process                                       */
+void cfdp_detach_external(solver_data *sd);
+cfdp_gpu *cfdp_group_context(comm_data *cd);
 int  cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
                              int flux_mode);
 

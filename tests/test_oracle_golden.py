@@ -137,7 +137,9 @@ def test_reference_binary_links_no_product_code():
     """the pin: oracle/_ref/ref_dump_raw = reference translation units + oracle/ref_dump_raw.c; the
     recipe names nothing under cfd-proxy_amd/ and the binary holds no NetCDF reader of any kind"""
     mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
-    recipe = mk[mk.index("_ref/ref_dump_raw: "):mk.index("else\nref:")]
+    start = mk.index("_ref/ref_dump_raw: ")
+    recipe = mk[start:mk.index("\n\n", start)]  # the target line and its recipe lines
+    assert "-o $@" in recipe and "$(REF)/src/$$f.c" in recipe
     assert "cfd-proxy_amd" not in recipe and "nc_classic" not in recipe and "dropin" not in recipe
     if os.path.exists(REF_RAW):
         r = subprocess.run(["nm", REF_RAW], capture_output=True, text=True)
