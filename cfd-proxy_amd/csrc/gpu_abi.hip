@@ -97,6 +97,7 @@ struct cfdp_gpu {
   std::vector<int> new2old, partner, send_off, recv_off, send_idx_host;
   std::vector<cfdp_tile_desc> h_tiles;
   bool interior_reads_ghosts = false;  // some tile without send points has a ghost in its halo
+  bool faceless_send = false;          // some send point has no faces: its stored row travels, no tile computes one
   std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
   int max_halo[2] = {0, 0}, max_blob[2] = {0, 0};  // per tile class: halo rows, blob 16-byte units
   bool streaming = false;      // per-iteration bytes exceed the Infinity Cache: non-temporal blobs/rows
@@ -333,6 +334,9 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
     if (const char *e = getenv("CFDP_ALTERNATE")) g->alternate = atoi(e) != 0;
   }
   g->send_idx_host.assign(p->send_idx, p->send_idx + nsend);
+  g->faceless_send = false;
+  for (size_t j = 0; j < nsend && p->degree; j++)
+    if (p->degree[p->send_idx[j]] == 0) g->faceless_send = true;
   if (nsend)
     HIP_TRY(hipMemcpy(g->d_sendidx, p->send_idx, sizeof(int) * nsend, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(g->d_var, 0, sizeof(double) * 8 * (size_t)p->nall));
@@ -1412,7 +1416,10 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       HIP_TRY(hipMalloc(&I.d_ent_row, sizeof(int) * ent_row.size()));
       HIP_TRY(hipMemcpy(I.d_ent_row, ent_row.data(), sizeof(int) * ent_row.size(), hipMemcpyHostToDevice));
       const char *e = getenv("CFDP_IPC_INKERNEL");
-      I.inkernel = g->nbtiles > 0 && !(e && atoi(e) == 0);
+      // the tiles push what they have just computed; a send point WITHOUT faces is computed by nobody
+      // and its stored row must travel (as pack / the push kernel send it, and the reference's
+      // exchange_dbl_copy_in, src/threads.c:791-813): such partitions keep the separate push kernel
+      I.inkernel = g->nbtiles > 0 && !g->faceless_send && !(e && atoi(e) == 0);
     }
   }
   if (flush_flux(g)) return 1;

@@ -56,6 +56,10 @@ const char *cfdp_nc_strerror(int code) {
   case CFDP_NC_ENOTFOUND: return "dimension or variable not found";
   case CFDP_NC_ETYPE: return "unsupported variable type for this accessor";
   case CFDP_NC_ENOMEM: return "out of memory";
+  case CFDP_NC_ECDF5: return "CDF-5 (64-bit data) file: convert with `nccopy -k classic` or `nccopy -k 64-bit-offset` "
+                             "(the reference's libnetcdf 3.6.3 reads CDF-1/CDF-2 only, and so does this reader)";
+  case CFDP_NC_EHDF5: return "NetCDF-4/HDF5 file: convert with `nccopy -k classic` or `nccopy -k 64-bit-offset` "
+                             "(the reference's libnetcdf 3.6.3 reads CDF-1/CDF-2 only, and so does this reader)";
   default: return "unknown error";
   }
 }
@@ -126,6 +130,10 @@ int cfdp_ncfile_open(const char *path, cfdp_ncfile **out) {
   int rc = CFDP_NC_EFORMAT;
   unsigned char magic[4];
   if (fread(magic, 1, 4, fp) != 4) { rc = CFDP_NC_EIO; goto fail; }
+  /* the formats the reference's pinned libnetcdf 3.6.3 (src/Makefile:2) reads are CDF-1 and CDF-2; name the
+   * newer containers instead of calling them corrupt, so the message says what to do (nccopy -k classic) */
+  if (magic[0] == 'C' && magic[1] == 'D' && magic[2] == 'F' && magic[3] == 5) { rc = CFDP_NC_ECDF5; goto fail; }
+  if (magic[0] == 0x89 && magic[1] == 'H' && magic[2] == 'D' && magic[3] == 'F') { rc = CFDP_NC_EHDF5; goto fail; }
   if (magic[0] != 'C' || magic[1] != 'D' || magic[2] != 'F' || (magic[3] != 1 && magic[3] != 2))
     goto fail;
   f->version = magic[3];

@@ -28,7 +28,7 @@ typedef struct cfdp_ncfile cfdp_ncfile;
 
 /* ---- reading ---- all return 0 on success, a negative CFDP_NC_E* code on failure */
 enum { CFDP_NC_OK = 0, CFDP_NC_EIO = -1, CFDP_NC_EFORMAT = -2, CFDP_NC_ENOTFOUND = -3,
-       CFDP_NC_ETYPE = -4, CFDP_NC_ENOMEM = -5 };
+       CFDP_NC_ETYPE = -4, CFDP_NC_ENOMEM = -5, CFDP_NC_ECDF5 = -6, CFDP_NC_EHDF5 = -7 };
 
 int  cfdp_ncfile_open(const char *path, cfdp_ncfile **out);
 void cfdp_ncfile_close(cfdp_ncfile *f);

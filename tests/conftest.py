@@ -78,3 +78,14 @@ def rel_err(orc, got, ref, fpoint, fnormal, pvolume, var, nown):
     scale = np.maximum(np.abs(ref), orc.np_scale(fpoint, fnormal, pvolume, var))
     scale = np.where(scale > 0, scale, 1.0)
     return float((np.abs(got - ref)[:nown] / scale[:nown]).max())
+
+
+def whole_mesh_scale(orc, truth, fpoint, fnormal, pvolume, var):
+    """per-component scale max(|g_ref|, s_p) of the un-partitioned mesh, to be indexed by global id: the
+    criterion of rel_err() for rows of a partition (ghost rows take the scale of the owner point)"""
+    scale = np.maximum(np.abs(truth), orc.np_scale(fpoint, fnormal, pvolume, var))
+    return np.where(scale > 0, scale, 1.0)
+
+
+def rel_err_rows(got, truth_rows, scale_rows):
+    return float((np.abs(got - truth_rows) / scale_rows).max())

@@ -113,6 +113,16 @@ def test_loader_errors_exit_with_code_2_like_the_reference(tmp_path):
     bad.write_bytes(b"HDF5 not netcdf classic")
     r = _run(pre + f"l.cfdp_nc_open(b'{bad}')")
     assert r.returncode == 2 and "not a NetCDF classic" in r.stderr
+    # the containers newer than what the reference's pinned libnetcdf 3.6.3 reads are named, with the fix
+    for magic, what in ((b"CDF\x05" + b"\0" * 60, "CDF-5"), (b"\x89HDF\r\n\x1a\n" + b"\0" * 60, "NetCDF-4/HDF5")):
+        bad.write_bytes(magic)
+        r = _run(pre + f"l.cfdp_nc_open(b'{bad}')")
+        assert r.returncode == 2 and what in r.stderr and "nccopy -k classic" in r.stderr, r.stderr
+    # libnetcdf's own calling convention (what the reference's main() uses): a code, explained by nc_strerror
+    r = _run(pre + "import ctypes as C; i = C.c_int(); l.nc_strerror.restype = C.c_char_p; "
+                   "rc = l.nc_open(b'/nonexistent/file', 0, C.byref(i)); print(rc, l.nc_strerror(rc).decode()); "
+                   "print(l.nc_close(12345), l.nc_strerror(l.nc_close(12345)).decode())")
+    assert r.returncode == 0 and "I/O error" in r.stdout and "not a valid ncid" in r.stdout, r.stdout + r.stderr
     gp_code = pre + f"gp = p.gen_params(4,4,4); p.write_mesh(gp, '{tmp_path}/m', 1); n = l.cfdp_nc_open(b'{tmp_path}/m_domain_0_lvl_1'); l.get_nc_val(n, b'no_such_dim')"
     r = _run(gp_code)
     assert r.returncode == 2 and "no_such_dim" in r.stderr
