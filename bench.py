@@ -193,37 +193,7 @@ def main() -> None:
             return dt
 
         def exchange_check() -> dict:
-            """every row that was sent must have arrived in ITS slot: per partner slice, a position-weighted
-            checksum of the packed send rows must equal the partner's checksum of the ghost rows it received
-            from this rank (row j of a message weighs j+1, so permuted or mis-slotted rows do not cancel);
-            and something must have been sent at all"""
-            solver.synchronize()
-            g = solver.grad_host()
-            mine = {}
-            for k in part.partners:
-                sidx, ridx = part.sendindex(k), part.recvindex(k)
-                ws, wr = np.arange(1, len(sidx) + 1.0), np.arange(1, len(ridx) + 1.0)
-                mine[int(k)] = (float((np.abs(g[sidx]).sum(axis=(1, 2)) * ws).sum()), float(np.abs(g[sidx]).sum()),
-                                float((np.abs(g[ridx]).sum(axis=(1, 2)) * wr).sum()))
-            allc = [None] * world
-            dist.all_gather_object(allc, mine)
-            ok, sent_total, worst = True, 0.0, 0.0
-            for a in range(world):
-                for b, (ws_ab, s_ab, _) in allc[a].items():
-                    got = allc[b].get(a, (0.0, 0.0, float("nan")))[2]  # what b received from a
-                    sent_total += s_ab
-                    rel = abs(ws_ab - got) / max(abs(ws_ab), 1e-300)
-                    worst = max(worst, rel if rel == rel else float("inf"))
-                    ok = ok and rel <= 1e-9
-            chk = {"sum_abs_sent_rows": sent_total, "worst_partner_slice_mismatch": worst,
-                   "check": "position-weighted |row| sums per partner slice, sender vs receiver",
-                   "ok": bool(ok and sent_total > 0.0)}
-            if solver.transport == "ipc":
-                et = torch.tensor([float(solver.gpu.ipc_error() != 0)], dtype=torch.float64, device=coll_device)
-                dist.all_reduce(et)
-                chk["wait_timeouts"] = int(et.item())
-                chk["ok"] = chk["ok"] and int(et.item()) == 0
-            return chk
+            return solver.exchange_check()
 
         # warmup (untimed), then EXACTLY K timed steps; a transport whose rows did not all arrive is dropped
         # and the measurement repeated on the next one (every rank sees the same gathered check)
@@ -256,6 +226,7 @@ def main() -> None:
                 "fused_iterations": not args.no_fusion,
                 "transport": solver.transport if world > 1 else "none (one partition)",
                 "transport_probe_us_per_iteration": solver.probe if world > 1 else {},
+                "transport_probe_rows_arrived": solver.checks if world > 1 else {},
                 "mesh_iterations_per_s": its, "via_dualgrid_files": not args.no_files,
                 "tiles": solver.gpu.stats["ntiles"], "tile_points": solver.gpu.stats["tile_points"],
                 "setup_s": round(t_setup, 2),

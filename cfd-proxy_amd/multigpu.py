@@ -191,6 +191,7 @@ class RankSolver:
         # "auto": set up both device-side transports and let choose_transport() time them
         self.available: List[str] = []
         self.probe: Dict[str, float] = {}
+        self.checks: Dict[str, bool] = {}   # choose_transport: did every row arrive in its slot, per transport
         if transport in ("ipc", "auto") and world > 1:
             import sys
             # a second attempt with a fine-grained landing block (every rank fails or passes alike:
@@ -304,18 +305,52 @@ class RankSolver:
             dt = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=self._coll_device())
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
             self.probe[name] = float(dt.item()) / steps * 1e6
-            if name == "ipc":  # a wait that gave up voids the transport (all ranks alike)
-                bad = torch.tensor([float(self.gpu.ipc_error() != 0)], dtype=torch.float64, device=self._coll_device())
-                dist.all_reduce(bad)
-                if float(bad.item()) > 0:
-                    del self.probe[name]
-                    self.available.remove(name)
+            # a transport whose rows did not all arrive in their slots (or, ipc: a wait that gave up) is
+            # out, however fast it looked (all ranks see the same gathered evidence)
+            self.checks[name] = bool(self.exchange_check()["ok"])
+            if not self.checks[name]:
+                del self.probe[name]
+                self.available.remove(name)
+                if name == "ipc":
                     self.gpu.ipc_enable(False)
         if self.probe:
             self.use_transport(min(self.probe, key=self.probe.get))
         elif self.transport not in self.available:
             self.transport = "torch"  # nothing device-side is left: torch.distributed P2P ops
         return self.transport
+
+    def exchange_check(self) -> dict:
+        """collective: every row that was sent must have arrived in ITS slot.  Per partner slice a
+        position-weighted checksum of the rows this rank sent must equal the partner's checksum of the
+        ghost rows it received from this rank (row j of a message weighs j+1, so permuted or mis-slotted
+        rows do not cancel); something must have been sent at all; no device-side wait may have given up"""
+        torch, dist, part = self.torch, self.dist, self.gpu.dom
+        g = self.grad_host()
+        mine = {}
+        for k in part.partners:
+            sidx, ridx = part.sendindex(k), part.recvindex(k)
+            ws, wr = np.arange(1, len(sidx) + 1.0), np.arange(1, len(ridx) + 1.0)
+            mine[int(k)] = (float((np.abs(g[sidx]).sum(axis=(1, 2)) * ws).sum()), float(np.abs(g[sidx]).sum()),
+                            float((np.abs(g[ridx]).sum(axis=(1, 2)) * wr).sum()))
+        allc = [None] * self.world
+        dist.all_gather_object(allc, mine)
+        ok, sent_total, worst = True, 0.0, 0.0
+        for a in range(self.world):
+            for b, (ws_ab, s_ab, _) in allc[a].items():
+                got = allc[b].get(a, (0.0, 0.0, float("nan")))[2]  # what b received from a
+                sent_total += s_ab
+                rel = abs(ws_ab - got) / max(abs(ws_ab), 1e-300)
+                worst = max(worst, rel if rel == rel else float("inf"))
+                ok = ok and rel <= 1e-9
+        chk = {"sum_abs_sent_rows": sent_total, "worst_partner_slice_mismatch": worst,
+               "check": "position-weighted |row| sums per partner slice, sender vs receiver",
+               "ok": bool(ok and sent_total > 0.0)}
+        if self.transport == "ipc":
+            et = torch.tensor([float(self.gpu.ipc_error() != 0)], dtype=torch.float64, device=self._coll_device())
+            dist.all_reduce(et)
+            chk["wait_timeouts"] = int(et.item())
+            chk["ok"] = chk["ok"] and int(et.item()) == 0
+        return chk
 
     def fallback(self) -> bool:
         """collective (every rank takes the same decision from the same all-reduced evidence): give up

@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--ndomains", type=int, default=12)
     ap.add_argument("--files", action="store_true")
     ap.add_argument("--transport", default="staged")
+    ap.add_argument("--per-device", action="store_true",
+                    help="one device per rank (LOCAL_RANK) and the nccl backend: the real multi-GPU set-up")
+    ap.add_argument("--soak", type=int, default=0, help="extra iterations before the values are checked")
     ap.add_argument("--fail-first-validation", action="store_true",
                     help="the first exchange validation reports failure: the set-up must be torn down and retried")
     args = ap.parse_args()
@@ -30,7 +33,13 @@ def main():
     import torch.distributed as dist
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    device = 0
+    if args.per_device:
+        device = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count()
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg, orc = load_package(), load_oracle()
     from cfd_proxy_amd import multigpu as mg
 
@@ -80,8 +89,10 @@ def main():
             dist.destroy_process_group()
             return
         for fusion in (False, True):
-            solver = mg.RankSolver(part, rank, world, 0, dist, transport=args.transport, tile_points=32, fusion=fusion)
+            solver = mg.RankSolver(part, rank, world, device, dist, transport=args.transport, tile_points=32, fusion=fusion)
             assert solver.transport == args.transport, solver.transport  # no silent fallback in the tests
+            if args.soak:
+                solver.run_steps(args.soak, with_exchange=True, overlap=True)
             for overlap in (True, False):
                 part.grad[:] = 1.0
                 part.psd_flux[:] = 2.0

@@ -19,12 +19,12 @@ def _free_port():
     return p
 
 
-def _launch(world, extra):
+def _launch(world, extra, extra_env=None):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rank_worker.py")] + extra,
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -67,6 +67,29 @@ def test_write_notify_setup_is_retried_with_a_fine_grained_block(gpu):
     """a failed exchange validation tears the IPC mappings down on every rank and the set-up is retried
     once with a fine-grained landing block (CFDP_IPC_FINEGRAINED=1) before any other transport is tried"""
     _launch(2, ["--gpu", "--fail-first-validation"])
+
+
+def _device_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+two_devices = pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs (a 1-GPU box shares cuda:0 between the ranks instead)")
+
+
+@pytest.mark.gpu
+@two_devices
+@pytest.mark.parametrize("transport,env", [("ipc", {"CFDP_IPC_FINEGRAINED": "0"}), ("ipc", {"CFDP_IPC_FINEGRAINED": "1"}),
+                                           ("rccl", {})])
+def test_transports_between_two_devices_against_the_oracle(gpu, transport, env):
+    """the first thing to run on a multi-GPU node (also: tools/multigpu_selftest.py): one rank per DEVICE, the xGMI
+    write + notify exchange with a coarse-grained and with a fine-grained landing block, and the C library's RCCL
+    send/recv group (cfdp_gpu_step_rccl), 1000 iterations each, then owned AND ghost rows and the flux of every rank
+    against the un-partitioned mesh -- stale ghost rows across xGMI cannot pass"""
+    _launch(2, ["--gpu", "--per-device", "--transport", transport, "--soak", "1000"], extra_env=env)
 
 
 MPIEXEC = "/opt/conda/bin/mpiexec"

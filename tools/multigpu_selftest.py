@@ -1,0 +1,43 @@
+"""First thing to run on a node with >= 2 GPUs: one rank per device, each device-side exchange for 1000 iterations,
+values of every rank (owned AND ghost gradient rows, flux) against the un-partitioned mesh.  Prints which passed.
+
+    python tools/multigpu_selftest.py [NRANKS]
+
+  ipc / coarse-grained   xGMI write + notify into a hipMalloc'd landing block (system-scope loads and fences)
+  ipc / fine-grained     the same into a fine-grained block (CFDP_IPC_FINEGRAINED=1)
+  rccl                   grouped ncclSend/ncclRecv issued by the C library (cfdp_gpu_step_rccl)
+"""
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+cases = [("ipc / coarse-grained", "ipc", {"CFDP_IPC_FINEGRAINED": "0"}), ("ipc / fine-grained", "ipc", {"CFDP_IPC_FINEGRAINED": "1"}),
+         ("rccl", "rccl", {})]
+results = {}
+for label, transport, env in cases:
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                 OMP_NUM_THREADS="2", **env)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rank_worker.py"), "--gpu", "--per-device",
+                                       "--transport", transport, "--soak", "1000", "--dims", "32,24,24", "--ndomains", str(4 * n)],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    ok, tails = True, []
+    for r, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            out = "TIMEOUT"
+        ok = ok and p.returncode == 0 and f"RANK_OK {r}" in out
+        tails.append(out[-800:])
+    results[label] = ok
+    print(f"{label:24s} {'PASSED' if ok else 'FAILED'}", flush=True)
+    if not ok:
+        print("\n".join(tails), flush=True)
+sys.exit(0 if all(results.values()) else 1)
