@@ -559,14 +559,29 @@ def algo_bytes_flux(nfaces: int, nown: int, nadd: int) -> float:
 class Plan:
     """The GPU tiling of one partition (host/tiling.c) -- the init_threads() analogue."""
 
-    def __init__(self, dom: Domain, tile_points: int = 0, boundary_first: bool = True):
+    def __init__(self, dom: Domain, tile_points: int = 0, boundary_first: bool = True, device_stages: int = 0,
+                 device: int = 0):
+        """device_stages: 0 = all on the host; bit 0 = the point->face CSR, bit 1 = the tile blobs built by HIP
+        kernels on `device` (cfdp_plan_build_gpu; needs a GPU, no fallback); stage_seconds then holds their times"""
         lib = host_lib()
         o = PlanOpts()
         lib.cfdp_plan_default_opts(C.byref(o))
         if tile_points:
             o.tile_points = tile_points
         o.boundary_first = 1 if boundary_first else 0
-        self.ptr = lib.cfdp_plan_build(C.byref(dom.sd), C.byref(dom.cd), C.byref(o))
+        self.stage_seconds = None
+        if device_stages:
+            hl = hip_lib()
+            hl.cfdp_plan_build_gpu.argtypes = [C.POINTER(SolverData), C.POINTER(CommData), C.POINTER(PlanOpts), C.c_int, C.c_int,
+                                               C.POINTER(C.POINTER(PlanStruct)), C.POINTER(C.c_double)]
+            ptr = C.POINTER(PlanStruct)()
+            secs = (C.c_double * 2)()
+            if hl.cfdp_plan_build_gpu(C.byref(dom.sd), C.byref(dom.cd), C.byref(o), device, device_stages, C.byref(ptr), secs):
+                raise GpuError(hl.cfdp_gpu_last_error().decode())
+            self.ptr = ptr
+            self.stage_seconds = (secs[0], secs[1])
+        else:
+            self.ptr = lib.cfdp_plan_build(C.byref(dom.sd), C.byref(dom.cd), C.byref(o))
         if not self.ptr:
             raise RuntimeError("plan build failed")
         self.p = self.ptr.contents
@@ -619,11 +634,12 @@ class GpuPartition:
         self.dom = dom
         self.h = C.c_void_p()
         self._ck(self.lib.cfdp_gpu_create(device, C.byref(self.h)))
-        plan = Plan(dom, tile_points, boundary_first)
+        # CFDP_PLAN_DEVICE: which heavy stages of the plan run as HIP kernels (bit 0 CSR, bit 1 tile blobs)
+        plan = Plan(dom, tile_points, boundary_first, device_stages=int(os.environ.get("CFDP_PLAN_DEVICE", "0")), device=device)
         self.stats = dict(ntiles=plan.ntiles, nbtiles=plan.nbtiles, nfaces_used=plan.nfaces_used,
                           nfaces_dup=plan.nfaces_dup, ninc=plan.ninc_total, lds_grad=plan.lds_grad,
                           lds_flux=plan.lds_flux, blob_bytes=plan.blob_bytes, nhalo=plan.nhalo_total,
-                          tile_points=plan.tile_points)
+                          tile_points=plan.tile_points, plan_stage_seconds=plan.stage_seconds)
         try:
             self._ck(self.lib.cfdp_gpu_upload_plan(self.h, plan.ptr))
         finally:

@@ -36,6 +36,15 @@ int fail(const char *fmt, ...) {
 
 }  // namespace
 
+// for the other translation units of the library (plan_kernels.hip): same buffer as cfdp_gpu_last_error()
+int cfdp_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
 struct cfdp_gpu {
   int device = 0;
   hipStream_t s_main = nullptr, s_comm = nullptr;

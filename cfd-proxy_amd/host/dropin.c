@@ -166,15 +166,21 @@ void init_threads(comm_data *cd, solver_data *sd, int NTHREADS) {
     device_rank = ip; /* ranks of a node take its devices in turn */
   }
   CFDP_ASSERT(rank >= 0 && rank < grp->G);
-  cfdp_plan *plan = cfdp_plan_build(sd, cd, &o);
   int ndev = cfdp_gpu_device_count();
   if (ndev <= 0) {
     fprintf(stderr, "Error: no HIP device (the GPU path has no CPU fallback) [%s:%i]\n", __FILE__, __LINE__);
     exit(EXIT_FAILURE);
   }
-  cfdp_gpu *gpu = NULL;
   const char *devenv = getenv("CFDP_DEVICE"); /* default: ranks of a node take its devices in turn */
-  GPU_OK(cfdp_gpu_create(devenv ? atoi(devenv) : device_rank % ndev, &gpu));
+  const int device = devenv ? atoi(devenv) : device_rank % ndev;
+  /* the plan: tile growth on the host; its two heavy stages on the host too, or -- CFDP_PLAN_DEVICE bit 0 / 1 --
+   * as HIP kernels (the reference's init_thread_rangelist work, src/rangelist.c:500-764, on the device)        */
+  cfdp_plan *plan = NULL;
+  const char *pd = getenv("CFDP_PLAN_DEVICE");
+  if (pd && (atoi(pd) & 3)) GPU_OK(cfdp_plan_build_gpu(sd, cd, &o, device, atoi(pd) & 3, &plan, NULL));
+  else plan = cfdp_plan_build(sd, cd, &o);
+  cfdp_gpu *gpu = NULL;
+  GPU_OK(cfdp_gpu_create(device, &gpu));
   GPU_OK(cfdp_gpu_upload_plan(gpu, plan));
   cfdp_plan_free(plan);
   /* fused iterations: compute_psd_flux() defers the flux loop into the pass of the next

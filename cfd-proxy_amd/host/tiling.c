@@ -147,27 +147,13 @@ static inline int lmap_index(lmap *m, int k, int *next) {
   }
 }
 
-cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *opts) {
-  cfdp_plan_opts o;
-  if (opts) o = *opts; else cfdp_plan_default_opts(&o);
-  CFDP_ASSERT(o.tile_points >= 8 && o.tile_points <= 1024);
-  const int nown = sd->nownpoints, nall = sd->nallpoints, nf = sd->nfaces;
-  CFDP_ASSERT(nown > 0 && nall >= nown);
-  const int has_comm = cd && cd->ndomains > 1 && cd->ncommdomains > 0;
-
-  const int trace = getenv("CFDP_PLAN_TRACE") != NULL;
-  double t_prev = cfdp_now();
-#define PLAN_STAGE(name)                                                              \
-  do {                                                                                \
-    if (trace) { double t_ = cfdp_now(); fprintf(stderr, "[plan] %-28s %.3f s\n", name, t_ - t_prev); t_prev = t_; } \
-  } while (0)
-  cfdp_plan *P = cfdp_calloc(1, sizeof(*P));
-  P->nown = nown; P->nall = nall; P->tile_points = o.tile_points;
-
-  /* ---- 1. point -> incident faces (CSR over owned points, file face order) ----
-   * Every thread streams the whole face list but only keeps the ends that fall into its own
-   * range of points: the scattered writes stay inside a cache-sized slice, and a point's list
-   * is in file order whatever the thread count (the order the kernels add a point's faces in). */
+/* stage 1 on the host.  Every thread streams the whole face list but only keeps the ends that fall into its own
+ * range of points: the scattered writes stay inside a cache-sized slice, and a point's list is in file order
+ * whatever the thread count (the order the kernels add a point's faces in).
+ * Out: xadj[nown+1], adj_face[nadj] (bit 31: the owned end is p1), adj_other[nadj] (the other end, file id). */
+static int host_csr(const solver_data *sd, int **xadj_out, int **adj_face_out, int **adj_other_out, long *used_out, void *ctx) {
+  (void)ctx;
+  const int nown = sd->nownpoints, nf = sd->nfaces;
   int *xadj = cfdp_calloc((size_t)nown + 2, sizeof(int));
   long used = 0;
 #pragma omp parallel reduction(+ : used)
@@ -181,7 +167,6 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
       if (th == 0 && (a < nown || b < nown)) used++;
     }
   }
-  P->nfaces_used = used;
   for (int p = 0; p < nown; p++) xadj[p + 1] += xadj[p];
   const int nadj = xadj[nown];
   int *adj_face = cfdp_malloc((size_t)(nadj ? nadj : 1) * sizeof(int)); /* bit31: owned end is p1 */
@@ -199,7 +184,190 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
     }
   }
   free(fill);
+  *xadj_out = xadj; *adj_face_out = adj_face; *adj_other_out = adj_other; *used_out = used;
+  return 0;
+}
 
+/* stage 5 on the host.  Tiles are independent: pass A sizes every tile, a prefix sum places its blob and its halo
+ * list, pass B fills them -- both passes in parallel over tiles.  The tile-local numbering of faces and halo
+ * points (first touch, walking the tile's points and their faces in file order) lives in small per-thread hash
+ * maps instead of mesh-sized stamp arrays.  Needs P->ntiles, nbtiles, nown, old2new; fills tiles, blob, halo_idx,
+ * the LDS sizes and the totals.                                                                              */
+static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P, void *ctx) {
+  (void)ctx;
+  const int nown = P->nown;
+  P->tiles = cfdp_calloc((size_t)P->ntiles, sizeof(cfdp_tile_desc));
+  int max_inc = 1;
+  for (int t = 0; t < P->ntiles; t++) {
+    int n = 0;
+    for (int i = tl->tile_first[t]; i < tl->tile_first[t + 1]; i++) n += tl->xadj[tl->order[i] + 1] - tl->xadj[tl->order[i]];
+    if (n > max_inc) max_inc = n;
+  }
+  long lds_g[2] = {0, 0}, lds_f[2] = {0, 0};
+  long *boff = cfdp_calloc((size_t)P->ntiles + 1, sizeof(long)); /* blob offsets, bytes */
+  long *hoff = cfdp_calloc((size_t)P->ntiles + 1, sizeof(long)); /* halo offsets, entries */
+  long dup_total = 0, inc_total = 0;
+  int bad = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) {
+      for (int t = 0; t < P->ntiles; t++) {
+        boff[t + 1] += boff[t];
+        hoff[t + 1] += hoff[t];
+      }
+      P->blob_bytes = boff[P->ntiles];
+      P->nhalo_total = hoff[P->ntiles];
+      CFDP_ASSERT(P->blob_bytes % 16 == 0 && P->blob_bytes / 16 < 0x7FFFFFFF);
+      P->blob = cfdp_malloc((size_t)(P->blob_bytes ? P->blob_bytes : 16));
+      P->halo_idx = cfdp_malloc((size_t)(P->nhalo_total ? P->nhalo_total : 1) * sizeof(int));
+    }
+#pragma omp parallel reduction(+ : dup_total, inc_total) reduction(| : bad)
+    {
+      lmap fmap, hmap;
+      lmap_init(&fmap, max_inc);
+      lmap_init(&hmap, max_inc);
+      long tg[2] = {0, 0}, tf[2] = {0, 0};
+#pragma omp for schedule(dynamic, 64)
+      for (int t = 0; t < P->ntiles; t++) {
+        const int ts = tl->tile_first[t], te = tl->tile_first[t + 1], np = te - ts;
+        cfdp_tile_desc *td = &P->tiles[t];
+        lmap_reset(&fmap);
+        lmap_reset(&hmap);
+        int E = 0, H = 0, I = 0;
+        if (pass == 0) {
+          for (int li = 0; li < np; li++) {
+            int p = tl->order[ts + li];
+            for (int e = tl->xadj[p]; e < tl->xadj[p + 1]; e++) {
+              int q = tl->adj_other[e];
+              int f = tl->adj_face[e] & 0x7FFFFFFF, sgn = (unsigned)tl->adj_face[e] >> 31;
+              int in_tile = q < nown && tl->tile_of[q] == t;
+              I++;
+              /* an internal face is listed by both ends and numbered at its p0 end */
+              if (!in_tile || sgn == 0) lmap_index(&fmap, f, &E);
+              if (!in_tile) lmap_index(&hmap, q, &H);
+            }
+          }
+          if (np + H > 65535 || E > 32767) bad = 1;
+          td->pstart = ts; td->npts = np;
+          td->nhalo = H; td->nfaces = E; td->ninc = I;
+          const long b_fn = cfdp_blob_fn_bytes(E), b_inc = cfdp_blob_inc_bytes(I), b_off = cfdp_blob_off_bytes(np);
+          td->blob_qw = (int)((b_fn + b_inc + b_off) / 16);
+          boff[t + 1] = b_fn + b_inc + b_off;
+          hoff[t + 1] = H;
+          dup_total += E;
+          inc_total += I;
+          const int cls = t < P->nbtiles ? 0 : 1;
+          long lg = (long)td->blob_qw * 16 + (long)(np + H) * 64;
+          long lf = (long)td->blob_qw * 16 + (long)(np + H) * 80;
+          if (lg > tg[cls]) tg[cls] = lg;
+          if (lf > tf[cls]) tf[cls] = lf;
+        } else {
+          td->blob_off = (int)(boff[t] / 16);
+          td->halo_off = (int)hoff[t];
+          E = td->nfaces;
+          const long b_fn = cfdp_blob_fn_bytes(E), b_inc = cfdp_blob_inc_bytes(td->ninc);
+          unsigned char *bp = P->blob + boff[t];
+          memset(bp, 0, (size_t)(boff[t + 1] - boff[t])); /* alignment padding is defined */
+          int *hp = P->halo_idx + hoff[t];
+          double *fn = (double *)bp;
+          const long plane = cfdp_blob_plane_bytes(E) / 8; /* doubles per normal-component plane */
+          uint32_t *inc = (uint32_t *)(bp + b_fn);
+          uint32_t *ioff = (uint32_t *)(bp + b_fn + b_inc);
+          /* numbering pass first (an internal face may be met at its p1 end before its p0 end) */
+          int En = 0, Hn = 0;
+          for (int li = 0; li < np; li++) {
+            int p = tl->order[ts + li];
+            for (int e = tl->xadj[p]; e < tl->xadj[p + 1]; e++) {
+              int q = tl->adj_other[e];
+              int f = tl->adj_face[e] & 0x7FFFFFFF, sgn = (unsigned)tl->adj_face[e] >> 31;
+              int in_tile = q < nown && tl->tile_of[q] == t;
+              if (!in_tile || sgn == 0) lmap_index(&fmap, f, &En);
+              if (!in_tile) lmap_index(&hmap, q, &Hn);
+            }
+          }
+          int Ic = 0;
+          for (int li = 0; li < np; li++) {
+            int p = tl->order[ts + li];
+            ioff[li] = (uint32_t)Ic;
+            for (int e = tl->xadj[p]; e < tl->xadj[p + 1]; e++) {
+              int q = tl->adj_other[e];
+              int f = tl->adj_face[e] & 0x7FFFFFFF;
+              unsigned sgn = (unsigned)tl->adj_face[e] >> 31;
+              int in_tile = q < nown && tl->tile_of[q] == t;
+              int dummy = 0;
+              int lf = lmap_index(&fmap, f, &dummy);
+              /* an internal face is listed by both ends; the normal is stored once */
+              fn[lf] = sd->fnormal[f][0];
+              fn[plane + lf] = sd->fnormal[f][1];
+              fn[2 * plane + lf] = sd->fnormal[f][2];
+              unsigned nbr;
+              if (in_tile) nbr = (unsigned)(P->old2new[q] - ts);
+              else {
+                int hv = lmap_index(&hmap, q, &dummy);
+                nbr = (unsigned)(np + hv);
+                hp[hv] = P->old2new[q];
+              }
+              inc[Ic++] = nbr | ((unsigned)lf << 16) | (sgn << 31);
+            }
+          }
+          ioff[np] = (uint32_t)Ic;
+          if (Ic != td->ninc || En != E || Hn != td->nhalo) bad = 1;
+        }
+      }
+#pragma omp critical
+      for (int c = 0; c < 2; c++) {
+        if (tg[c] > lds_g[c]) lds_g[c] = tg[c];
+        if (tf[c] > lds_f[c]) lds_f[c] = tf[c];
+      }
+      lmap_free(&fmap);
+      lmap_free(&hmap);
+    }
+    if (bad) { free(boff); free(hoff); return 1; }
+  }
+  P->nfaces_dup = dup_total;
+  P->ninc_total = inc_total;
+  free(boff); free(hoff);
+  for (int c = 0; c < 2; c++) { P->lds_grad_cls[c] = lds_g[c]; P->lds_flux_cls[c] = lds_f[c]; }
+  P->lds_grad = lds_g[0] > lds_g[1] ? lds_g[0] : lds_g[1];
+  P->lds_flux = lds_f[0] > lds_f[1] ? lds_f[0] : lds_f[1];
+  return 0;
+}
+
+/* the host's stage 5, for a provider that has to decline a mesh (a tile too big for its scratch memory) */
+int cfdp_plan_host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P) { return host_blobs(sd, tl, P, NULL); }
+
+cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *opts) {
+  return cfdp_plan_build_with(sd, cd, opts, NULL);
+}
+
+/* the plan with stage 1 (point->face CSR) and / or stage 5 (tile blobs) done by `stages` -- e.g. on the device
+ * (csrc/plan_kernels.hip) -- and everything else (tile growth, tile order, renumbering, pack lists) here */
+cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *opts,
+                                const cfdp_plan_stages *stages) {
+  cfdp_plan_opts o;
+  if (opts) o = *opts; else cfdp_plan_default_opts(&o);
+  CFDP_ASSERT(o.tile_points >= 8 && o.tile_points <= 1024);
+  const int nown = sd->nownpoints, nall = sd->nallpoints;
+  CFDP_ASSERT(nown > 0 && nall >= nown);
+  const int has_comm = cd && cd->ndomains > 1 && cd->ncommdomains > 0;
+
+  const int trace = getenv("CFDP_PLAN_TRACE") != NULL;
+  double t_prev = cfdp_now();
+#define PLAN_STAGE(name)                                                              \
+  do {                                                                                \
+    if (trace) { double t_ = cfdp_now(); fprintf(stderr, "[plan] %-28s %.3f s\n", name, t_ - t_prev); t_prev = t_; } \
+  } while (0)
+  cfdp_plan *P = cfdp_calloc(1, sizeof(*P));
+  P->nown = nown; P->nall = nall; P->tile_points = o.tile_points;
+
+  /* ---- 1. point -> incident faces (CSR over owned points, file face order): host or device ---- */
+  int *xadj = NULL, *adj_face = NULL, *adj_other = NULL;
+  long used = 0;
+  {
+    const int rc = stages && stages->csr ? stages->csr(sd, &xadj, &adj_face, &adj_other, &used, stages->ctx)
+                                         : host_csr(sd, &xadj, &adj_face, &adj_other, &used, NULL);
+    CFDP_ASSERT(rc == 0 && xadj && adj_face && adj_other);
+  }
+  P->nfaces_used = used;
   PLAN_STAGE("point->face CSR");
   /* ---- 2. which owned points are sent (reference htype 2, src/rangelist.c:129-141) ---- */
   unsigned char *is_send = cfdp_calloc((size_t)nown, 1);
@@ -381,144 +549,12 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
   }
 
   PLAN_STAGE("renumber");
-  /* ---- 5. per-tile face copies, halo lists, incidence lists ----
-   * Tiles are independent: pass A sizes every tile, a prefix sum places its blob and its halo
-   * list, pass B fills them -- both passes in parallel over tiles.  The tile-local numbering
-   * of faces and halo points (first touch, walking the tile's points and their faces in file
-   * order) lives in small per-thread hash maps instead of mesh-sized stamp arrays.           */
-  P->tiles = cfdp_calloc((size_t)P->ntiles, sizeof(cfdp_tile_desc));
-  int max_inc = 1;
-  for (int t = 0; t < P->ntiles; t++) {
-    int n = 0;
-    for (int i = T.tile_first[t]; i < T.tile_first[t + 1]; i++) n += xadj[T.order[i] + 1] - xadj[T.order[i]];
-    if (n > max_inc) max_inc = n;
+  /* ---- 5. per-tile face copies, halo lists, incidence lists: host or device ---- */
+  {
+    cfdp_tiling tl = {xadj, adj_face, adj_other, T.order, T.tile_first, T.tile_of};
+    const int rc = stages && stages->blobs ? stages->blobs(sd, &tl, P, stages->ctx) : host_blobs(sd, &tl, P, NULL);
+    CFDP_ASSERT(rc == 0); /* tile too large for 16-bit neighbour / 15-bit face slots, or an internal error */
   }
-  long lds_g[2] = {0, 0}, lds_f[2] = {0, 0};
-  long *boff = cfdp_calloc((size_t)P->ntiles + 1, sizeof(long)); /* blob offsets, bytes */
-  long *hoff = cfdp_calloc((size_t)P->ntiles + 1, sizeof(long)); /* halo offsets, entries */
-  long dup_total = 0, inc_total = 0;
-  int bad = 0;
-  for (int pass = 0; pass < 2; pass++) {
-    if (pass == 1) {
-      for (int t = 0; t < P->ntiles; t++) {
-        boff[t + 1] += boff[t];
-        hoff[t + 1] += hoff[t];
-      }
-      P->blob_bytes = boff[P->ntiles];
-      P->nhalo_total = hoff[P->ntiles];
-      CFDP_ASSERT(P->blob_bytes % 16 == 0 && P->blob_bytes / 16 < 0x7FFFFFFF);
-      P->blob = cfdp_malloc((size_t)(P->blob_bytes ? P->blob_bytes : 16));
-      P->halo_idx = cfdp_malloc((size_t)(P->nhalo_total ? P->nhalo_total : 1) * sizeof(int));
-    }
-#pragma omp parallel reduction(+ : dup_total, inc_total) reduction(| : bad)
-    {
-      lmap fmap, hmap;
-      lmap_init(&fmap, max_inc);
-      lmap_init(&hmap, max_inc);
-      long tg[2] = {0, 0}, tf[2] = {0, 0};
-#pragma omp for schedule(dynamic, 64)
-      for (int t = 0; t < P->ntiles; t++) {
-        const int ts = T.tile_first[t], te = T.tile_first[t + 1], np = te - ts;
-        cfdp_tile_desc *td = &P->tiles[t];
-        lmap_reset(&fmap);
-        lmap_reset(&hmap);
-        int E = 0, H = 0, I = 0;
-        if (pass == 0) {
-          for (int li = 0; li < np; li++) {
-            int p = T.order[ts + li];
-            for (int e = xadj[p]; e < xadj[p + 1]; e++) {
-              int q = adj_other[e];
-              int f = adj_face[e] & 0x7FFFFFFF, sgn = (unsigned)adj_face[e] >> 31;
-              int in_tile = q < nown && T.tile_of[q] == t;
-              I++;
-              /* an internal face is listed by both ends and numbered at its p0 end */
-              if (!in_tile || sgn == 0) lmap_index(&fmap, f, &E);
-              if (!in_tile) lmap_index(&hmap, q, &H);
-            }
-          }
-          if (np + H > 65535 || E > 32767) bad = 1;
-          td->pstart = ts; td->npts = np;
-          td->nhalo = H; td->nfaces = E; td->ninc = I;
-          const long b_fn = cfdp_blob_fn_bytes(E), b_inc = cfdp_blob_inc_bytes(I), b_off = cfdp_blob_off_bytes(np);
-          td->blob_qw = (int)((b_fn + b_inc + b_off) / 16);
-          boff[t + 1] = b_fn + b_inc + b_off;
-          hoff[t + 1] = H;
-          dup_total += E;
-          inc_total += I;
-          const int cls = t < P->nbtiles ? 0 : 1;
-          long lg = (long)td->blob_qw * 16 + (long)(np + H) * 64;
-          long lf = (long)td->blob_qw * 16 + (long)(np + H) * 80;
-          if (lg > tg[cls]) tg[cls] = lg;
-          if (lf > tf[cls]) tf[cls] = lf;
-        } else {
-          td->blob_off = (int)(boff[t] / 16);
-          td->halo_off = (int)hoff[t];
-          E = td->nfaces;
-          const long b_fn = cfdp_blob_fn_bytes(E), b_inc = cfdp_blob_inc_bytes(td->ninc);
-          unsigned char *bp = P->blob + boff[t];
-          memset(bp, 0, (size_t)(boff[t + 1] - boff[t])); /* alignment padding is defined */
-          int *hp = P->halo_idx + hoff[t];
-          double *fn = (double *)bp;
-          const long plane = cfdp_blob_plane_bytes(E) / 8; /* doubles per normal-component plane */
-          uint32_t *inc = (uint32_t *)(bp + b_fn);
-          uint32_t *ioff = (uint32_t *)(bp + b_fn + b_inc);
-          /* numbering pass first (an internal face may be met at its p1 end before its p0 end) */
-          int En = 0, Hn = 0;
-          for (int li = 0; li < np; li++) {
-            int p = T.order[ts + li];
-            for (int e = xadj[p]; e < xadj[p + 1]; e++) {
-              int q = adj_other[e];
-              int f = adj_face[e] & 0x7FFFFFFF, sgn = (unsigned)adj_face[e] >> 31;
-              int in_tile = q < nown && T.tile_of[q] == t;
-              if (!in_tile || sgn == 0) lmap_index(&fmap, f, &En);
-              if (!in_tile) lmap_index(&hmap, q, &Hn);
-            }
-          }
-          int Ic = 0;
-          for (int li = 0; li < np; li++) {
-            int p = T.order[ts + li];
-            ioff[li] = (uint32_t)Ic;
-            for (int e = xadj[p]; e < xadj[p + 1]; e++) {
-              int q = adj_other[e];
-              int f = adj_face[e] & 0x7FFFFFFF;
-              unsigned sgn = (unsigned)adj_face[e] >> 31;
-              int in_tile = q < nown && T.tile_of[q] == t;
-              int dummy = 0;
-              int lf = lmap_index(&fmap, f, &dummy);
-              /* an internal face is listed by both ends; the normal is stored once */
-              fn[lf] = sd->fnormal[f][0];
-              fn[plane + lf] = sd->fnormal[f][1];
-              fn[2 * plane + lf] = sd->fnormal[f][2];
-              unsigned nbr;
-              if (in_tile) nbr = (unsigned)(P->old2new[q] - ts);
-              else {
-                int hv = lmap_index(&hmap, q, &dummy);
-                nbr = (unsigned)(np + hv);
-                hp[hv] = P->old2new[q];
-              }
-              inc[Ic++] = nbr | ((unsigned)lf << 16) | (sgn << 31);
-            }
-          }
-          ioff[np] = (uint32_t)Ic;
-          if (Ic != td->ninc || En != E || Hn != td->nhalo) bad = 1;
-        }
-      }
-#pragma omp critical
-      for (int c = 0; c < 2; c++) {
-        if (tg[c] > lds_g[c]) lds_g[c] = tg[c];
-        if (tf[c] > lds_f[c]) lds_f[c] = tf[c];
-      }
-      lmap_free(&fmap);
-      lmap_free(&hmap);
-    }
-    CFDP_ASSERT(!bad); /* tile too large for 16-bit neighbour / 15-bit face slots, or an internal error */
-  }
-  P->nfaces_dup = dup_total;
-  P->ninc_total = inc_total;
-  free(boff); free(hoff);
-  for (int c = 0; c < 2; c++) { P->lds_grad_cls[c] = lds_g[c]; P->lds_flux_cls[c] = lds_f[c]; }
-  P->lds_grad = lds_g[0] > lds_g[1] ? lds_g[0] : lds_g[1];
-  P->lds_flux = lds_f[0] > lds_f[1] ? lds_f[0] : lds_f[1];
   PLAN_STAGE("tile blobs");
 #undef PLAN_STAGE
   free(T.hseen);

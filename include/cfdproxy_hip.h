@@ -53,6 +53,15 @@ const char *cfdp_gpu_last_error(void);
 int  cfdp_gpu_create(int device, cfdp_gpu **out);
 void cfdp_gpu_destroy(cfdp_gpu *g);
 
+/* the plan with its two heavy stages done by HIP kernels (csrc/plan_kernels.hip) -- the reference's
+ * init_threads() preprocessing (src/rangelist.c:500-764, src/thread_comm.c:27-432) on the device: `which` bit 0 =
+ * point->face CSR (atomics + scan + per-point sort), bit 1 = per-tile blobs (one workgroup per tile: first-touch
+ * numbering by prefix sums and an LDS hash).  Tile growth (BFS), tile order, renumbering and pack lists stay on
+ * the host.  The result is bit-identical to cfdp_plan_build()'s; free it with cfdp_plan_free().
+ * stage_seconds (optional): [0] stage 1, [1] stage 5 (-1: fell back to the host stage), transfers included. */
+int  cfdp_plan_build_gpu(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *opts, int device, int which,
+                         cfdp_plan **out, double *stage_seconds);
+
 /* copy the tiled mesh to the device and allocate the fields (var, grad, psd_flux, send
  * arena).  The plan may be freed afterwards.                                             */
 int  cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *plan);

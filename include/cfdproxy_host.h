@@ -147,6 +147,30 @@ typedef struct cfdp_plan {
 
 void cfdp_plan_default_opts(cfdp_plan_opts *o);
 cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *o);
+
+/* The two heavy, data-parallel stages of the plan can be done elsewhere -- on the device
+ * (cfdp_plan_build_gpu, cfdproxy_hip.h: the reference's init_thread_rangelist / thread_comm preprocessing,
+ * src/rangelist.c:500-764, src/thread_comm.c:27-432, as HIP kernels) -- while tile growth, tile order,
+ * renumbering and the pack lists stay on the host.  A provider must produce what the host stage produces,
+ * bit for bit (tests compare the plans):
+ *   csr    stage 1: xadj[nown+1], adj_face[nadj] (file face id | bit 31 when the owned end is p1),
+ *          adj_other[nadj] (file id of the other end), a point's entries in file face order; malloc'd
+ *   blobs  stage 5: P->tiles, blob, blob_bytes, halo_idx, nhalo_total, lds_grad/_flux(_cls), nfaces_dup,
+ *          ninc_total from the tiling (P->ntiles, nbtiles, nown, old2new are set); malloc'd            */
+typedef struct {
+  const int *xadj, *adj_face, *adj_other;  /* stage 1 */
+  const int *order;                        /* [nown] file ids of the owned points, tile-major            */
+  const int *tile_first;                   /* [ntiles+1] into order                                      */
+  const int *tile_of;                      /* [nown] tile of an owned point (file id)                    */
+} cfdp_tiling;
+typedef struct {
+  int (*csr)(const solver_data *sd, int **xadj, int **adj_face, int **adj_other, long *nfaces_used, void *ctx);
+  int (*blobs)(const solver_data *sd, const cfdp_tiling *tl, struct cfdp_plan *P, void *ctx);
+  void *ctx;
+} cfdp_plan_stages;
+cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *o,
+                                const cfdp_plan_stages *stages);
+int cfdp_plan_host_blobs(const solver_data *sd, const cfdp_tiling *tl, struct cfdp_plan *P); /* the host's stage 5 */
 void cfdp_plan_free(cfdp_plan *p);
 /* layout of a tile blob: [nx[E] | ny[E] | nz[E]] (one 16-byte padded plane per normal component),
  * then the incidence words, then the per-point offsets */

@@ -834,3 +834,81 @@ def test_hub_point_with_hundreds_of_faces(gpu, orc, nleaf):
         assert np.abs(dom.psd_flux - fref).max() <= 1e-11 * np.abs(fref).max(), fusion
         part.close()
         dom.free()
+
+
+# ------------------------------------------------------- the plan's heavy stages on the device
+def _plan_bytes(pkg, plan):
+    p = plan.p
+    out = {}
+    for name, arr, n, t in (("new2old", p.new2old, p.nall, np.int32), ("old2new", p.old2new, p.nall, np.int32),
+                            ("halo_idx", p.halo_idx, p.nhalo_total, np.int32), ("blob", p.blob, p.blob_bytes, np.uint8),
+                            ("vol", p.vol, p.nown, np.float64), ("degree", p.degree, p.nown, np.int32)):
+        out[name] = np.ctypeslib.as_array(arr, shape=(max(n, 1),))[:n].tobytes()
+    out["tiles"] = bytes(memoryview((pkg.TileDesc * p.ntiles).from_address(C.addressof(p.tiles.contents))))
+    out["scalars"] = (p.nown, p.nall, p.nfaces_used, p.ntiles, p.nbtiles, p.tile_points, p.nhalo_total, p.blob_bytes, p.lds_grad,
+                      p.lds_flux, tuple(p.lds_grad_cls), tuple(p.lds_flux_cls), p.nfaces_dup, p.ninc_total, p.npartners)
+    if p.npartners:
+        ns = p.send_off[p.npartners]
+        out["send_idx"] = np.ctypeslib.as_array(p.send_idx, shape=(max(ns, 1),))[:ns].tobytes()
+    return out
+
+
+@pytest.mark.parametrize("which", [1, 2, 3])
+def test_device_built_plan_equals_host_plan(gpu, which):
+    """init_threads()-equivalent preprocessing with its heavy stages as HIP kernels (which: 1 = point->face CSR,
+    2 = per-tile blobs, 3 = both): the plan must equal the host-built plan BIT FOR BIT -- tile descriptors, blobs
+    (normals, incidence words, offsets), halo lists, LDS sizes -- on whole meshes, partitions with halos and
+    boundary tiles, small and large tiles, and a hub point whose list takes the big-list sort"""
+    pkg = gpu
+    cases = []
+    d = pkg.gen_domain(pkg.gen_params(24, 20, 18, ndomains=1), 0)
+    cases += [(d, 16), (d, 64), (d, 128)]
+    gp = pkg.gen_params(20, 18, 16, ndomains=4)
+    doms = [pkg.gen_domain(gp, i) for i in range(4)]
+    pkg.link_raw_group(doms)
+    cases += [(doms[0], 64), (doms[3], 32)]
+    # a hub: point 0 joined to 300 leaves, next to a small lattice-free star (degree 300 > the small-sort bound)
+    nleaf = 300
+    fp = np.stack([np.zeros(nleaf, np.int32), np.arange(1, nleaf + 1, dtype=np.int32)], 1)
+    fp[::3] = fp[::3, ::-1]  # the hub is p1 of every third face
+    rng = np.random.default_rng(5)
+    hub = pkg.domain_from_arrays(fp, rng.normal(size=(nleaf, 3)), rng.uniform(0.5, 2.0, nleaf + 1), nleaf + 1,
+                                 var=rng.normal(size=(nleaf + 1, 7)))
+    cases += [(hub, 64)]
+    for dom, tp in cases:
+        host = pkg.Plan(dom, tile_points=tp)
+        dev = pkg.Plan(dom, tile_points=tp, device_stages=which)
+        a, b = _plan_bytes(pkg, host), _plan_bytes(pkg, dev)
+        assert a.keys() == b.keys()
+        for k in a:
+            assert a[k] == b[k], (which, tp, k)
+        assert dev.stage_seconds[1] != -1.0  # the device stage did the blobs itself
+        host.free()
+        dev.free()
+    for dom in [d, hub] + doms:
+        dom.free()
+
+
+def test_partition_built_from_a_device_plan_computes_the_same(gpu, orc):
+    """end to end: GpuPartition on a device-built plan (CFDP_PLAN_DEVICE=3) against the oracle"""
+    pkg = gpu
+    dom = pkg.gen_domain(pkg.gen_params(20, 18, 16, ndomains=1), 0)
+    pkg.fill_var(dom, None, pkg.VAR_HASH)
+    var = dom.var.copy()
+    os.environ["CFDP_PLAN_DEVICE"] = "3"
+    try:
+        part = pkg.GpuPartition(dom)
+    finally:
+        os.environ.pop("CFDP_PLAN_DEVICE", None)
+    assert part.stats["plan_stage_seconds"] is not None
+    part.gradients()
+    part.flux(pkg.FLUX_CONSISTENT)
+    part.pull_fields()
+    ref = orc.CpuRef(dom.fpoint, dom.fnormal, dom.pvolume, dom.nown, nthreads=2)
+    g_ref = ref.gradients(var)
+    f_ref = ref.flux(g_ref, mode=0)
+    ref.close()
+    assert rel_err(orc, dom.grad, g_ref, dom.fpoint, dom.fnormal, dom.pvolume, var, dom.nown) <= TOL
+    assert np.abs(dom.psd_flux - f_ref)[: dom.nown].max() <= TOL * np.abs(f_ref[: dom.nown]).max()
+    part.close()
+    dom.free()
