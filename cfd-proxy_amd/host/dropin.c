@@ -173,11 +173,13 @@ void init_threads(comm_data *cd, solver_data *sd, int NTHREADS) {
   }
   const char *devenv = getenv("CFDP_DEVICE"); /* default: ranks of a node take its devices in turn */
   const int device = devenv ? atoi(devenv) : device_rank % ndev;
-  /* the plan: tile growth on the host; its two heavy stages on the host too, or -- CFDP_PLAN_DEVICE bit 0 / 1 --
-   * as HIP kernels (the reference's init_thread_rangelist work, src/rangelist.c:500-764, on the device)        */
+  /* the plan: tile growth on the host; its two heavy stages (point->face CSR, per-tile blobs) as HIP kernels
+   * -- the reference's init_thread_rangelist work, src/rangelist.c:500-764, on the device; the plans are
+   * bit-identical -- or, CFDP_PLAN_DEVICE=0 (bit 0 / bit 1 select a stage), on the host                     */
   cfdp_plan *plan = NULL;
   const char *pd = getenv("CFDP_PLAN_DEVICE");
-  if (pd && (atoi(pd) & 3)) GPU_OK(cfdp_plan_build_gpu(sd, cd, &o, device, atoi(pd) & 3, &plan, NULL));
+  const int which = pd ? atoi(pd) & 3 : 3;
+  if (which) GPU_OK(cfdp_plan_build_gpu(sd, cd, &o, device, which, &plan, NULL));
   else plan = cfdp_plan_build(sd, cd, &o);
   cfdp_gpu *gpu = NULL;
   GPU_OK(cfdp_gpu_create(device, &gpu));

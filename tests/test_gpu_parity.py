@@ -890,17 +890,21 @@ def test_device_built_plan_equals_host_plan(gpu, which):
 
 
 def test_partition_built_from_a_device_plan_computes_the_same(gpu, orc):
-    """end to end: GpuPartition on a device-built plan (CFDP_PLAN_DEVICE=3) against the oracle"""
+    """end to end: GpuPartition on a device-built plan (the default) and on a host-built one (CFDP_PLAN_DEVICE=0)
+    against the oracle"""
     pkg = gpu
     dom = pkg.gen_domain(pkg.gen_params(20, 18, 16, ndomains=1), 0)
     pkg.fill_var(dom, None, pkg.VAR_HASH)
     var = dom.var.copy()
-    os.environ["CFDP_PLAN_DEVICE"] = "3"
+    os.environ["CFDP_PLAN_DEVICE"] = "0"
     try:
         part = pkg.GpuPartition(dom)
     finally:
         os.environ.pop("CFDP_PLAN_DEVICE", None)
-    assert part.stats["plan_stage_seconds"] is not None
+    assert part.stats["plan_stage_seconds"] is None
+    part.close()
+    part = pkg.GpuPartition(dom)
+    assert part.stats["plan_stage_seconds"] is not None and part.stats["plan_stage_seconds"][1] >= 0
     part.gradients()
     part.flux(pkg.FLUX_CONSISTENT)
     part.pull_fields()
