@@ -34,6 +34,10 @@ struct gg_push_args {
   int *const *rflag;
   int *done;
   int nbtiles, nslots;
+  // > 0: the boundary tiles (the only ones that read ghost rows) first wait -- bounded -- until every partner's
+  // rows of the PREVIOUS exchange have arrived: the job of gg_wait_kernel done at the top of the next pass, so
+  // that an iteration is ONE launch (no wait kernel, no kernel boundary behind it)
+  long wait_polls;
 };
 
 struct gg_args {

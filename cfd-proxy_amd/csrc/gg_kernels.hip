@@ -286,6 +286,29 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   }
 }
 
+// The wait for the previous exchange, at the top of a boundary tile of the next pass (see gg_push_args::
+// wait_polls; the protocol is gg_wait_kernel's).  hdr[GG_IPC_ITER] = exchanges this rank has announced so far:
+// it only changes when the LAST boundary tile of a launch has finished, i.e. after every tile's wait here.
+__device__ __forceinline__ void wait_previous_exchange(const gg_push_args &pa, int tile, int tid) {
+  if (!pa.tile_off || pa.wait_polls <= 0 || tile >= pa.nbtiles) return;  // uniform per workgroup
+  if (tid < pa.nslots && !pa.hdr[GG_IPC_ERR]) {
+    const int need = pa.hdr[GG_IPC_ITER];
+    bool ok = false;
+    for (long k = 0; k < pa.wait_polls && !ok; k++) {
+      ok = __hip_atomic_load(&pa.hdr[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
+      if (!ok) __builtin_amdgcn_s_sleep(32);
+    }
+    if (!ok) {  // bounded: a lost partner must not hang the device.  Leave what was seen for the post-mortem.
+      pa.hdr[GG_IPC_ERR] = 1;
+      pa.hdr[GG_IPC_ERR + 1] = tid;
+      pa.hdr[GG_IPC_ERR + 2] = need;
+      pa.hdr[GG_IPC_ERR + 3] = __hip_atomic_load(&pa.hdr[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      atomicAdd(&pa.hdr[GG_IPC_ERR + 4], 1);
+    }
+  }
+  __syncthreads();
+}
+
 // After the pushes of a boundary tile: count it; the last one of the launch raises this rank's
 // iteration counter in every partner's flag word (gg_notify_kernel's job, done in place).  Every
 // thread has made its remote stores visible (system-scope fence) before the tile is counted.
@@ -753,6 +776,7 @@ void gg_fused_dma_kernel(
   const cfdp_tile_desc td = tiles[t];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
+  wait_previous_exchange(pa, t, tid);  // before any ghost row is requested
   const int *hid = halo_idx + td.halo_off;
   const int hmax = td.nhalo > 0 ? td.nhalo - 1 : 0;
   // (1) halo row numbers of this thread's var pieces (4 per row) and gradient pieces (5 per row)
@@ -859,6 +883,7 @@ void gg_fused_split_kernel(
                                             (dbg & GG_DBG_REVERSE) != 0);
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
+  wait_previous_exchange(pa, t, tid);  // before any ghost row is requested
   int hv[KV], hg[KG], part[KG], rloc[KG];
   // with a fixed-stride row list the row numbers are requested before the descriptor is even here:
   // descriptor -> blob and row list -> rows are two chains of two round trips instead of one of three

@@ -93,6 +93,11 @@ struct cfdp_gpu {
     int *d_slot_of_row = nullptr, *d_send_off = nullptr;
     int *d_tile_off = nullptr, *d_ent = nullptr, *d_ent_row = nullptr;  // send rows per boundary tile
     bool inkernel = false;   // the fused pass pushes and notifies by itself
+    // the latest exchange has been started but nothing on the main stream waits for its arrival yet: the
+    // boundary tiles of the next pushing pass wait themselves (gg_push_args::wait_polls); anything else that
+    // touches ghost rows first enqueues the wait kernel (ipc_settle)
+    bool wait_pending = false;
+    bool wait_inkernel = true;
     hipGraphExec_t graph = nullptr, graph_rem = nullptr;  // main chunk; what is left after whole chunks
     int graph_n = 0, graph_rem_n = 0;
     int g_exch = -1, g_overlap = -1, g_flux = -1, g_mode = -1, g_xpar = -1;
@@ -387,9 +392,21 @@ int cfdp_gpu_bind_sendbuf(cfdp_gpu *g, void *dev_sendbuf) {
 }
 
 static int launch_flux(cfdp_gpu *g, int mode, hipStream_t st);
+static long ipc_max_polls_c();
+
+// xGMI write + notify: make the main stream wait (bounded, on the device) for the latest exchange's arrival,
+// if nothing has done so yet -- before anything but a pushing fused pass touches ghost rows
+static int ipc_settle(cfdp_gpu *g) {
+  if (!g->ipc.on || !g->ipc.wait_pending) return 0;
+  g->ipc.wait_pending = false;
+  g->main_marked = false;
+  HIP_TRY(gg_launch_wait(g->ipc_hdr(), (int)g->partner.size(), ipc_max_polls_c(), g->s_main));
+  return 0;
+}
 
 // run the deferred flux of the last fused-mode iteration, if any
 static int flush_flux(cfdp_gpu *g, bool record = true, hipStream_t st = nullptr) {
+  if (ipc_settle(g)) return 1;
   if (g->flux_pending < 0) return 0;
   const int mode = g->flux_pending;
   g->flux_pending = -1;
@@ -1229,8 +1246,13 @@ long ipc_max_polls() {
   return (long)(g_ipc_wait_seconds * 1e6);
 }
 
+}  // namespace
+static long ipc_max_polls_c() { return ipc_max_polls(); }
+namespace {
+
 void ipc_release(cfdp_gpu *g) {
   auto &I = g->ipc;
+  I.wait_pending = false;
   if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
   if (I.graph_rem) { (void)hipGraphExecDestroy(I.graph_rem); I.graph_rem = nullptr; }
   I.graph_n = I.graph_rem_n = 0;
@@ -1253,6 +1275,9 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   const bool fused = g->will_fuse();
   if (!fused && flush_flux(g)) return 1;
   auto grad_tiles = [&](int which, hipStream_t st) { return fused ? launch_fused(g, which, st) : launch_grad(g, which, st); };
+  // a pending wait for the previous exchange is absorbed by the boundary tiles of a pushing fused pass;
+  // every other schedule reads ghost rows without that check and needs the wait kernel first
+  if (!(comm && fused && g->ipc.inkernel && g->ipc.wait_inkernel) && ipc_settle(g)) return 1;
   if (!comm) {
     if (grad_tiles(CFDP_TILES_ALL, g->s_main)) return 1;
     if (fused) fused_done(g);
@@ -1270,9 +1295,12 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
       pa.tile_off = I.d_tile_off; pa.ent = I.d_ent; pa.ent_row = I.d_ent_row; pa.dst = I.d_dst[par];
       pa.hdr = g->ipc_hdr(); pa.rflag = I.d_rflag; pa.done = g->ipc_hdr() + GG_IPC_DONE;
       pa.nbtiles = g->nbtiles; pa.nslots = nslots;
+      pa.wait_polls = I.wait_pending && I.wait_inkernel ? (long)ipc_max_polls() : 0;
       const int rc = launch_fused(g, CFDP_TILES_ALL, g->s_main, &pa);
       if (rc == 1) return 1;
       pushed = rc == 0;
+      if (pushed) I.wait_pending = false;  // absorbed (or there was none)
+      else if (ipc_settle(g)) return 1;    // no fused kernel fits these tiles: the separate kernels below
     }
     if (pushed) {
     } else if (overlap) {
@@ -1293,7 +1321,10 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
     if (fused) fused_done(g);
     I.xiter++;  // from here on the ghost block is the arena this exchange lands in
     g->main_marked = false;
-    HIP_TRY(gg_launch_wait(g->ipc_hdr(), nslots, (long)ipc_max_polls(), g->s_main));  // bounded
+    // the wait for this exchange: left to the boundary tiles of the next pushing pass (one launch per
+    // iteration), or -- ipc_settle -- to a wait kernel in front of whatever else reads the ghost rows first
+    I.wait_pending = true;
+    if (!(pushed && I.wait_inkernel) && ipc_settle(g)) return 1;
   }
   return 0;
 }
@@ -1429,6 +1460,8 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       // and its stored row must travel (as pack / the push kernel send it, and the reference's
       // exchange_dbl_copy_in, src/threads.c:791-813): such partitions keep the separate push kernel
       I.inkernel = g->nbtiles > 0 && !g->faceless_send && !(e && atoi(e) == 0);
+      const char *w = getenv("CFDP_IPC_WAIT_INKERNEL");  // 0: always a separate wait kernel (A/B timing)
+      I.wait_inkernel = !(w && atoi(w) == 0);
     }
   }
   if (flush_flux(g)) return 1;
@@ -1542,6 +1575,7 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       const int pend0 = g->flux_pending;
       const long iter0 = g->iter, x0 = I.xiter;
       const unsigned passes0 = g->fused_passes;
+      const bool wait0 = I.wait_pending;  // a chunk starts and ends with the wait of its last exchange pending
       hipGraph_t gr = nullptr;
       if (hipStreamBeginCapture(g->s_main, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
       g->main_marked = false;  // the first captured step must fork off a record made INSIDE the capture
@@ -1551,12 +1585,13 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       (void)hipEventRecord(g->ev_fork, g->s_main);      // events last recorded inside a capture may not
       (void)hipEventRecord(g->ev_senddone, g->s_comm);  // be waited for outside it: re-arm them
       (void)mark_main(g);
-      const bool ok = !rc && ec == hipSuccess && gr && g->d_grad == cur0 && g->flux_pending == pend0;
+      const bool ok = !rc && ec == hipSuccess && gr && g->d_grad == cur0 && g->flux_pending == pend0 && I.wait_pending == wait0;
       if (ok && hipGraphInstantiate(&slot, gr, nullptr, nullptr, 0) != hipSuccess) slot = nullptr;
       if (gr) (void)hipGraphDestroy(gr);
       g->iter = iter0;
       I.xiter = x0;  // nothing of the capture has run
       g->fused_passes = passes0;
+      I.wait_pending = wait0;
       if (!ok || !slot) {
         if (g->d_grad != cur0) { std::swap(g->d_grad, g->d_grad_alt); std::swap(g->own_grad, g->own_grad_alt); }
         g->flux_pending = pend0;
