@@ -8,7 +8,7 @@ PORT=$((20000 + RANDOM % 20000))
 pids=()
 for r in $(seq 0 $((N-1))); do
   RANK=$r LOCAL_RANK=0 WORLD_SIZE=$N MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT CFDP_SHARED_GPU=1 \
-    timeout -k 10 500 python3 $R/bench.py --gpus $N --steps $STEPS --warmup 20 \
+    timeout -k 10 500 python3 $R/bench.py --gpus $N --steps $STEPS --warmup ${3:-20} \
     > $R/gpurun_out/rehearse_n${N}_rank$r.json 2> $R/gpurun_out/rehearse_n${N}_rank$r.err &
   pids+=($!)
 done
