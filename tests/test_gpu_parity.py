@@ -916,3 +916,81 @@ def test_partition_built_from_a_device_plan_computes_the_same(gpu, orc):
     assert np.abs(dom.psd_flux - f_ref)[: dom.nown].max() <= TOL * np.abs(f_ref[: dom.nown]).max()
     part.close()
     dom.free()
+
+
+# -------------------------------------------------- genuinely unstructured meshes (Delaunay edges), SURVEY 8c edge cases
+def test_unstructured_delaunay_mesh_single_domain(gpu, orc):
+    """a mesh without lattice regularity -- Delaunay edges of random points: ~15 faces per point, degrees up to 35+,
+    random face order and orientation -- through the tiler, the device plan stages, the separate kernels in every
+    lanes-per-point form and the fused pass, against the C oracle (and the numpy statement)"""
+    from unstructured import delaunay_mesh
+    pkg = gpu
+    xyz, fp, fn_, vol, var = delaunay_mesh(20000)
+    dom = pkg.domain_from_arrays(fp, fn_, vol, len(vol), var=var)
+    ref = orc.CpuRef(fp, fn_, vol, len(vol), nthreads=4)
+    g_ref = ref.gradients(var)
+    f_ref = ref.flux(g_ref, mode=0)
+    ref.close()
+    g_np = orc.np_gradients(fp, fn_, vol, var, len(vol))
+    assert rel_err(orc, g_np, g_ref, fp, fn_, vol, var, len(vol)) <= 1e-12
+    deg = np.bincount(fp.ravel())
+    assert deg.max() >= 30 and abs(deg.mean() - 15.5) < 1.5  # what "unstructured" means here
+    for tp, lanes in ((64, 4), (64, 8), (32, 2), (128, 1)):
+        g, f = run_partition(pkg, dom, tp, lanes)
+        assert rel_err(orc, g, g_ref, fp, fn_, vol, var, len(vol)) <= TOL, (tp, lanes)
+        assert np.abs(f - f_ref).max() <= TOL * np.abs(f_ref).max(), (tp, lanes)
+    host, dev = pkg.Plan(dom), pkg.Plan(dom, device_stages=3)
+    assert _plan_bytes(pkg, host) == _plan_bytes(pkg, dev)
+    host.free()
+    dev.free()
+    part = pkg.GpuPartition(dom)
+    part.run_iterations(2, True, 0, use_graph=False)
+    part.pull_fields()
+    g_sep, f_sep = dom.grad.copy(), dom.psd_flux.copy()
+    part.set_fusion(True)
+    for iters in (3, 20, 53):
+        dom.grad[:] = 0.0
+        dom.psd_flux[:] = 0.0
+        part.push_fields()
+        part.run_iterations(iters, True, 0, use_graph=True)
+        part.pull_fields()
+        assert np.array_equal(dom.grad, g_sep) and np.array_equal(dom.psd_flux, f_sep), iters
+    assert rel_err(orc, dom.grad, g_ref, fp, fn_, vol, var, len(vol)) <= TOL
+    part.close()
+    dom.free()
+
+
+@pytest.mark.parametrize("nd", [2, 4])
+def test_unstructured_delaunay_mesh_partitioned_with_halo_exchange(gpu, orc, nd):
+    """the same kind of mesh cut into domains with ghost points (dualgrid schema), one in-process rank per domain,
+    fused iterations with the overlapped exchange: own rows, delivered ghost rows and flux of every rank against
+    the oracle on the un-partitioned mesh"""
+    from unstructured import delaunay_mesh, partition
+    pkg = gpu
+    xyz, fp, fn_, vol, var = delaunay_mesh(12000, seed=11)
+    ref = orc.CpuRef(fp, fn_, vol, len(vol), nthreads=4)
+    truth = ref.gradients(var)
+    ftruth = ref.flux(truth, mode=0)
+    ref.close()
+    wscale = whole_mesh_scale(orc, truth, fp, fn_, vol, var)
+    parts = partition(xyz, fp, fn_, vol, var, nd)
+    doms = [pkg.domain_from_arrays(p["fpoint"], p["fnormal"], p["pvolume"], p["nown"], var=p["var"], ndomains=nd, iproc=d,
+                                   addpoint_owner=p["addpoint_owner"], addpoint_idx=p["addpoint_idx"],
+                                   commpartner=p["commpartner"], sendcount=p["sendcount"], recvcount=p["recvcount"])
+            for d, p in enumerate(parts)]
+    pkg.link_raw_group(doms)
+    for fusion in (False, True):
+        gparts = [pkg.GpuPartition(dom) for dom in doms]
+        for gp_ in gparts:
+            gp_.set_fusion(fusion)
+        for _ in range(3):
+            pkg.group_iteration(gparts, with_exchange=True, overlap=True, with_flux=True)
+        pkg.group_sync(gparts)
+        for d, (dom, gp_, p) in enumerate(zip(doms, gparts, parts)):
+            gp_.pull_fields()
+            gid = p["gid"]
+            assert rel_err_rows(dom.grad, truth[gid], wscale[gid]) <= TOL, (fusion, d)      # ghost rows included
+            assert np.abs(dom.psd_flux[: dom.nown] - ftruth[gid[: dom.nown]]).max() <= TOL * np.abs(ftruth).max(), (fusion, d)
+            gp_.close()
+    for dom in doms:
+        dom.free()
