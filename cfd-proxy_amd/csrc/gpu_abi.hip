@@ -114,6 +114,8 @@ struct cfdp_gpu {
   bool faceless_send = false;          // some send point has no faces: its stored row travels, no tile computes one
   std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
   int max_halo[2] = {0, 0}, max_blob[2] = {0, 0};  // per tile class: halo rows, blob 16-byte units
+  int max_rows[2] = {0, 0};    // per tile class: rows a tile stages (own + halo) -- NOT tp + max_halo: the tile with
+                               // the most halo rows usually is not one with the most points
   bool streaming = false;      // per-iteration bytes exceed the Infinity Cache: non-temporal blobs/rows
   // fused passes over ALL tiles alternate the direction in which every XCD walks its run of tiles, so
   // that a pass starts on what the previous one left in the Infinity Cache (only worth it when a pass
@@ -280,8 +282,10 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   g->tp[0] = g->tp[1] = 0;
   g->max_halo[0] = g->max_halo[1] = 0;
   g->max_blob[0] = g->max_blob[1] = 0;
+  g->max_rows[0] = g->max_rows[1] = 0;
   for (int t = 0; t < p->ntiles; t++) {
     int c = t < p->nbtiles ? 0 : 1;
+    if (p->tiles[t].npts + p->tiles[t].nhalo > g->max_rows[c]) g->max_rows[c] = p->tiles[t].npts + p->tiles[t].nhalo;
     if (p->tiles[t].npts > g->tp[c]) g->tp[c] = p->tiles[t].npts;
     if (p->tiles[t].nhalo > g->max_halo[c]) g->max_halo[c] = p->tiles[t].nhalo;
     if (p->tiles[t].blob_qw > g->max_blob[c]) g->max_blob[c] = p->tiles[t].blob_qw;
@@ -578,11 +582,16 @@ static int fork_comm(cfdp_gpu *g) {
   return 0;
 }
 
-struct tile_range { int begin, n, tp, max_halo, max_blob; size_t lds_grad, lds_flux; };
+struct tile_range {
+  int begin, n, tp, max_halo, max_blob, max_rows;
+  size_t lds_grad, lds_flux;
+  // what the fixed-capacity kernels size their row regions with: they take (points, halo rows) and add them
+  int row_halo() const { return max_rows > tp ? max_rows - tp : 0; }
+};
 static tile_range range_of(const cfdp_gpu *g, int which) {
   auto cls = [&](int c) {
     return tile_range{c ? g->nbtiles : 0, c ? g->ntiles - g->nbtiles : g->nbtiles, g->tp[c], g->max_halo[c],
-                      g->max_blob[c], g->lds_grad[c], g->lds_flux[c]};
+                      g->max_blob[c], g->max_rows[c], g->lds_grad[c], g->lds_flux[c]};
   };
   if (which == CFDP_TILES_BOUNDARY) return cls(0);
   if (which == CFDP_TILES_INTERIOR) return cls(1);
@@ -590,8 +599,8 @@ static tile_range range_of(const cfdp_gpu *g, int which) {
   if (b.n == 0) return i;
   if (i.n == 0) return b;
   return tile_range{0, g->ntiles, b.tp > i.tp ? b.tp : i.tp, b.max_halo > i.max_halo ? b.max_halo : i.max_halo,
-                    b.max_blob > i.max_blob ? b.max_blob : i.max_blob, b.lds_grad > i.lds_grad ? b.lds_grad : i.lds_grad,
-                    b.lds_flux > i.lds_flux ? b.lds_flux : i.lds_flux};
+                    b.max_blob > i.max_blob ? b.max_blob : i.max_blob, b.max_rows > i.max_rows ? b.max_rows : i.max_rows,
+                    b.lds_grad > i.lds_grad ? b.lds_grad : i.lds_grad, b.lds_flux > i.lds_flux ? b.lds_flux : i.lds_flux};
 }
 
 static int launch_grad(cfdp_gpu *g, int which, hipStream_t st, const gg_grad_view *into = nullptr) {
@@ -599,7 +608,8 @@ static int launch_grad(cfdp_gpu *g, int which, hipStream_t st, const gg_grad_vie
   gg_args a = g->args();
   if (into) a.grad = *into;
   const tile_range r = range_of(g, which);
-  HIP_TRY(gg_launch_gradient(a, g->grad_lanes, r.begin, r.n, r.tp, r.lds_grad, r.max_halo, r.max_blob, pipe_for(g, r.n),
+  const int pipe = pipe_for(g, r.n);  // (the persistent form holds halo pieces per thread: it needs the true halo bound)
+  HIP_TRY(gg_launch_gradient(a, g->grad_lanes, r.begin, r.n, r.tp, r.lds_grad, pipe ? r.max_halo : r.row_halo(), r.max_blob, pipe,
                              g->streaming, st));
   return 0;
 }
@@ -608,7 +618,7 @@ static int launch_flux_tiles(cfdp_gpu *g, int mode, int which, hipStream_t st) {
   g->main_marked = false;
   const gg_args a = g->args();
   const tile_range r = range_of(g, which);
-  HIP_TRY(gg_launch_flux(a, g->flux_lanes, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.lds_flux, r.max_halo,
+  HIP_TRY(gg_launch_flux(a, g->flux_lanes, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.lds_flux, r.row_halo(),
                          r.max_blob, g->streaming, st));
   return 0;
 }
@@ -626,9 +636,9 @@ static int launch_fused(cfdp_gpu *g, int which, hipStream_t st, const gg_push_ar
   const gg_grad_view gnew = g->alt_view();
   const int mode = g->flux_pending;
   const tile_range r = range_of(g, which);
-  if (push && !gg_fused_fits(r.tp, r.max_halo, r.max_blob)) return 2;
+  if (push && !gg_fused_fits(r.tp, r.row_halo(), r.max_blob)) return 2;
   const bool reverse = g->alternate && which == CFDP_TILES_ALL && !push && (g->fused_passes++ & 1u);
-  const hipError_t e = gg_launch_fused(a, gnew, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.max_halo, r.max_blob,
+  const hipError_t e = gg_launch_fused(a, gnew, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.row_halo(), r.max_blob,
                                        g->streaming, !g->beside_rccl, st, push, reverse);
   if (e == hipErrorNotSupported && push) return 2;
   if (e == hipErrorNotSupported) {

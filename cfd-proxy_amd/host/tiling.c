@@ -54,6 +54,11 @@ typedef struct {
    * marks q as a member or a halo point of the tile being grown; NULL = unbounded */
   int *hseen;
   int halo_cap;
+  /* hard budgets of a tile, checked BEFORE a point joins (0 = none): bytes of its blob and rows it stages (own +
+   * halo), so that every tile of the launch fits the fastest kernel's LDS image -- one oversized tile would
+   * otherwise put the whole launch into the next capacity class (fewer workgroups per CU) */
+  long blob_cap;
+  int rows_cap;
 } tiler;
 
 static void tiler_open_tile(tiler *T) {
@@ -74,7 +79,8 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
   while (remaining > 0) {
     const int t = T->ntiles;
     tiler_open_tile(T);
-    int cnt = 0, head = 0, tail = 0, seen = 0;
+    int cnt = 0, head = 0, tail = 0, seen = 0, rejected = -1;
+    long ninc = 0, ninternal = 0; /* incidences of the tile so far; faces with both ends in it */
     while (cnt < TP) {
       /* a tile made of leftovers scattered between finished tiles reads ~14 rows per point; close
        * it early rather than let one such tile size the LDS image of the whole launch */
@@ -96,11 +102,30 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
         T->stamp[seed] = t + 1;
         T->lq[tail++] = seed;
       }
-      int p = T->lq[head++];
+      int p = T->lq[head];
+      int internal_add = 0;
+      for (int e = T->xadj[p]; e < T->xadj[p + 1]; e++) {
+        int q = T->adj_other[e];
+        if (q < nown && q != p && T->tile_of[q] == t) internal_add++;
+      }
+      if (T->hseen && T->blob_cap > 0 && cnt >= 1) { /* would the tile still fit with p in it? (exact for the blob) */
+        int newrows = T->hseen[p] != t + 1 ? 1 : 0;
+        for (int e = T->xadj[p]; e < T->xadj[p + 1]; e++)
+          if (T->hseen[T->adj_other[e]] != t + 1) newrows++; /* (an upper bound: parallel faces count twice) */
+        const long I2 = ninc + (T->xadj[p + 1] - T->xadj[p]), E2 = I2 - (ninternal + internal_add);
+        const long blob = cfdp_blob_fn_bytes((int)E2) + cfdp_blob_inc_bytes((int)I2) + cfdp_blob_off_bytes(cnt + 1);
+        if (blob > T->blob_cap || seen + newrows > T->rows_cap) {
+          rejected = p; /* stays un-tiled: it seeds a later tile */
+          break;
+        }
+      }
+      head++;
       T->tile_of[p] = t;
       T->order[T->norder++] = p;
       cnt++;
       remaining--;
+      ninc += T->xadj[p + 1] - T->xadj[p];
+      ninternal += internal_add;
       if (T->hseen && T->hseen[p] != t + 1) { T->hseen[p] = t + 1; seen++; }
       for (int e = T->xadj[p]; e < T->xadj[p + 1]; e++) {
         int q = T->adj_other[e];
@@ -115,6 +140,7 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
     for (int i = head; i < tail; i++) {
       int q = T->lq[i];
       if (!T->seeded[q]) { T->seeded[q] = 1; T->seedq[T->sq_tail++] = q; }
+      else if (q == rejected) T->seedq[T->sq_tail++] = q; /* it was popped as a seed already: queue it again */
     }
     T->ntiles++;
     CFDP_ASSERT(cnt > 0);
@@ -391,7 +417,7 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
   for (int p = 0; p < nown; p++) T.tile_of[p] = -1;
   T.stamp = cfdp_calloc((size_t)nown, sizeof(int));
   T.seeded = cfdp_calloc((size_t)nown, 1);
-  T.seedq = cfdp_malloc((size_t)nown * sizeof(int));
+  T.seedq = cfdp_malloc(((size_t)2 * nown + 2) * sizeof(int)); /* first-time seeds + re-queued rejected points */
   T.lq = cfdp_malloc((size_t)nown * sizeof(int));
   T.order = cfdp_malloc((size_t)nown * sizeof(int));
   /* bound the halo so that own + halo rows fit the smallest staging capacity of the kernels:
@@ -400,6 +426,20 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
   /* (a point adds at most 14 halo rows on these meshes and the check precedes the addition: the cap
    * leaves room for that, 126 + 14 = 140 <= 2.2 * 64; small tiles: only the scattered ones) */
   T.halo_cap = o.tile_points * 2 - 2 < 96 ? 96 : o.tile_points * 2 - 2;
+  {
+    /* what the fastest form of the fused pass stages per tile (gg_fused_split_kernel<.., 5, 4, 4, 4>, 4 lanes per
+     * point): 5 sixteen-byte blob pieces per thread, and rows in 4 pieces per thread at 5 pieces per 80-byte row */
+    const int block = ((o.tile_points * 4 + 63) / 64) * 64;
+    T.blob_cap = (long)5 * block * 16;
+    T.rows_cap = 4 * block / 5;
+    const char *e = getenv("CFDP_TILE_BUDGET"); /* 0: tiles close by point count and the soft halo bound only */
+    if (e && atoi(e) == 0) T.blob_cap = 0;
+    /* with the hard row budget in force the soft halo bound may go up to it: tiles of meshes with many
+     * neighbours per point (15+) then fill up instead of closing at 2/3 of their points */
+    if (T.blob_cap > 0 && T.rows_cap - o.tile_points > T.halo_cap) T.halo_cap = T.rows_cap - o.tile_points;
+    const char *hc = getenv("CFDP_HALO_CAP"); /* experiments */
+    if (hc && atoi(hc) > 0) T.halo_cap = atoi(hc);
+  }
   if (any_send && o.boundary_first) {
     int btp = o.tile_points / 2 < 8 ? 8 : o.tile_points / 2; /* sheets have big halos */
     tiler_pass(&T, is_send, 1, btp);
