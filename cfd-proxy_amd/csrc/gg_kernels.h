@@ -85,6 +85,7 @@ hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row
 hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, hipStream_t stream);
 hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, hipStream_t stream);
 extern int gg_debug_flags;
+hipError_t gg_set_stamp_buffer(unsigned long long *dev);  // diagnostics: phase stamps of the split fused pass
 extern int gg_fused_split;
 hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux);
 

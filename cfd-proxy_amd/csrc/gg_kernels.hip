@@ -98,6 +98,9 @@ template <bool NT> __device__ __forceinline__ void st_row(double v, double *p) {
 
 // bit of the kernels' `dbg` argument that is not a timing experiment: walk the tiles backwards
 #define GG_DBG_REVERSE 0x10000
+// diagnostic build only (dbg bit GG_DBG_STAMP; never set in a timed run): thread 0 of every workgroup of the
+// split fused pass writes shader-clock stamps of its phase boundaries, 8 per tile, to a buffer of its own
+#define GG_DBG_STAMP 0x20000
 #ifndef GG_DEEP_BATCH
 #define GG_DEEP_BATCH 7
 #endif
@@ -862,6 +865,11 @@ __global__ __launch_bounds__(256) void gg_unpack_kernel(const double *__restrict
     ghost[i] = recvbuf[i];  // ghost rows are in message order (host/tiling.c)
 }
 
+__device__ unsigned long long *gg_stamp_buf = nullptr;
+__device__ __forceinline__ void gg_stamp(int dbg, int tile, int slot) {
+  if ((dbg & GG_DBG_STAMP) && threadIdx.x == 0 && gg_stamp_buf) gg_stamp_buf[(size_t)tile * 8 + slot] = __builtin_amdgcn_s_memtime();
+}
+
 // Phase-split form of the fused pass: ONE row region of LDS holds the gradient rows during the flux
 // phase and the var rows during the gradient phase (the var rows are gathered after the flux phase,
 // their row numbers were fetched at the start), so a tile occupies CB + KX pieces per thread instead
@@ -883,6 +891,7 @@ void gg_fused_split_kernel(
                                             (dbg & GG_DBG_REVERSE) != 0);
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
+  gg_stamp(dbg, t, 0);
   wait_previous_exchange(pa, t, tid);  // before any ghost row is requested
   int hv[KV], hg[KG], part[KG], rloc[KG];
   // with a fixed-stride row list the row numbers are requested before the descriptor is even here:
@@ -933,6 +942,7 @@ void gg_fused_split_kernel(
     else glds16(b4 + q, smem + (size_t)q0 * 16);
   }
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CB) : "memory");
+  gg_stamp(dbg, t, 1);  // descriptor + row numbers are here
 #pragma unroll
   for (int k = 0; k < KV; k++) asm volatile("" : "+v"(hv[k]));
 #pragma unroll
@@ -963,9 +973,11 @@ void gg_fused_split_kernel(
     }
   }
   __syncthreads();
+  gg_stamp(dbg, t, 2);  // blob + gradient rows (+ var rows in registers) have landed
   if (!(dbg & 128))  // timing experiment: no flux phase
     flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   __syncthreads();  // every wave is done with the gradient rows: the region takes the var rows
+  gg_stamp(dbg, t, 3);  // flux phase done
   if constexpr (EARLY) {
 #pragma unroll
     for (int k = 0; k < KV; k++) *reinterpret_cast<u32x4 *>(xbuf + (size_t)(tid + k * nthr) * 16) = vr[k];
@@ -978,8 +990,14 @@ void gg_fused_split_kernel(
     }
   }
   __syncthreads();  // vmcnt(0) + barrier
+  gg_stamp(dbg, t, 4);  // var rows in place
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
                                    CB * nthr * 16, &pa, t);
+  gg_stamp(dbg, t, 5);  // gradient arithmetic done, row stores issued (wave 0)
+  if (dbg & GG_DBG_STAMP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gg_stamp(dbg, t, 6);  // wave 0's stores acknowledged
+  }
   push_tile_done(pa, t, tid);
 }
 
@@ -1054,6 +1072,9 @@ hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, hipStream_t stre
 }
 
 // ------------------------------------------------------------------------------ launchers
+hipError_t gg_set_stamp_buffer(unsigned long long *dev) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(gg_stamp_buf), &dev, sizeof dev);
+}
 int gg_fused_split = 1;  // fused pass: prefer the phase-split form (one shared row region, 4 workgroups per CU)
 int gg_debug_flags = 0;  // timing experiments only: 1 = skip arithmetic, 2 = skip tile streaming
 

@@ -1100,6 +1100,37 @@ int cfdp_gpu_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_
   return run_or_prepare_iterations(g, iters, with_flux, flux_mode, 1, false, nullptr);
 }
 
+// diagnostics (tools/phase_stamps.py): run `passes` fused passes with phase stamping on and return, per tile, 8
+// shader-clock stamps of the LAST pass (start, indices here, loads landed, flux done, var rows in place, gradient
+// arithmetic done + stores issued, stores acknowledged, unused); stamps[ntiles*8]
+int cfdp_gpu_debug_phase_stamps(cfdp_gpu *g, int passes, unsigned long long *stamps) {
+  NEED_UPLOAD(g);
+  if (!g->fusion || !g->d_grad_alt || passes < 1 || !stamps) return fail("fusion must be on");
+  if (flush_flux(g)) return 1;
+  unsigned long long *d = nullptr;
+  const size_t n = (size_t)g->ntiles * 8;
+  HIP_TRY(hipMalloc(&d, n * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(d, 0, n * sizeof(unsigned long long)));
+  HIP_TRY(gg_set_stamp_buffer(d));
+  if (launch_grad(g, CFDP_TILES_ALL, g->s_main)) return 1;
+  const int saved = gg_debug_flags;
+  gg_debug_flags |= 0x20000;
+  int rc = 0;
+  for (int i = 0; i < passes && !rc; i++) {
+    g->flux_pending = CFDP_FLUX_CONSISTENT;
+    rc = launch_fused(g, CFDP_TILES_ALL, g->s_main);
+    if (!rc) fused_done(g);
+  }
+  gg_debug_flags = saved;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(gg_set_stamp_buffer(nullptr));
+  if (!rc) HIP_TRY(hipMemcpy(stamps, d, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  if (rc) return 1;
+  g->flux_pending = CFDP_FLUX_CONSISTENT;
+  return flush_flux(g);
+}
+
 // ------------------------------------------------------- one process per GPU: RCCL from C
 // The halo exchange of a step issued straight from this library: one ncclGroup of
 // ncclSend/ncclRecv per iteration on the context's comm stream, between the two step brackets

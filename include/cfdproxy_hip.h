@@ -202,6 +202,9 @@ int  cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overl
 int  cfdp_gpu_time_kernels(cfdp_gpu *g, int iters, int flux_mode, float *ms_grad, float *ms_flux);
 /* average milliseconds of the fused pass (flux(i) + gradients(i+1), all tiles); fusion on  */
 int  cfdp_gpu_time_fused(cfdp_gpu *g, int iters, int flux_mode, float *ms_fused);
+/* diagnostics: per tile 8 shader-clock stamps of the phase boundaries of the last of `passes` fused passes
+ * (start, indices here, loads landed, flux done, var rows in place, gradients done, stores acknowledged, -)  */
+int  cfdp_gpu_debug_phase_stamps(cfdp_gpu *g, int passes, unsigned long long *stamps);
 /* the schedule of an exchange step without the exchange itself (the two brackets only), from one
  * hipGraph or from the streams: average milliseconds per step                             */
 int  cfdp_gpu_time_schedule(cfdp_gpu *g, int steps, int with_exchange, int overlap, int use_graph, float *ms_step);
