@@ -869,6 +869,11 @@ __device__ unsigned long long *gg_stamp_buf = nullptr;
 __device__ __forceinline__ void gg_stamp(int dbg, int tile, int slot) {
   if ((dbg & GG_DBG_STAMP) && threadIdx.x == 0 && gg_stamp_buf) gg_stamp_buf[(size_t)tile * 8 + slot] = __builtin_amdgcn_s_memtime();
 }
+// the same per WAVE (lane 0 of each of the 4 waves), behind the per-tile stamps: [ntiles*8 + (tile*4 + wave)*4 + slot]
+__device__ __forceinline__ void gg_stamp_wave(int dbg, int ntiles, int tile, int slot) {
+  if ((dbg & GG_DBG_STAMP) && (threadIdx.x & 63) == 0 && gg_stamp_buf)
+    gg_stamp_buf[(size_t)ntiles * 8 + ((size_t)tile * 4 + (threadIdx.x >> 6)) * 4 + slot] = __builtin_amdgcn_s_memtime();
+}
 
 // Phase-split form of the fused pass: ONE row region of LDS holds the gradient rows during the flux
 // phase and the var rows during the gradient phase (the var rows are gathered after the flux phase,
@@ -892,6 +897,9 @@ void gg_fused_split_kernel(
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
   gg_stamp(dbg, t, 0);
+  if ((dbg & GG_DBG_STAMP) && tid == 0 && gg_stamp_buf)  // which CU: HW_ID (cu, sh, se) and XCC_ID
+    gg_stamp_buf[(size_t)t * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                     (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
   wait_previous_exchange(pa, t, tid);  // before any ghost row is requested
   int hv[KV], hg[KG], part[KG], rloc[KG];
   // with a fixed-stride row list the row numbers are requested before the descriptor is even here:
@@ -972,10 +980,15 @@ void gg_fused_split_kernel(
       vr[k] = *reinterpret_cast<const u32x4 *>(gv4 + (size_t)row * 4 + (q & 3));
     }
   }
+  if (dbg & GG_DBG_STAMP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gg_stamp_wave(dbg, (int)gridDim.x, t, 0);  // this wave's own pieces have landed
+  }
   __syncthreads();
   gg_stamp(dbg, t, 2);  // blob + gradient rows (+ var rows in registers) have landed
   if (!(dbg & 128))  // timing experiment: no flux phase
     flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
+  gg_stamp_wave(dbg, (int)gridDim.x, t, 1);  // this wave is through its flux phase
   __syncthreads();  // every wave is done with the gradient rows: the region takes the var rows
   gg_stamp(dbg, t, 3);  // flux phase done
   if constexpr (EARLY) {
@@ -993,6 +1006,7 @@ void gg_fused_split_kernel(
   gg_stamp(dbg, t, 4);  // var rows in place
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
                                    CB * nthr * 16, &pa, t);
+  gg_stamp_wave(dbg, (int)gridDim.x, t, 2);  // this wave is through its gradient phase (stores issued)
   gg_stamp(dbg, t, 5);  // gradient arithmetic done, row stores issued (wave 0)
   if (dbg & GG_DBG_STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1102,13 +1102,14 @@ int cfdp_gpu_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_
 
 // diagnostics (tools/phase_stamps.py): run `passes` fused passes with phase stamping on and return, per tile, 8
 // shader-clock stamps of the LAST pass (start, indices here, loads landed, flux done, var rows in place, gradient
-// arithmetic done + stores issued, stores acknowledged, unused); stamps[ntiles*8]
+// arithmetic done + stores issued, stores acknowledged, unused) and, behind them, 4 per wave of the tile (own pieces
+// landed, through the flux phase, through the gradient phase, unused); stamps[ntiles*24]
 int cfdp_gpu_debug_phase_stamps(cfdp_gpu *g, int passes, unsigned long long *stamps) {
   NEED_UPLOAD(g);
   if (!g->fusion || !g->d_grad_alt || passes < 1 || !stamps) return fail("fusion must be on");
   if (flush_flux(g)) return 1;
   unsigned long long *d = nullptr;
-  const size_t n = (size_t)g->ntiles * 8;
+  const size_t n = (size_t)g->ntiles * 24;  // 8 per tile, then 4 x 4 per wave
   HIP_TRY(hipMalloc(&d, n * sizeof(unsigned long long)));
   HIP_TRY(hipMemset(d, 0, n * sizeof(unsigned long long)));
   HIP_TRY(gg_set_stamp_buffer(d));
