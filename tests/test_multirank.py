@@ -216,3 +216,30 @@ def test_reference_main_and_harness_unchanged_under_mpiexec(gpu, tmp_path, nrank
     assert "exchange_dbl_mpi_pscw_async:" in r.stdout and "comm_free:" in r.stdout
     if nranks > 1:
         assert "validated" in r.stdout
+
+
+MPI_LIB = os.path.join(ROOT, "cfd-proxy_amd", "lib", "libcfdproxy_mpi.so")
+
+
+@pytest.mark.skipif(not (os.path.exists(MPIEXEC) and os.path.exists(MPI_LIB)), reason="no MPI in this image")
+@pytest.mark.parametrize("nranks", [2, 3, 4])
+def test_mpi_hooks_index_exchange_on_cpu(pkg, tmp_path, nranks):
+    """world_size > 1 on the CPU, under mpiexec: a C host linked with libcfdproxy_mpi.so + libcfdproxy_host.so calls
+    init_communication (MPI_Init_thread through the hook), the loader, compute_communication_tables (the sendindex
+    exchange of src/comm_data.c:203-249), free_communication_ressources; every rank's send list must name, by global
+    lattice id and in message order, exactly the ghosts its partner expects from it"""
+    lib = os.path.join(ROOT, "cfd-proxy_amd", "lib")
+    exe = str(tmp_path / "host_mpi_tables")
+    r = subprocess.run(["gcc", "-std=gnu99", "-O1", "-Wall", "-Werror", "-fopenmp", "-Wno-stringop-overflow", "-I/opt/conda/include",
+                        os.path.join(ROOT, "tests", "host_mpi_tables.c"), "-I" + os.path.join(ROOT, "include"), "-L" + lib,
+                        "-Wl,--no-as-needed", "-lcfdproxy_mpi", "-lcfdproxy_hip", os.path.join(lib, "mpi", "libmpi.so.12"),
+                        "-Wl,-rpath," + lib, "-Wl,-rpath," + os.path.join(lib, "mpi"), "-Wl,--allow-shlib-undefined", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    dims = (12, 10, 8)
+    pkg.write_mesh(pkg.gen_params(*dims, ndomains=nranks), str(tmp_path / "dualgrid"), 2)
+    r = subprocess.run([MPIEXEC, "-n", str(nranks), exe, "dualgrid", "2"] + [str(d) for d in dims], cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=120)
+    if r.returncode == 127:
+        pytest.skip("MPI runtime libraries not resolvable on this box")
+    assert r.returncode == 0 and "*** SUCCESS" in r.stdout and "mismatches 0" in r.stdout, r.stdout + r.stderr
