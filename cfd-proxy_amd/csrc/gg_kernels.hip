@@ -98,8 +98,9 @@ template <bool NT> __device__ __forceinline__ void st_row(double v, double *p) {
 
 // bit of the kernels' `dbg` argument that is not a timing experiment: walk the tiles backwards
 #define GG_DBG_REVERSE 0x10000
-// diagnostic build only (dbg bit GG_DBG_STAMP; never set in a timed run): thread 0 of every workgroup of the
-// split fused pass writes shader-clock stamps of its phase boundaries, 8 per tile, to a buffer of its own
+// diagnostics (dbg bit GG_DBG_STAMP selects a separate instantiation of the split fused pass, STAMP = true; the
+// kernels of a timed run contain none of it -- merely compiled in and switched off it cost 1-2.5 %): thread 0 of
+// every workgroup writes shader-clock stamps of its phase boundaries, 8 per tile, to a buffer of its own
 #define GG_DBG_STAMP 0x20000
 #ifndef GG_DEEP_BATCH
 #define GG_DEEP_BATCH 7
@@ -880,7 +881,7 @@ __device__ __forceinline__ void gg_stamp_wave(int dbg, int ntiles, int tile, int
 // their row numbers were fetched at the start), so a tile occupies CB + KX pieces per thread instead
 // of CB + KV + KG: 36 KiB instead of 48 KiB for 64-point tiles = FOUR workgroups per CU.  The price is
 // a second, exposed gather round trip per tile.
-template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, bool EARLY = true>
+template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, bool EARLY = true, bool STAMP = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
@@ -896,7 +897,8 @@ void gg_fused_split_kernel(
                                             (dbg & GG_DBG_REVERSE) != 0);
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
-  gg_stamp(dbg, t, 0);
+  if constexpr (STAMP) gg_stamp(dbg, t, 0);
+  if constexpr (STAMP)
   if ((dbg & GG_DBG_STAMP) && tid == 0 && gg_stamp_buf)  // which CU: HW_ID (cu, sh, se) and XCC_ID
     gg_stamp_buf[(size_t)t * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                                      (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -950,7 +952,7 @@ void gg_fused_split_kernel(
     else glds16(b4 + q, smem + (size_t)q0 * 16);
   }
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CB) : "memory");
-  gg_stamp(dbg, t, 1);  // descriptor + row numbers are here
+  if constexpr (STAMP) gg_stamp(dbg, t, 1);  // descriptor + row numbers are here
 #pragma unroll
   for (int k = 0; k < KV; k++) asm volatile("" : "+v"(hv[k]));
 #pragma unroll
@@ -980,17 +982,17 @@ void gg_fused_split_kernel(
       vr[k] = *reinterpret_cast<const u32x4 *>(gv4 + (size_t)row * 4 + (q & 3));
     }
   }
-  if (dbg & GG_DBG_STAMP) {
+  if constexpr (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     gg_stamp_wave(dbg, (int)gridDim.x, t, 0);  // this wave's own pieces have landed
   }
   __syncthreads();
-  gg_stamp(dbg, t, 2);  // blob + gradient rows (+ var rows in registers) have landed
+  if constexpr (STAMP) gg_stamp(dbg, t, 2);  // blob + gradient rows (+ var rows in registers) have landed
   if (!(dbg & 128))  // timing experiment: no flux phase
     flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
-  gg_stamp_wave(dbg, (int)gridDim.x, t, 1);  // this wave is through its flux phase
+  if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 1);  // this wave is through its flux phase
   __syncthreads();  // every wave is done with the gradient rows: the region takes the var rows
-  gg_stamp(dbg, t, 3);  // flux phase done
+  if constexpr (STAMP) gg_stamp(dbg, t, 3);  // flux phase done
   if constexpr (EARLY) {
 #pragma unroll
     for (int k = 0; k < KV; k++) *reinterpret_cast<u32x4 *>(xbuf + (size_t)(tid + k * nthr) * 16) = vr[k];
@@ -1003,12 +1005,12 @@ void gg_fused_split_kernel(
     }
   }
   __syncthreads();  // vmcnt(0) + barrier
-  gg_stamp(dbg, t, 4);  // var rows in place
+  if constexpr (STAMP) gg_stamp(dbg, t, 4);  // var rows in place
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
                                    CB * nthr * 16, &pa, t);
-  gg_stamp_wave(dbg, (int)gridDim.x, t, 2);  // this wave is through its gradient phase (stores issued)
-  gg_stamp(dbg, t, 5);  // gradient arithmetic done, row stores issued (wave 0)
-  if (dbg & GG_DBG_STAMP) {
+  if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 2);  // this wave is through its gradient phase (stores issued)
+  if constexpr (STAMP) gg_stamp(dbg, t, 5);  // gradient arithmetic done, row stores issued (wave 0)
+  if constexpr (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     gg_stamp(dbg, t, 6);  // wave 0's stores acknowledged
   }
@@ -1279,6 +1281,15 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
   hipLaunchKernelGGL((gg_fused_split_kernel<R, N, 5, 4, 4, 4>), dim3(ntiles), dim3(block), split_lds, stream, a.tiles, \
                      tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, \
                      dbgf, pa)
+    if (gg_debug_flags & GG_DBG_STAMP) {  // diagnostic build of the same kernel: phase stamps (tools/phase_stamps.py)
+      if (nt) hipLaunchKernelGGL((gg_fused_split_kernel<false, true, 5, 4, 4, 4, true, true>), dim3(ntiles), dim3(block), split_lds, stream,
+                                 a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a,
+                                 gnew.b, dbgf, pa);
+      else hipLaunchKernelGGL((gg_fused_split_kernel<false, false, 5, 4, 4, 4, true, true>), dim3(ntiles), dim3(block), split_lds, stream,
+                              a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a,
+                              gnew.b, dbgf, pa);
+      return hipGetLastError();
+    }
     if (gg_debug_flags & 1024) {  // timing experiment: the var rows gathered after the flux phase
       hipLaunchKernelGGL((gg_fused_split_kernel<false, false, 5, 4, 4, 4, false>), dim3(ntiles), dim3(block), split_lds,
                          stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown,
@@ -1391,6 +1402,8 @@ hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
   SET_LDS((gg_fused_dma_kernel<true, true, CB, KV, KG>), all)
   SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4>), all)
   SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4, false>), all)
+  SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4, true, true>), all)
+  SET_LDS((gg_fused_split_kernel<false, true, 5, 4, 4, 4, true, true>), all)
   SET_LDS((gg_fused_split_kernel<false, true, 5, 4, 4, 4>), all)
   SET_LDS((gg_fused_split_kernel<true, false, 5, 4, 4, 4>), all)
   SET_LDS((gg_fused_split_kernel<true, true, 5, 4, 4, 4>), all)
