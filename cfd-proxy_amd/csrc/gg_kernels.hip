@@ -102,6 +102,13 @@ template <bool NT> __device__ __forceinline__ void st_row(double v, double *p) {
 // kernels of a timed run contain none of it -- merely compiled in and switched off it cost 1-2.5 %): thread 0 of
 // every workgroup writes shader-clock stamps of its phase boundaries, 8 per tile, to a buffer of its own
 #define GG_DBG_STAMP 0x20000
+// the timing experiments of CFDP_DEBUG_ABLATE (skip a phase, skip the stores, ...) are compiled in only with
+// -DGG_WITH_ABLATION=1 (tools build such a library under tools/bin/): as run-time branches of the timed kernels they
+// would cost what the switched-off phase stamps did
+#ifndef GG_WITH_ABLATION
+#define GG_WITH_ABLATION 0
+#endif
+#define GG_ABL(dbg, bits) (GG_WITH_ABLATION && ((dbg) & (bits)))
 #ifndef GG_DEEP_BATCH
 #define GG_DEEP_BATCH 7
 #endif
@@ -197,7 +204,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     for (int j = 0; j < NE; j++) vs[j] = var_l[li * 8 + eq0 + j];
     ks = (int)ioff[li];
     ke0 = (int)ioff[li + 1];
-    const int ke = (dbg & 4) ? ks : ke0;  // timing experiment: no arithmetic, stores only
+    const int ke = GG_ABL(dbg, 4) ? ks : ke0;  // timing experiment: no arithmetic, stores only
     const double *var_eq0 = var_l + eq0;
     int k = ks;
     if constexpr (NE <= 2)  // few registers per incidence: deeper batches (a point has ~14 incidences)
@@ -281,7 +288,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     const size_t p0 = (size_t)(td.pstart + wp + h * SPP);
     double *ga = gradA + p0 * 10, *gb = gradB + p0 * 11;
     const int na = nvh * 10, nd = nvh * 21;
-    if (dbg & 256) continue;  // timing experiment: no row stores
+    if (GG_ABL(dbg, 256)) continue;  // timing experiment: no row stores
     for (int c = lane; c < nd; c += 64) {
       if (c < na) st_row<NT>(slab[c], &ga[c]);
       else st_row<NT>(slab[SPP * 10 + c - na], &gb[c - na]);
@@ -542,14 +549,14 @@ __global__ __launch_bounds__(1024) void gg_gradient_pipe_kernel(
   for (; t < tend; t += tstep) {
     unsigned char *bcur = smem + (size_t)cur * buf_bytes;
     unsigned char *bnxt = smem + (size_t)(cur ^ 1) * buf_bytes;
-    if (t + tstep < tend && !(dbg & 2)) pipe_issue_tile<NT>(bnxt, tn, blob, gv4, hrow, tid, nthr);
+    if (t + tstep < tend && !GG_ABL(dbg, 2)) pipe_issue_tile<NT>(bnxt, tn, blob, gv4, hrow, tid, nthr);
     cfdp_tile_desc tnn = tn;
     if (t + 2 * tstep < tend) {
       tnn = tiles[t + 2 * tstep];
       pipe_load_hrows(hrow, tnn, halo_idx, tid, nthr);  // used one iteration from now
     }
-    if (dbg & 2) grad_tile_compute<LPP, NT>(smem, td0, tid, gradA, gradB, stage, dbg);  // timing experiment: buffer 0 only
-    else if (!(dbg & 1)) grad_tile_compute<LPP, NT>(bcur, td, tid, gradA, gradB, stage, dbg);
+    if (GG_ABL(dbg, 2)) grad_tile_compute<LPP, NT>(smem, td0, tid, gradA, gradB, stage, dbg);  // timing experiment: buffer 0 only
+    else if (!GG_ABL(dbg, 1)) grad_tile_compute<LPP, NT>(bcur, td, tid, gradA, gradB, stage, dbg);
     __syncthreads();  // (a) everyone is done reading bcur, (b) tile t+1 has landed in bnxt
     td = tn;
     tn = tnn;
@@ -838,9 +845,9 @@ void gg_fused_dma_kernel(
                  gbuf + (size_t)(w0 + k * nthr) * 16);
   }
   __syncthreads();
-  if (!(dbg & 128))  // timing experiment: no flux phase
+  if (!GG_ABL(dbg, 128))  // timing experiment: no flux phase
     flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
-  if (dbg & 512) return;  // timing experiment: no gradient phase
+  if (GG_ABL(dbg, 512)) return;  // timing experiment: no gradient phase
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(gbuf), dbg,
                                    CB * nthr * 16, &pa, t);
   push_tile_done(pa, t, tid);
@@ -881,7 +888,11 @@ __device__ __forceinline__ void gg_stamp_wave(int dbg, int ntiles, int tile, int
 // their row numbers were fetched at the start), so a tile occupies CB + KX pieces per thread instead
 // of CB + KV + KG: 36 KiB instead of 48 KiB for 64-point tiles = FOUR workgroups per CU.  The price is
 // a second, exposed gather round trip per tile.
-template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, bool EARLY = true, bool STAMP = false>
+// LISTED: the fixed-stride row lists exist (gg_args::rowlist); PUSH: an exchange rides in the pass (the boundary
+// tiles wait for the previous exchange, push their rows, notify) -- both compile-time, so the pass that runs one
+// partition on one GPU carries neither the other path's code nor its registers
+template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, bool EARLY = true, bool STAMP = false, bool LISTED = true,
+          bool PUSH = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
@@ -893,7 +904,7 @@ void gg_fused_split_kernel(
   static_assert(KX >= KV && KX >= KG, "the shared row region must hold either set of rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LPP = 4;
-  const int t = tile_begin + xcd_tile_bfirst(blockIdx.x, gridDim.x, pa.tile_off && tile_begin == 0 ? pa.nbtiles : 0,
+  const int t = tile_begin + xcd_tile_bfirst(blockIdx.x, gridDim.x, PUSH && pa.tile_off && tile_begin == 0 ? pa.nbtiles : 0,
                                             (dbg & GG_DBG_REVERSE) != 0);
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
@@ -902,11 +913,11 @@ void gg_fused_split_kernel(
   if ((dbg & GG_DBG_STAMP) && tid == 0 && gg_stamp_buf)  // which CU: HW_ID (cu, sh, se) and XCC_ID
     gg_stamp_buf[(size_t)t * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                                      (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-  wait_previous_exchange(pa, t, tid);  // before any ghost row is requested
+  if constexpr (PUSH) wait_previous_exchange(pa, t, tid);  // before any ghost row is requested
   int hv[KV], hg[KG], part[KG], rloc[KG];
   // with a fixed-stride row list the row numbers are requested before the descriptor is even here:
   // descriptor -> blob and row list -> rows are two chains of two round trips instead of one of three
-  const bool listed = rowlist != nullptr;
+  constexpr bool listed = LISTED;
   if (listed) {
     const int *rl = rowlist + (size_t)t * GG_ROW_STRIDE;
 #pragma unroll
@@ -988,7 +999,7 @@ void gg_fused_split_kernel(
   }
   __syncthreads();
   if constexpr (STAMP) gg_stamp(dbg, t, 2);  // blob + gradient rows (+ var rows in registers) have landed
-  if (!(dbg & 128))  // timing experiment: no flux phase
+  if (!GG_ABL(dbg, 128))  // timing experiment: no flux phase
     flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 1);  // this wave is through its flux phase
   __syncthreads();  // every wave is done with the gradient rows: the region takes the var rows
@@ -1007,14 +1018,14 @@ void gg_fused_split_kernel(
   __syncthreads();  // vmcnt(0) + barrier
   if constexpr (STAMP) gg_stamp(dbg, t, 4);  // var rows in place
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
-                                   CB * nthr * 16, &pa, t);
+                                   CB * nthr * 16, PUSH ? &pa : nullptr, t);
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 2);  // this wave is through its gradient phase (stores issued)
   if constexpr (STAMP) gg_stamp(dbg, t, 5);  // gradient arithmetic done, row stores issued (wave 0)
   if constexpr (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     gg_stamp(dbg, t, 6);  // wave 0's stores acknowledged
   }
-  push_tile_done(pa, t, tid);
+  if constexpr (PUSH) push_tile_done(pa, t, tid);
 }
 
 // ------------------------------------------------------------- xGMI write + notify exchange
@@ -1277,28 +1288,30 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
   if (cb < 1 || kv < 1 || kg < 1) return hipErrorNotSupported;
   if (gg_fused_split && allow_split && cb <= 5 && kv <= 4 && kg <= 4) {
     const size_t split_lds = (size_t)(5 + 4) * block * 16;
-#define LAUNCH_SPLIT(R, N)                                                                        \
-  hipLaunchKernelGGL((gg_fused_split_kernel<R, N, 5, 4, 4, 4>), dim3(ntiles), dim3(block), split_lds, stream, a.tiles, \
-                     tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, \
-                     dbgf, pa)
+    const bool listed = a.rowlist != nullptr, pushing = pa.tile_off != nullptr;
+#define LAUNCH_SPLIT_X(R, N, E, S, L, P)                                                                            \
+  hipLaunchKernelGGL((gg_fused_split_kernel<R, N, 5, 4, 4, 4, E, S, L, P>), dim3(ntiles), dim3(block), split_lds, stream, \
+                     a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, \
+                     gnew.a, gnew.b, dbgf, pa)
+#define LAUNCH_SPLIT_LP(R, N, E, S)                                                     \
+  do {                                                                                  \
+    if (listed) { if (pushing) LAUNCH_SPLIT_X(R, N, E, S, true, true); else LAUNCH_SPLIT_X(R, N, E, S, true, false); } \
+    else { if (pushing) LAUNCH_SPLIT_X(R, N, E, S, false, true); else LAUNCH_SPLIT_X(R, N, E, S, false, false); }      \
+  } while (0)
     if (gg_debug_flags & GG_DBG_STAMP) {  // diagnostic build of the same kernel: phase stamps (tools/phase_stamps.py)
-      if (nt) hipLaunchKernelGGL((gg_fused_split_kernel<false, true, 5, 4, 4, 4, true, true>), dim3(ntiles), dim3(block), split_lds, stream,
-                                 a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a,
-                                 gnew.b, dbgf, pa);
-      else hipLaunchKernelGGL((gg_fused_split_kernel<false, false, 5, 4, 4, 4, true, true>), dim3(ntiles), dim3(block), split_lds, stream,
-                              a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a,
-                              gnew.b, dbgf, pa);
+      if (nt) LAUNCH_SPLIT_X(false, true, true, true, true, true); else LAUNCH_SPLIT_X(false, false, true, true, true, true);
       return hipGetLastError();
     }
+#if GG_WITH_ABLATION
     if (gg_debug_flags & 1024) {  // timing experiment: the var rows gathered after the flux phase
-      hipLaunchKernelGGL((gg_fused_split_kernel<false, false, 5, 4, 4, 4, false>), dim3(ntiles), dim3(block), split_lds,
-                         stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown,
-                         gnew.a, gnew.b, dbgf, pa);
+      LAUNCH_SPLIT_X(false, false, false, false, true, true);
       return hipGetLastError();
     }
-    if (refmode) { if (nt) LAUNCH_SPLIT(true, true); else LAUNCH_SPLIT(true, false); }
-    else { if (nt) LAUNCH_SPLIT(false, true); else LAUNCH_SPLIT(false, false); }
-#undef LAUNCH_SPLIT
+#endif
+    if (refmode) { if (nt) LAUNCH_SPLIT_LP(true, true, true, false); else LAUNCH_SPLIT_LP(true, false, true, false); }
+    else { if (nt) LAUNCH_SPLIT_LP(false, true, true, false); else LAUNCH_SPLIT_LP(false, false, true, false); }
+#undef LAUNCH_SPLIT_LP
+#undef LAUNCH_SPLIT_X
     return hipGetLastError();
   }
 #define LAUNCH_FUSED_RN(R, N, CB, KV, KG)                                                         \
@@ -1400,13 +1413,21 @@ hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
   SET_LDS((gg_fused_dma_kernel<false, true, CB, KV, KG>), all)   \
   SET_LDS((gg_fused_dma_kernel<true, false, CB, KV, KG>), all)   \
   SET_LDS((gg_fused_dma_kernel<true, true, CB, KV, KG>), all)
-  SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4>), all)
-  SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4, false>), all)
-  SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4, true, true>), all)
-  SET_LDS((gg_fused_split_kernel<false, true, 5, 4, 4, 4, true, true>), all)
-  SET_LDS((gg_fused_split_kernel<false, true, 5, 4, 4, 4>), all)
-  SET_LDS((gg_fused_split_kernel<true, false, 5, 4, 4, 4>), all)
-  SET_LDS((gg_fused_split_kernel<true, true, 5, 4, 4, 4>), all)
+#define SET_LDS_SPLIT(R, N)                                                             \
+  SET_LDS((gg_fused_split_kernel<R, N, 5, 4, 4, 4, true, false, true, true>), all)      \
+  SET_LDS((gg_fused_split_kernel<R, N, 5, 4, 4, 4, true, false, true, false>), all)     \
+  SET_LDS((gg_fused_split_kernel<R, N, 5, 4, 4, 4, true, false, false, true>), all)     \
+  SET_LDS((gg_fused_split_kernel<R, N, 5, 4, 4, 4, true, false, false, false>), all)
+  SET_LDS_SPLIT(false, false)
+  SET_LDS_SPLIT(false, true)
+  SET_LDS_SPLIT(true, false)
+  SET_LDS_SPLIT(true, true)
+#undef SET_LDS_SPLIT
+  SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4, true, true, true, true>), all)
+  SET_LDS((gg_fused_split_kernel<false, true, 5, 4, 4, 4, true, true, true, true>), all)
+#if GG_WITH_ABLATION
+  SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4, false, false, true, true>), all)
+#endif
   SET_LDS_FUSED(5, 3, 4)
   SET_LDS_FUSED(5, 4, 4)
   SET_LDS_FUSED(5, 4, 5)
