@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- Green-Gauss gradient iterations/s on the F6-like dualgrid stand-ins.
 
-    python bench.py --gpus N --steps K --warmup W [--config NAME]   (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--config NAME]
+
+N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment,
+one rank per GPU), or -- started plainly, without a rank environment -- this process only LAUNCHES: before it
+touches the GPU it starts N fresh rank processes of itself (the reference is started the same way, `mpirun -np N`
+around init_communication, reference src/comm_data.c:257-307, README.txt:92-93), forwards rank 0's JSON line, and
+exits non-zero if any rank fails or the job times out (CFDP_BENCH_TIMEOUT seconds, default 1500).
 
 One "step" = one iteration of the hot path as the reference harness times it
 (reference src/solver.c:48-54): Green-Gauss gradients over all faces (+ halo exchange of the
@@ -22,7 +28,9 @@ checkout, so deterministic stand-ins with the same schema are generated, see DES
 `value` is the whole-job rate in units of one level-2 mesh: iterations/s of the mesh x (mesh points /
 262,144) -- so the strong series (64^3 on 1, 2, 4 GPUs) and the weak point (128^3 on 8) read on one
 scale, and value(N) / (N x value(1)) is the scaling efficiency either way.  With --gpus 2 / 4 the line
-also carries the weak-scaling measurement of the same run under "weak_scaling".
+also carries the weak-scaling measurement of the same run under "weak_scaling"; with --gpus 8 the
+dualgrid.192 strong-scaling point (BASELINE config 4) under "strong_scaling".  "cpu_baseline" (the compiled
+reference on rank 0's host cores, the whole mesh of the config as one domain) is carried at every N.
 
 Prints ONE JSON line on rank 0.
 """
@@ -97,6 +105,71 @@ def committed_traffic(workload_key: str):
     return out, src
 
 
+def launch_ranks(n: int, argv: list, ndev: int, child_cmd=None, timeout: float = None) -> int:
+    """`python bench.py --gpus N` without a rank environment: start N fresh processes of this script, one rank
+    each (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), forward rank 0's stdout (the JSON line)
+    and every rank's stderr, and return the exit code for the job: non-zero if any rank failed or the job ran
+    past `timeout` seconds -- the remaining ranks are then killed (by pid).  The caller has not touched the GPU
+    (no exec from a GPU process either: children are spawned).  `child_cmd` replaces [python, bench.py] in tests."""
+    import socket
+    import subprocess
+    if n > ndev and os.environ.get("CFDP_SHARED_GPU") != "1":
+        print(f"bench.py: --gpus {n} but {ndev} GPU(s) are visible; one rank per GPU is the contract "
+              f"(CFDP_SHARED_GPU=1 lets ranks share devices: rehearsals only, the timings mean nothing)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    timeout = timeout if timeout is not None else float(os.environ.get("CFDP_BENCH_TIMEOUT", "1500"))
+    cmd = list(child_cmd) if child_cmd else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % max(ndev, 1)), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=None, text=True))
+    t_end = time.time() + timeout
+    rc, out0 = 0, ""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                try:
+                    if r == 0:
+                        out0, _ = procs[0].communicate(timeout=0.2)
+                    else:
+                        procs[r].wait(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.discard(r)
+                if procs[r].returncode != 0:
+                    print(f"bench.py: rank {r} exited with code {procs[r].returncode}", file=sys.stderr)
+                    rc = rc or (procs[r].returncode if procs[r].returncode > 0 else 1)
+            if rc:
+                break
+            if time.time() > t_end:
+                print(f"bench.py: the {n}-rank job ran past {timeout:.0f} s", file=sys.stderr)
+                rc = 124
+                break
+    finally:
+        for p in procs:  # only on failure / timeout is anything still running here
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                pass
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    if rc == 0 and not any(l.startswith("{") for l in out0.splitlines()):
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,7 +192,14 @@ def main() -> None:
                          "between the processes of a node (falls back to rccl if its check fails); rccl: "
                          "ncclSend/ncclRecv issued by the C library; torch: torch.distributed P2P ops; staged: "
                          "through the host (tests)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the extra dualgrid.192 strong-scaling measurement at --gpus 8")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (no launcher): this process only launches the ranks, BEFORE anything touches the GPU
+        # (counting devices does not initialise HIP on this image)
+        import torch
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], torch.cuda.device_count()))
 
     import numpy as np
     import torch
@@ -132,7 +212,7 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; running {world} rank(s)", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -309,12 +389,36 @@ def main() -> None:
         except Exception as e:  # the extra must never cost the line
             out["weak_scaling"] = {"error": repr(e)[:300]}
 
+    # ---- --gpus 8: BASELINE config 4 (dualgrid.192 lvl 2, ~33 k points per GPU: the strong-scaling point) rides along ----
+    if world == 8 and cfg["name"] != "dualgrid.192" and not args.no_strong:
+        if solver is not None:
+            solver.close()
+            part.free()
+            solver = part = None
+        try:
+            sres, _, _ = measure(mg.bench_config("dualgrid.192", world))
+            out["strong_scaling"] = {k: sres[k] for k in ("value", "ms_per_step", "scaling", "config", "exchange_check", "overlap")
+                                     if k in sres}
+        except Exception as e:  # the extra must never cost the line
+            out["strong_scaling"] = {"error": repr(e)[:300]}
+
+    if world > 1:
+        # the other ranks are done: the CPU baseline below runs on rank 0's host cores alone
+        if solver is not None:
+            solver.close()
+            part.free()
+            solver = part = None
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
+        if rank != 0:
+            return
+
     if rank == 0 and world == 1:
         # ---- the truly HBM-bound single-GPU case: finest level (2.1 M points, 0.95 GB per pass) ----
         if not args.no_finest:
-            gp1 = pkg.gen_params(128, ndomains=1)
-            d1 = pkg.gen_domain(gp1, 0)
-            pkg.fill_var(d1, None, pkg.VAR_HASH)
+            gp1 = pkg.gen_params(128, ndomains=384)
+            d1, _ = mg.build_rank_partition(gp1, 384, 1, 0, via_files=not args.no_files)
             p1 = pkg.GpuPartition(d1, device=device, tile_points=args.tile_points, grad_lanes=args.grad_lanes,
                                   flux_lanes=args.flux_lanes)
             p1.time_kernels(10)  # first touches of 1.7 GB of device memory
@@ -327,7 +431,8 @@ def main() -> None:
             b1 = pkg.algo_bytes_grad(d1.nfaces, d1.nown, 0)
             b1f = pkg.algo_bytes_flux(d1.nfaces, d1.nown, 0)
             tr1, _ = committed_traffic("dualgrid.384 finest-level stand-in (128^3)")
-            fl = {"workload": "dualgrid.384 finest-level stand-in merged on 1 GPU (128^3)", "points": d1.nown, "faces": d1.nfaces,
+            fl = {"workload": "dualgrid.384 finest-level stand-in (128^3): 384 domain files -> loader -> merged on 1 GPU, no halo exchange",
+                  "points": d1.nown, "faces": d1.nfaces,
                   "iterations_per_s": 1e3 / (fu1 if fu1 else g1 + f1),
                   "gradient_kernel": fracs(b1, b1, tr1.get("gg_gradient"), g1), "flux_kernel": fracs(b1f, b1f, tr1.get("gg_flux"), f1)}
             if fu1:
@@ -335,57 +440,75 @@ def main() -> None:
             out["finest_level"] = fl
             p1.close()
             d1.free()
-        # ---- CPU baseline on the host cores: the COMPILED REFERENCE (oracle/_ref/ref_dump_raw: the
-        # reference's own OpenMP path, src/solver.c:42-58 comm_free loop + flux) when the binary is there,
-        # with the oracle's port of the same algorithm class beside it ----
-        if not args.no_cpu:
-            from __graft_entry__ import load_oracle
-            orc = load_oracle()
-            cores = usable_cores()
-            ref = orc.CpuRef(part.fpoint, part.fnormal, part.pvolume, part.nown, nthreads=cores)
-            samples = sorted(ref.timed(part.var, niter=25, with_flux=True) for _ in range(args.cpu_samples))
-            gsamples = sorted(ref.timed(part.var, niter=25, with_flux=False) for _ in range(3))
-            ref.close()
-            med = samples[len(samples) // 2]
-            port = {"value": 25.0 / med, "unit": "iterations/s", "cores": cores, "kind": "port",
-                    "sample": f"same 64^3 merged mesh, {args.cpu_samples} samples x 25 iterations "
-                              f"(gradients+flux), median; oracle/cpu_ref.c OpenMP, threads not bound",
-                    "gradient_only_iterations_per_s": 25.0 / gsamples[len(gsamples) // 2]}
-            out["cpu_baseline"] = port
-            ref_bin = orc.ref_dump_path()
-            if os.path.exists(ref_bin):
-                import re
-                import subprocess
-                import tempfile
-                try:
-                    best = None
-                    with tempfile.TemporaryDirectory() as tmp:
-                        raw = os.path.join(tmp, "merged")
-                        orc.write_raw_domain(raw, 0, part.fpoint, part.fnormal, part.pvolume, part.nown, var=part.var)
-                        # the reference spin-waits between its threads: where they are pinned matters on a box
-                        # that grants a share of a bigger host, so both placements are timed and the faster kept
-                        for bind in ("false", "true"):
-                            env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND=bind)
-                            for wf in (1, 0):
-                                r = subprocess.run([ref_bin, "time", raw, str(args.cpu_samples), str(wf)],
-                                                   env=env, capture_output=True, text=True, timeout=300)
-                                m = re.search(r"median_s=([0-9.]+)", r.stdout)
-                                if r.returncode == 0 and m:
-                                    v = 25.0 / float(m.group(1))
-                                    if wf and (best is None or v > best["value"]):
-                                        best = {"value": v, "omp_proc_bind": bind}
-                                    elif not wf and best is not None and best["omp_proc_bind"] == bind:
-                                        best["gradient_only_iterations_per_s"] = v
-                    if best:
-                        out["cpu_baseline"] = {
-                            "value": best["value"], "unit": "iterations/s", "cores": cores, "kind": "reference",
-                            "sample": f"compiled reference (oracle/_ref/ref_dump_raw: src/solver.c:42-58 comm_free loop + "
-                                      f"compute_psd_flux), same 64^3 merged mesh as one domain, {args.cpu_samples} samples x 25 "
-                                      f"iterations, median; OMP_PROC_BIND={best['omp_proc_bind']} (faster of false/true)",
-                            "gradient_only_iterations_per_s": best.get("gradient_only_iterations_per_s"),
-                            "port": port}
-                except Exception as e:  # the baseline is optional; the bench line must still print
-                    out["cpu_baseline"]["reference_binary_error"] = str(e)[:200]
+    # ---- CPU baseline on rank 0's host cores, at every N: the COMPILED REFERENCE (oracle/_ref/ref_dump_raw: the
+    # reference's own OpenMP path, src/solver.c:42-58 comm_free loop + flux) when the binary is there,
+    # with the oracle's port of the same algorithm class beside it ----
+    if rank == 0 and not args.no_cpu:
+        from __graft_entry__ import load_oracle
+        orc = load_oracle()
+        cores = usable_cores()
+        dims = cfg["dims"]
+        mesh_name = f"{dims[0]}x{dims[1]}x{dims[2]}" if len(set(dims)) > 1 else f"{dims[0]}^3"
+        nsamp = args.cpu_samples if dims[0] * dims[1] * dims[2] <= UNIT_POINTS else min(args.cpu_samples, 3)
+        cpu_dom = None
+        if part is None:
+            # N > 1: the whole mesh of this config as ONE domain, on rank 0's host cores (the other ranks are done)
+            cpu_dom = pkg.gen_domain(pkg.gen_params(*dims, ndomains=1), 0)
+            pkg.fill_var(cpu_dom, None, pkg.VAR_HASH)
+            part = cpu_dom
+            mesh_what = f"the whole {mesh_name} mesh of this config as one domain"
+        else:
+            mesh_what = f"same {mesh_name} merged mesh"
+        in_units = dims[0] * dims[1] * dims[2] / UNIT_POINTS
+        ref = orc.CpuRef(part.fpoint, part.fnormal, part.pvolume, part.nown, nthreads=cores)
+        samples = sorted(ref.timed(part.var, niter=25, with_flux=True) for _ in range(nsamp))
+        gsamples = sorted(ref.timed(part.var, niter=25, with_flux=False) for _ in range(3))
+        ref.close()
+        med = samples[len(samples) // 2]
+        port = {"value": 25.0 / med, "unit": "iterations/s", "cores": cores, "kind": "port",
+                "sample": f"{mesh_what}, {nsamp} samples x 25 iterations "
+                          f"(gradients+flux), median; oracle/cpu_ref.c OpenMP, threads not bound",
+                "gradient_only_iterations_per_s": 25.0 / gsamples[len(gsamples) // 2],
+                "value_in_units_of_the_headline": 25.0 / med * in_units}
+        out["cpu_baseline"] = port
+        ref_bin = orc.ref_dump_path()
+        if os.path.exists(ref_bin):
+            import re
+            import subprocess
+            import tempfile
+            try:
+                best = None
+                with tempfile.TemporaryDirectory() as tmp:
+                    raw = os.path.join(tmp, "merged")
+                    orc.write_raw_domain(raw, 0, part.fpoint, part.fnormal, part.pvolume, part.nown, var=part.var)
+                    # the reference spin-waits between its threads: where they are pinned matters on a box
+                    # that grants a share of a bigger host, so both placements are timed and the faster kept
+                    for bind in ("false", "true"):
+                        env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND=bind)
+                        for wf in (1, 0):
+                            r = subprocess.run([ref_bin, "time", raw, str(nsamp), str(wf)],
+                                               env=env, capture_output=True, text=True, timeout=300)
+                            m = re.search(r"median_s=([0-9.]+)", r.stdout)
+                            if r.returncode == 0 and m:
+                                v = 25.0 / float(m.group(1))
+                                if wf and (best is None or v > best["value"]):
+                                    best = {"value": v, "omp_proc_bind": bind}
+                                elif not wf and best is not None and best["omp_proc_bind"] == bind:
+                                    best["gradient_only_iterations_per_s"] = v
+                if best:
+                    out["cpu_baseline"] = {
+                        "value": best["value"], "unit": "iterations/s", "cores": cores, "kind": "reference",
+                        "sample": f"compiled reference (oracle/_ref/ref_dump_raw: src/solver.c:42-58 comm_free loop + "
+                                  f"compute_psd_flux), {mesh_what}{'' if cpu_dom else ' as one domain'}, {nsamp} samples x 25 "
+                                  f"iterations, median; OMP_PROC_BIND={best['omp_proc_bind']} (faster of false/true)",
+                        "gradient_only_iterations_per_s": best.get("gradient_only_iterations_per_s"),
+                        "value_in_units_of_the_headline": best["value"] * in_units,
+                        "port": port}
+            except Exception as e:  # the baseline is optional; the bench line must still print
+                out["cpu_baseline"]["reference_binary_error"] = str(e)[:200]
+        if cpu_dom is not None:
+            cpu_dom.free()
+            part = None
     if rank == 0:
         print(json.dumps(out))
     if solver is not None:

@@ -62,7 +62,7 @@ def _bench_two_ranks(transport, extra_env=None, expect=None, weak=False):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), CFDP_SHARED_GPU="1", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
-                                       "--warmup", "3", "--transport", transport, "--no-files"] + ([] if weak else ["--no-weak"]),
+                                       "--warmup", "3", "--transport", transport, "--no-files", "--no-cpu"] + ([] if weak else ["--no-weak"]),
                                       env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
@@ -83,7 +83,7 @@ def _bench_two_ranks(transport, extra_env=None, expect=None, weak=False):
     assert out["exchange_check"]["ok"], out["exchange_check"]
     assert out["config"]["transport"] == (expect or ("ipc" if transport == "auto" else transport))
     assert out["config"]["fused_iterations"]
-    assert "cpu_baseline" not in out
+    assert "cpu_baseline" not in out  # (--no-cpu here; the self-launched run below carries it)
     return out
 
 
@@ -109,3 +109,72 @@ def test_bench_falls_back_when_the_exchange_check_fails(gpu):
     other transport two ranks sharing one GPU have)"""
     out = _bench_two_ranks("auto", extra_env={"CFDP_BENCH_REJECT_FIRST": "1"}, expect="staged")
     assert out["exchange_check"]["transports_rejected"] == ["ipc"]
+
+
+# ---- `python bench.py --gpus N` started plainly (no launcher, no rank environment) starts its N ranks itself ----
+_FAKE_RANK = r"""
+import json, os, sys, time
+r, n = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0 and "LOCAL_RANK" in os.environ
+mode = sys.argv[1]
+if mode == "fail" and r == 1:
+    sys.exit(7)
+if mode == "hang" or (mode == "fail" and r != 1):
+    time.sleep(600)
+if r == 0:
+    print(json.dumps({"n_gpus": n, "local_rank": os.environ["LOCAL_RANK"], "argv": sys.argv[1:]}))
+"""
+
+
+def test_launcher_starts_the_ranks_and_forwards_rank0(capfd):
+    import bench
+    cmd = [sys.executable, "-c", _FAKE_RANK]
+    assert bench.launch_ranks(3, ["ok", "--steps", "5"], ndev=3, child_cmd=cmd, timeout=60) == 0
+    out = json.loads([l for l in capfd.readouterr().out.splitlines() if l.startswith("{")][-1])
+    assert out == {"n_gpus": 3, "local_rank": "0", "argv": ["ok", "--steps", "5"]}
+
+
+def test_launcher_fails_the_job_when_a_rank_fails_or_hangs(capfd, monkeypatch):
+    import time
+    import bench
+    cmd = [sys.executable, "-c", _FAKE_RANK]
+    t = time.time()
+    assert bench.launch_ranks(3, ["fail"], ndev=3, child_cmd=cmd, timeout=60) == 7  # ranks 0 and 2 are killed, not waited for
+    assert time.time() - t < 30
+    assert "rank 1 exited with code 7" in capfd.readouterr().err
+    assert bench.launch_ranks(2, ["hang"], ndev=2, child_cmd=cmd, timeout=2) == 124
+    # more ranks than devices: refused with a message, unless the ranks are told to share devices (rehearsals)
+    monkeypatch.delenv("CFDP_SHARED_GPU", raising=False)
+    assert bench.launch_ranks(2, ["ok"], ndev=1, child_cmd=cmd, timeout=60) == 2
+    assert "2 but 1 GPU(s) are visible" in capfd.readouterr().err
+    monkeypatch.setenv("CFDP_SHARED_GPU", "1")
+    assert bench.launch_ranks(2, ["ok"], ndev=1, child_cmd=cmd, timeout=60) == 0
+
+
+def test_bench_without_launcher_refuses_more_ranks_than_gpus():
+    """started as the driver starts it (`python bench.py --gpus N`, no rank environment): never a silent 1-rank run"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CFDP_SHARED_GPU")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the devices")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr and not r.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_started_plainly_launches_two_ranks(gpu):
+    """`python bench.py --gpus 2 --steps 20 --warmup 3` with NO rank environment (how the driver starts it): the
+    process launches its two ranks itself -- sharing this box's one GPU -- and rank 0's line says n_gpus 2, the
+    exchange check holds, the overlap report and the CPU baseline are there"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CFDP_SHARED_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+                        "--no-weak", "--cpu-samples", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 3
+    assert out["exchange_check"]["ok"] and out["overlap"]["efficiency_async"] > 0
+    assert out["config"]["baseline_config"] == "dualgrid.24" and out["config"]["ghost_points_per_gpu"] > 0
+    cb = out["cpu_baseline"]
+    assert cb["value"] > 0 and "whole 64^3 mesh of this config as one domain" in cb["sample"]
