@@ -213,7 +213,6 @@ def _declare_hip(lib: C.CDLL) -> None:
     for n in ("set_var", "set_grad", "set_flux", "get_grad", "get_flux"):
         getattr(lib, "cfdp_gpu_" + n).argtypes = [vp, P(C.c_double)]
     lib.cfdp_gpu_set_variant.argtypes = [vp, C.c_int, C.c_int]
-    lib.cfdp_gpu_set_pipeline.argtypes = [vp, C.c_int]
     lib.cfdp_gpu_gradients.argtypes = [vp, C.c_int, vp]
     lib.cfdp_gpu_flux.argtypes = [vp, C.c_int, vp]
     lib.cfdp_gpu_pack.argtypes = [vp, vp]
@@ -668,8 +667,6 @@ class GpuPartition:
     def set_variant(self, grad_lanes: int, flux_lanes: int = 0) -> None:
         self._ck(self.lib.cfdp_gpu_set_variant(self.h, grad_lanes, flux_lanes))
 
-    def set_pipeline(self, max_wg_per_cu: int) -> None:
-        self._ck(self.lib.cfdp_gpu_set_pipeline(self.h, max_wg_per_cu))
 
     def gradients(self, which: int = TILES_ALL, stream: int = 0) -> None:
         self._ck(self.lib.cfdp_gpu_gradients(self.h, which, C.c_void_p(stream)))

@@ -54,11 +54,9 @@ struct gg_args {
   int nown;
 };
 
-// pipeline: 0 = one workgroup per tile; k > 0 = persistent double-buffered LDS-DMA kernel
-// with at most k workgroups per CU (falls back to 0 when two buffers do not fit in LDS)
 hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int ntiles,
                               int tile_points, size_t lds, int max_halo, int max_blob_qw,
-                              int pipeline, bool nt, hipStream_t stream);
+                              bool nt, hipStream_t stream);
 hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_begin, int ntiles,
                           int tile_points, size_t lds, int max_halo, int max_blob_qw, bool nt,
                           hipStream_t stream);
@@ -87,6 +85,5 @@ hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, hipStream_t stre
 extern int gg_debug_flags;
 hipError_t gg_set_stamp_buffer(unsigned long long *dev);  // diagnostics: phase stamps of the split fused pass
 extern int gg_fused_split;
-hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux);
 
 #endif

@@ -102,13 +102,6 @@ template <bool NT> __device__ __forceinline__ void st_row(double v, double *p) {
 // kernels of a timed run contain none of it -- merely compiled in and switched off it cost 1-2.5 %): thread 0 of
 // every workgroup writes shader-clock stamps of its phase boundaries, 8 per tile, to a buffer of its own
 #define GG_DBG_STAMP 0x20000
-// the timing experiments of CFDP_DEBUG_ABLATE (skip a phase, skip the stores, ...) are compiled in only with
-// -DGG_WITH_ABLATION=1 (tools build such a library under tools/bin/): as run-time branches of the timed kernels they
-// would cost what the switched-off phase stamps did
-#ifndef GG_WITH_ABLATION
-#define GG_WITH_ABLATION 0
-#endif
-#define GG_ABL(dbg, bits) (GG_WITH_ABLATION && ((dbg) & (bits)))
 #ifndef GG_DEEP_BATCH
 #define GG_DEEP_BATCH 7
 #endif
@@ -204,7 +197,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     for (int j = 0; j < NE; j++) vs[j] = var_l[li * 8 + eq0 + j];
     ks = (int)ioff[li];
     ke0 = (int)ioff[li + 1];
-    const int ke = GG_ABL(dbg, 4) ? ks : ke0;  // timing experiment: no arithmetic, stores only
+    const int ke = ke0;
     const double *var_eq0 = var_l + eq0;
     int k = ks;
     if constexpr (NE <= 2)  // few registers per incidence: deeper batches (a point has ~14 incidences)
@@ -288,7 +281,6 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     const size_t p0 = (size_t)(td.pstart + wp + h * SPP);
     double *ga = gradA + p0 * 10, *gb = gradB + p0 * 11;
     const int na = nvh * 10, nd = nvh * 21;
-    if (GG_ABL(dbg, 256)) continue;  // timing experiment: no row stores
     for (int c = lane; c < nd; c += 64) {
       if (c < na) st_row<NT>(slab[c], &ga[c]);
       else st_row<NT>(slab[SPP * 10 + c - na], &gb[c - na]);
@@ -446,13 +438,7 @@ void gg_gradient_dma_kernel(
   grad_tile_compute<LPP, NT>(smem, td, tid, gradA, gradB, stage, dbg, var_off);
 }
 
-// Pipelined form: persistent workgroups walk a contiguous run of tiles with two LDS buffers.
-// While tile i is computed from one buffer, tile i+1 streams into the other by LDS-DMA
-// (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, asynchronous), so the HBM
-// stream never stops for the arithmetic.  The halo row numbers of tile i+2 are fetched one
-// iteration ahead into registers, so the gather of tile i+1 can be issued without waiting.
-constexpr int GG_HMAX = 4;  // halo 16-byte pieces per thread the pipelined kernel can hold
-
+// LDS-DMA: global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs, asynchronous (vmcnt)
 __device__ __forceinline__ void glds16(const uint4 *src, unsigned char *lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                    (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
@@ -470,98 +456,6 @@ __device__ __forceinline__ void glds16_sys(const uint4 *src, unsigned char *lds_
 __device__ __forceinline__ void glds16_nt(const uint4 *src, unsigned char *lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                    (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 2);
-}
-
-template <bool NT>
-__device__ __forceinline__ void pipe_issue_tile(unsigned char *buf, const cfdp_tile_desc &td,
-                                                const uint4 *__restrict__ blob,
-                                                const uint4 *__restrict__ gv4, const int (&hrow)[GG_HMAX],
-                                                int tid, int nthr) {
-  const int lane = tid & 63, w0 = tid & ~63;  // first thread of this wave
-  // region 1: the tile blob; region 2: own var rows -- both contiguous in HBM
-  const uint4 *b4 = blob + td.blob_off;
-  for (int q0 = w0; q0 < td.blob_qw; q0 += nthr)
-    if (q0 + lane < td.blob_qw) {
-      if constexpr (NT) glds16_nt(b4 + q0 + lane, buf + (size_t)q0 * 16);
-      else glds16(b4 + q0 + lane, buf + (size_t)q0 * 16);
-    }
-  unsigned char *vbuf = buf + (size_t)td.blob_qw * 16;
-  const uint4 *own = gv4 + (size_t)td.pstart * 4;
-  const int nown4 = td.npts * 4, nhalo4 = td.nhalo * 4;
-  for (int q0 = w0; q0 < nown4; q0 += nthr)
-    if (q0 + lane < nown4) glds16(own + q0 + lane, vbuf + (size_t)q0 * 16);
-  // region 3: halo var rows, gathered by row number (4 lanes per 64-byte row)
-  unsigned char *hbuf = vbuf + (size_t)nown4 * 16;
-#pragma unroll
-  for (int k = 0; k < GG_HMAX; k++) {
-    const int q0 = w0 + k * nthr;
-    if (q0 < nhalo4 && q0 + lane < nhalo4)
-      glds16(gv4 + (size_t)hrow[k] * 4 + (lane & 3), hbuf + (size_t)q0 * 16);
-  }
-}
-
-__device__ __forceinline__ void pipe_load_hrows(int (&hrow)[GG_HMAX], const cfdp_tile_desc &td,
-                                                const int *__restrict__ halo_idx, int tid, int nthr) {
-  const int *hid = halo_idx + td.halo_off;
-#pragma unroll
-  for (int k = 0; k < GG_HMAX; k++) {
-    const int q = tid + k * nthr;
-    hrow[k] = q < td.nhalo * 4 ? hid[q >> 2] : 0;
-  }
-}
-
-template <int LPP, bool NT>
-__global__ __launch_bounds__(1024) void gg_gradient_pipe_kernel(
-    const cfdp_tile_desc *__restrict__ tiles, int tile_begin, int ntiles,
-    const uint4 *__restrict__ blob, const int *__restrict__ halo_idx,
-    const double *__restrict__ var /*[nall][8]*/, double *__restrict__ gradA /*[nown][10]*/,
-    double *__restrict__ gradB /*[nown][11]*/, int buf_bytes, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
-
-  // Workgroups b, b+8, ... share an XCD (round-robin dispatch) and together own one contiguous
-  // chunk of the tile sequence; inside the chunk they take tiles round-robin (stride = the
-  // XCD's workgroup count), so at any moment the XCD works on ~nwx CONSECUTIVE tiles -- spatial
-  // neighbours (host/tiling.c orders tiles supertile by supertile) whose var rows, gathered as
-  // halo rows by each other, meet in that XCD's 4 MiB L2.  Placement is speed only.
-  const int b = blockIdx.x, nwg = gridDim.x, x = b & 7, j = b >> 3;
-  const int nwx = (nwg - x + 7) >> 3;  // workgroups on this XCD
-  const int xt0 = (int)((long)ntiles * x / 8), xt1 = (int)((long)ntiles * (x + 1) / 8);
-  int t = tile_begin + xt0 + j;
-  const int tend = tile_begin + xt1;
-  const int tstep = nwx;
-  if (t >= tend) return;
-
-  int hrow[GG_HMAX];
-  cfdp_tile_desc td = tiles[t];
-  pipe_load_hrows(hrow, td, halo_idx, tid, nthr);
-  pipe_issue_tile<NT>(smem, td, blob, gv4, hrow, tid, nthr);
-  cfdp_tile_desc tn = td;
-  if (t + tstep < tend) {
-    tn = tiles[t + tstep];
-    pipe_load_hrows(hrow, tn, halo_idx, tid, nthr);
-  }
-  __syncthreads();  // drains this wave's DMA (vmcnt(0)) and publishes everybody's
-  int cur = 0;
-  const cfdp_tile_desc td0 = td;
-  double *stage = reinterpret_cast<double *>(smem + 2 * (size_t)buf_bytes);
-  for (; t < tend; t += tstep) {
-    unsigned char *bcur = smem + (size_t)cur * buf_bytes;
-    unsigned char *bnxt = smem + (size_t)(cur ^ 1) * buf_bytes;
-    if (t + tstep < tend && !GG_ABL(dbg, 2)) pipe_issue_tile<NT>(bnxt, tn, blob, gv4, hrow, tid, nthr);
-    cfdp_tile_desc tnn = tn;
-    if (t + 2 * tstep < tend) {
-      tnn = tiles[t + 2 * tstep];
-      pipe_load_hrows(hrow, tnn, halo_idx, tid, nthr);  // used one iteration from now
-    }
-    if (GG_ABL(dbg, 2)) grad_tile_compute<LPP, NT>(smem, td0, tid, gradA, gradB, stage, dbg);  // timing experiment: buffer 0 only
-    else if (!GG_ABL(dbg, 1)) grad_tile_compute<LPP, NT>(bcur, td, tid, gradA, gradB, stage, dbg);
-    __syncthreads();  // (a) everyone is done reading bcur, (b) tile t+1 has landed in bnxt
-    td = tn;
-    tn = tnn;
-    cur ^= 1;
-  }
 }
 
 // ---------------------------------------------------------------------------------- flux
@@ -845,9 +739,7 @@ void gg_fused_dma_kernel(
                  gbuf + (size_t)(w0 + k * nthr) * 16);
   }
   __syncthreads();
-  if (!GG_ABL(dbg, 128))  // timing experiment: no flux phase
-    flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
-  if (GG_ABL(dbg, 512)) return;  // timing experiment: no gradient phase
+  flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(gbuf), dbg,
                                    CB * nthr * 16, &pa, t);
   push_tile_done(pa, t, tid);
@@ -884,15 +776,13 @@ __device__ __forceinline__ void gg_stamp_wave(int dbg, int ntiles, int tile, int
 }
 
 // Phase-split form of the fused pass: ONE row region of LDS holds the gradient rows during the flux
-// phase and the var rows during the gradient phase (the var rows are gathered after the flux phase,
-// their row numbers were fetched at the start), so a tile occupies CB + KX pieces per thread instead
-// of CB + KV + KG: 36 KiB instead of 48 KiB for 64-point tiles = FOUR workgroups per CU.  The price is
-// a second, exposed gather round trip per tile.
+// phase and the var rows during the gradient phase, so a tile occupies CB + KX pieces per thread instead
+// of CB + KV + KG: 36 KiB instead of 48 KiB for 64-point tiles = FOUR workgroups per CU.  The var rows
+// are requested together with the gradient rows, into registers, and wait out the flux phase there.
 // LISTED: the fixed-stride row lists exist (gg_args::rowlist); PUSH: an exchange rides in the pass (the boundary
 // tiles wait for the previous exchange, push their rows, notify) -- both compile-time, so the pass that runs one
 // partition on one GPU carries neither the other path's code nor its registers
-template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, bool EARLY = true, bool STAMP = false, bool LISTED = true,
-          bool PUSH = true>
+template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, bool STAMP = false, bool LISTED = true, bool PUSH = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
@@ -985,13 +875,11 @@ void gg_fused_split_kernel(
   const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   u32x4 vr[KV];
-  if constexpr (EARLY) {
 #pragma unroll
-    for (int k = 0; k < KV; k++) {
-      const int q = tid + k * nthr, r = q >> 2;
-      const int row = !listed && r < td.npts ? td.pstart + r : hv[k];
-      vr[k] = *reinterpret_cast<const u32x4 *>(gv4 + (size_t)row * 4 + (q & 3));
-    }
+  for (int k = 0; k < KV; k++) {
+    const int q = tid + k * nthr, r = q >> 2;
+    const int row = !listed && r < td.npts ? td.pstart + r : hv[k];
+    vr[k] = *reinterpret_cast<const u32x4 *>(gv4 + (size_t)row * 4 + (q & 3));
   }
   if constexpr (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -999,22 +887,12 @@ void gg_fused_split_kernel(
   }
   __syncthreads();
   if constexpr (STAMP) gg_stamp(dbg, t, 2);  // blob + gradient rows (+ var rows in registers) have landed
-  if (!GG_ABL(dbg, 128))  // timing experiment: no flux phase
-    flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
+  flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 1);  // this wave is through its flux phase
   __syncthreads();  // every wave is done with the gradient rows: the region takes the var rows
   if constexpr (STAMP) gg_stamp(dbg, t, 3);  // flux phase done
-  if constexpr (EARLY) {
 #pragma unroll
-    for (int k = 0; k < KV; k++) *reinterpret_cast<u32x4 *>(xbuf + (size_t)(tid + k * nthr) * 16) = vr[k];
-  } else {
-#pragma unroll
-    for (int k = 0; k < KV; k++) {
-      const int q = tid + k * nthr, r = q >> 2;
-      const int row = !listed && r < td.npts ? td.pstart + r : hv[k];
-      glds16(gv4 + (size_t)row * 4 + (q & 3), xbuf + (size_t)(w0 + k * nthr) * 16);
-    }
-  }
+  for (int k = 0; k < KV; k++) *reinterpret_cast<u32x4 *>(xbuf + (size_t)(tid + k * nthr) * 16) = vr[k];
   __syncthreads();  // vmcnt(0) + barrier
   if constexpr (STAMP) gg_stamp(dbg, t, 4);  // var rows in place
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
@@ -1099,165 +977,157 @@ hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, hipStream_t stre
 }
 
 // ------------------------------------------------------------------------------ launchers
+// Kernel forms that are instantiated (everything else was measured, lost and removed -- DESIGN.md appendix):
+//   gradient  gg_gradient_dma_kernel<4, NT, CB, KV>   fixed-count LDS-DMA staging, 4 lanes per point (default)
+//             gg_gradient_kernel<LPP, NT>             register-staged, any tile shape, LPP in {1,2,4,8} (fallback)
+//   flux      gg_flux_dma_kernel<8, REF, NT, CB, KV>  fixed-count LDS-DMA staging, 8 lanes per point (default)
+//             gg_flux_kernel<LPP, REF, NT>            register-staged, any tile shape (fallback)
+//   fused     gg_fused_split_kernel<REF, NT, 5,4,4,4> one shared row region, 4 workgroups per CU (default)
+//             gg_fused_dma_kernel<REF, NT, CB,KV,KG>  everything staged up front (beside an RCCL kernel; larger tiles)
 hipError_t gg_set_stamp_buffer(unsigned long long *dev) {
   return hipMemcpyToSymbol(HIP_SYMBOL(gg_stamp_buf), &dev, sizeof dev);
 }
 int gg_fused_split = 1;  // fused pass: prefer the phase-split form (one shared row region, 4 workgroups per CU)
-int gg_debug_flags = 0;  // timing experiments only: 1 = skip arithmetic, 2 = skip tile streaming
+int gg_debug_flags = 0;  // 16: register-staged kernels only; 64: per-lane row stores; GG_DBG_STAMP: phase stamps
 
-#define LAUNCH_GRAD(L, N)                                                                         \
-  hipLaunchKernelGGL((gg_gradient_kernel<L, N>), dim3(ntiles), dim3(block), lds + stage_bytes,   \
-                     stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b)
-#define LAUNCH_GRAD_PIPE(L, N)                                                                    \
-  hipLaunchKernelGGL((gg_gradient_pipe_kernel<L, N>), dim3(nwg), dim3(block),                     \
-                     2 * buf + stage_bytes, stream,                                            \
-                     a.tiles, tile_begin, ntiles, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b, (int)buf, gg_debug_flags)
+namespace {
 
-hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int ntiles,
-                              int tile_points, size_t lds, int max_halo, int max_blob_qw,
-                              int pipeline, bool nt, hipStream_t stream) {
-  if (ntiles <= 0) return hipSuccess;
-  const int block = ((tile_points * lanes + 63) / 64) * 64;
-  if (block > 1024) return hipErrorInvalidConfiguration;
-  const size_t buf = (lds + 15) & ~(size_t)15;
-  lds = buf;
-  const size_t stage_bytes = (gg_debug_flags & 64) ? 0 : (size_t)(block / 64) * 8 * 21 * 8;  // 8 rows of 168 bytes per wave
-  if (pipeline && 2 * buf + stage_bytes <= 160 * 1024 && (long)max_halo * 4 <= (long)GG_HMAX * block) {
-    // persistent grid: as many workgroups per CU as LDS (two buffers each) and waves allow
-    int per_cu = (int)((160 * 1024) / (2 * buf + stage_bytes));
-    const int by_waves = 2048 / block;
-    if (per_cu > by_waves) per_cu = by_waves;
-    if (per_cu > pipeline) per_cu = pipeline;
-    if (per_cu < 1) per_cu = 1;
-    int nwg = 256 * per_cu;
-    if (nwg > ntiles) nwg = ntiles;
-    switch (lanes) {
-      case 1: if (nt) LAUNCH_GRAD_PIPE(1, true); else LAUNCH_GRAD_PIPE(1, false); break;
-      case 2: if (nt) LAUNCH_GRAD_PIPE(2, true); else LAUNCH_GRAD_PIPE(2, false); break;
-      case 4: if (nt) LAUNCH_GRAD_PIPE(4, true); else LAUNCH_GRAD_PIPE(4, false); break;
-      case 8: if (nt) LAUNCH_GRAD_PIPE(8, true); else LAUNCH_GRAD_PIPE(8, false); break;
-      default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
+constexpr size_t LDS_MAX = 160 * 1024;
+
+// raise the dynamic-LDS limit of a kernel to the full 160 KiB, once per kernel and device
+template <typename K> hipError_t allow_lds(K *kernel) {
+  static bool done[64] = {false};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+  if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+  return e;
+}
+
+template <typename K, typename... A>
+hipError_t launch(K *kernel, int grid, int block, size_t lds, hipStream_t stream, A... args) {
+  if (lds > LDS_MAX) return hipErrorInvalidConfiguration;
+  if (lds > 64 * 1024) {
+    const hipError_t e = allow_lds(kernel);
+    if (e != hipSuccess) return e;
   }
-  // one workgroup per tile.  Preferred: fixed-count LDS-DMA staging (8 lanes per point), when
-  // the tile sizes of this launch fit one of the instantiated (CB, KV) capacities
-  if (lanes == 8 && !(gg_debug_flags & 16)) {
-    const int cb = (max_blob_qw + block - 1) / block;                       // blob pieces per wave
-    const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;      // var-row pieces per wave
-#define LAUNCH_GRAD_DMA_L(L, CB, KV)                                                              \
-  do {                                                                                            \
-    const size_t dma_lds = (size_t)((CB) + (KV)) * block * 16 + stage_bytes;                      \
-    if (dma_lds > 160 * 1024) break;                                                              \
-    if (nt) hipLaunchKernelGGL((gg_gradient_dma_kernel<L, true, CB, KV>), dim3(ntiles), dim3(block),  \
-                               dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b, gg_debug_flags); \
-    else hipLaunchKernelGGL((gg_gradient_dma_kernel<L, false, CB, KV>), dim3(ntiles), dim3(block),    \
-                            dma_lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b, gg_debug_flags); \
-    return hipGetLastError();                                                                     \
-  } while (0)
-#define LAUNCH_GRAD_DMA(CB, KV) LAUNCH_GRAD_DMA_L(8, CB, KV)
-    if (cb >= 1 && kv >= 1 && kv <= 2) {
-      if (cb <= 2) LAUNCH_GRAD_DMA(2, 2);
-      if (cb <= 3) LAUNCH_GRAD_DMA(3, 2);
-      if (cb <= 4) LAUNCH_GRAD_DMA(4, 2);
-      if (cb <= 6) LAUNCH_GRAD_DMA(6, 2);
-    } else if (cb >= 1 && kv == 3) {
-      if (cb <= 3) LAUNCH_GRAD_DMA(3, 3);
-      if (cb <= 4) LAUNCH_GRAD_DMA(4, 3);
-      if (cb <= 6) LAUNCH_GRAD_DMA(6, 3);
-    }
-#undef LAUNCH_GRAD_DMA
-  }
-  if (lanes == 4 && !(gg_debug_flags & 16)) {  // two equations per lane: half the LDS reads per point
-    const int cb = (max_blob_qw + block - 1) / block;
-    const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;
-    if (cb >= 1 && cb <= 5 && kv >= 1 && kv <= 3) LAUNCH_GRAD_DMA_L(4, 5, 3);
-    if (cb >= 1 && cb <= 5 && kv >= 1 && kv <= 4) LAUNCH_GRAD_DMA_L(4, 5, 4);
-    if (cb >= 1 && cb <= 6 && kv >= 1 && kv <= 5) LAUNCH_GRAD_DMA_L(4, 6, 5);
-    if (cb >= 1 && cb <= 8 && kv >= 1 && kv <= 6) LAUNCH_GRAD_DMA_L(4, 8, 6);
-  }
-  if (lanes == 2 && !(gg_debug_flags & 16)) {  // four equations per lane
-    const int cb = (max_blob_qw + block - 1) / block;
-    const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;
-    if (cb >= 1 && cb <= 10 && kv >= 1 && kv <= 6) LAUNCH_GRAD_DMA_L(2, 10, 6);
-    if (cb >= 1 && cb <= 10 && kv >= 1 && kv <= 8) LAUNCH_GRAD_DMA_L(2, 10, 8);
-    if (cb >= 1 && cb <= 12 && kv >= 1 && kv <= 8) LAUNCH_GRAD_DMA_L(2, 12, 8);
-    if (cb >= 1 && cb <= 16 && kv >= 1 && kv <= 12) LAUNCH_GRAD_DMA_L(2, 16, 12);
-  }
-#undef LAUNCH_GRAD_DMA_L
-  switch (lanes) {
-    case 1: if (nt) LAUNCH_GRAD(1, true); else LAUNCH_GRAD(1, false); break;
-    case 2: if (nt) LAUNCH_GRAD(2, true); else LAUNCH_GRAD(2, false); break;
-    case 4: if (nt) LAUNCH_GRAD(4, true); else LAUNCH_GRAD(4, false); break;
-    case 8: if (nt) LAUNCH_GRAD(8, true); else LAUNCH_GRAD(8, false); break;
-    default: return hipErrorInvalidValue;
-  }
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, args...);
   return hipGetLastError();
 }
 
-#define LAUNCH_FLUX(L, R, N)                                                                      \
-  hipLaunchKernelGGL((gg_flux_kernel<L, R, N>), dim3(ntiles), dim3(block), lds, stream, a.tiles,    \
-                     tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown)
+template <int L> hipError_t launch_grad_generic(const gg_args &a, bool nt, int tile_begin, int ntiles, int block, size_t lds,
+                                                hipStream_t stream) {
+  if (nt) return launch(gg_gradient_kernel<L, true>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b);
+  return launch(gg_gradient_kernel<L, false>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b);
+}
 
-hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_begin, int ntiles,
-                          int tile_points, size_t lds, int max_halo, int max_blob_qw, bool nt,
-                          hipStream_t stream) {
+template <int CB, int KV> hipError_t launch_grad_dma(const gg_args &a, bool nt, int tile_begin, int ntiles, int block,
+                                                     size_t stage_bytes, hipStream_t stream) {
+  const size_t lds = (size_t)(CB + KV) * block * 16 + stage_bytes;
+  if (nt) return launch(gg_gradient_dma_kernel<4, true, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b, gg_debug_flags);
+  return launch(gg_gradient_dma_kernel<4, false, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b, gg_debug_flags);
+}
+
+template <int L, bool R> hipError_t launch_flux_generic(const gg_args &a, bool nt, int tile_begin, int ntiles, int block, size_t lds,
+                                                        hipStream_t stream) {
+  if (nt) return launch(gg_flux_kernel<L, R, true>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown);
+  return launch(gg_flux_kernel<L, R, false>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown);
+}
+
+template <bool R, int CB, int KV> hipError_t launch_flux_dma(const gg_args &a, bool nt, int tile_begin, int ntiles, int block,
+                                                             hipStream_t stream) {
+  const size_t lds = (size_t)(CB + KV) * block * 16;
+  if (nt) return launch(gg_flux_dma_kernel<8, R, true, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown);
+  return launch(gg_flux_dma_kernel<8, R, false, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown);
+}
+
+template <bool R, bool N, bool S, bool L, bool P>
+hipError_t launch_split(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
+                        int dbgf, const gg_push_args &pa) {
+  return launch(gg_fused_split_kernel<R, N, 5, 4, 4, 4, S, L, P>, ntiles, block, (size_t)(5 + 4) * block * 16, stream, a.tiles, tile_begin,
+                a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa);
+}
+template <bool R, bool N>
+hipError_t launch_split_lp(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
+                           int dbgf, const gg_push_args &pa) {
+  const bool listed = a.rowlist != nullptr, pushing = pa.tile_off != nullptr;
+  if (listed) return pushing ? launch_split<R, N, false, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                             : launch_split<R, N, false, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
+  return pushing ? launch_split<R, N, false, false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                 : launch_split<R, N, false, false, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
+}
+
+template <int CB, int KV, int KG>
+hipError_t launch_fused_upfront(const gg_args &a, const gg_grad_view &gnew, bool refmode, bool nt, int tile_begin, int ntiles, int block,
+                                hipStream_t stream, int dbgf, const gg_push_args &pa) {
+  const size_t lds = (size_t)(CB + KV + KG) * block * 16;
+#define FUSED_ARGS ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa
+  if (refmode) return nt ? launch(gg_fused_dma_kernel<true, true, CB, KV, KG>, FUSED_ARGS) : launch(gg_fused_dma_kernel<true, false, CB, KV, KG>, FUSED_ARGS);
+  return nt ? launch(gg_fused_dma_kernel<false, true, CB, KV, KG>, FUSED_ARGS) : launch(gg_fused_dma_kernel<false, false, CB, KV, KG>, FUSED_ARGS);
+#undef FUSED_ARGS
+}
+
+}  // namespace
+
+hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int ntiles, int tile_points, size_t lds,
+                              int max_halo, int max_blob_qw, bool nt, hipStream_t stream) {
+  if (ntiles <= 0) return hipSuccess;
+  const int block = ((tile_points * lanes + 63) / 64) * 64;
+  if (block > 1024) return hipErrorInvalidConfiguration;
+  lds = (lds + 15) & ~(size_t)15;
+  const size_t stage_bytes = (gg_debug_flags & 64) ? 0 : (size_t)(block / 64) * 8 * 21 * 8;  // 8 rows of 168 bytes per wave
+  if (lanes == 4 && !(gg_debug_flags & 16)) {  // fixed-count LDS-DMA staging; two equations per lane
+    const int cb = (max_blob_qw + block - 1) / block;                    // blob pieces per thread
+    const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;  // var-row pieces per thread
+    if (cb >= 1 && kv >= 1) {
+      if (cb <= 5 && kv <= 3) return launch_grad_dma<5, 3>(a, nt, tile_begin, ntiles, block, stage_bytes, stream);
+      if (cb <= 5 && kv <= 4) return launch_grad_dma<5, 4>(a, nt, tile_begin, ntiles, block, stage_bytes, stream);
+      if (cb <= 6 && kv <= 5) return launch_grad_dma<6, 5>(a, nt, tile_begin, ntiles, block, stage_bytes, stream);
+      if (cb <= 8 && kv <= 6 && (size_t)(8 + 6) * block * 16 + stage_bytes <= LDS_MAX)
+        return launch_grad_dma<8, 6>(a, nt, tile_begin, ntiles, block, stage_bytes, stream);
+    }
+  }
+  switch (lanes) {
+    case 1: return launch_grad_generic<1>(a, nt, tile_begin, ntiles, block, lds + stage_bytes, stream);
+    case 2: return launch_grad_generic<2>(a, nt, tile_begin, ntiles, block, lds + stage_bytes, stream);
+    case 4: return launch_grad_generic<4>(a, nt, tile_begin, ntiles, block, lds + stage_bytes, stream);
+    case 8: return launch_grad_generic<8>(a, nt, tile_begin, ntiles, block, lds + stage_bytes, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_begin, int ntiles, int tile_points, size_t lds,
+                          int max_halo, int max_blob_qw, bool nt, hipStream_t stream) {
   if (ntiles <= 0) return hipSuccess;
   const int block = ((tile_points * lanes + 63) / 64) * 64;
   if (block > 1024) return hipErrorInvalidConfiguration;
   if (lanes == 8 && !(gg_debug_flags & 16)) {  // fixed-count LDS-DMA staging
     const int cb = (max_blob_qw + block - 1) / block;
     const int kv = ((tile_points + max_halo) * 5 + block - 1) / block;
-#define LAUNCH_FLUX_DMA(CB, KV)                                                                   \
-  do {                                                                                            \
-    const size_t dma_lds = (size_t)((CB) + (KV)) * block * 16;                                    \
-    if (dma_lds > 160 * 1024) break;                                                              \
-    if (refmode) {                                                                                \
-      if (nt) hipLaunchKernelGGL((gg_flux_dma_kernel<8, true, true, CB, KV>), dim3(ntiles), dim3(block), dma_lds, \
-                                 stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown); \
-      else hipLaunchKernelGGL((gg_flux_dma_kernel<8, true, false, CB, KV>), dim3(ntiles), dim3(block), dma_lds, \
-                              stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown); \
-    } else {                                                                                      \
-      if (nt) hipLaunchKernelGGL((gg_flux_dma_kernel<8, false, true, CB, KV>), dim3(ntiles), dim3(block), dma_lds, \
-                                 stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown); \
-      else hipLaunchKernelGGL((gg_flux_dma_kernel<8, false, false, CB, KV>), dim3(ntiles), dim3(block), dma_lds, \
-                              stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown); \
-    }                                                                                             \
-    return hipGetLastError();                                                                     \
-  } while (0)
-    if (cb >= 1 && kv >= 1 && kv <= 2) {
-      if (cb <= 2) LAUNCH_FLUX_DMA(2, 2);
-      if (cb <= 3) LAUNCH_FLUX_DMA(3, 2);
-      if (cb <= 4) LAUNCH_FLUX_DMA(4, 2);
-      if (cb <= 6) LAUNCH_FLUX_DMA(6, 2);
-    } else if (cb >= 1 && kv == 3) {
-      if (cb <= 3) LAUNCH_FLUX_DMA(3, 3);
-      if (cb <= 4) LAUNCH_FLUX_DMA(4, 3);
-      if (cb <= 6) LAUNCH_FLUX_DMA(6, 3);
-    } else if (cb >= 1 && kv == 4) {
-      if (cb <= 3) LAUNCH_FLUX_DMA(3, 4);
-      if (cb <= 6) LAUNCH_FLUX_DMA(6, 4);
+#define FLUX_DMA(CB, KV)                                                                                 \
+  if (cb <= CB && kv <= KV && (size_t)(CB + KV) * block * 16 <= LDS_MAX)                                   \
+    return refmode ? launch_flux_dma<true, CB, KV>(a, nt, tile_begin, ntiles, block, stream)               \
+                   : launch_flux_dma<false, CB, KV>(a, nt, tile_begin, ntiles, block, stream)
+    if (cb >= 1 && kv >= 1) {
+      FLUX_DMA(3, 2);
+      FLUX_DMA(4, 3);
+      FLUX_DMA(6, 4);
     }
-#undef LAUNCH_FLUX_DMA
+#undef FLUX_DMA
   }
-  if (refmode) {
-    switch (lanes) {
-      case 1: if (nt) LAUNCH_FLUX(1, true, true); else LAUNCH_FLUX(1, true, false); break;
-      case 2: if (nt) LAUNCH_FLUX(2, true, true); else LAUNCH_FLUX(2, true, false); break;
-      case 4: if (nt) LAUNCH_FLUX(4, true, true); else LAUNCH_FLUX(4, true, false); break;
-      case 8: if (nt) LAUNCH_FLUX(8, true, true); else LAUNCH_FLUX(8, true, false); break;
-      default: return hipErrorInvalidValue;
-    }
-  } else {
-    switch (lanes) {
-      case 1: if (nt) LAUNCH_FLUX(1, false, true); else LAUNCH_FLUX(1, false, false); break;
-      case 2: if (nt) LAUNCH_FLUX(2, false, true); else LAUNCH_FLUX(2, false, false); break;
-      case 4: if (nt) LAUNCH_FLUX(4, false, true); else LAUNCH_FLUX(4, false, false); break;
-      case 8: if (nt) LAUNCH_FLUX(8, false, true); else LAUNCH_FLUX(8, false, false); break;
-      default: return hipErrorInvalidValue;
-    }
+#define FLUX_GENERIC(L) \
+  return refmode ? launch_flux_generic<L, true>(a, nt, tile_begin, ntiles, block, lds, stream) \
+                 : launch_flux_generic<L, false>(a, nt, tile_begin, ntiles, block, lds, stream)
+  switch (lanes) {
+    case 1: FLUX_GENERIC(1);
+    case 2: FLUX_GENERIC(2);
+    case 4: FLUX_GENERIC(4);
+    case 8: FLUX_GENERIC(8);
+    default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
+#undef FLUX_GENERIC
 }
 
 // flux(i) from `a.grad`, gradients(i+1) into `gnew`.  hipErrorNotSupported: no instantiated
@@ -1269,7 +1139,7 @@ bool gg_fused_fits(int tile_points, int max_halo, int max_blob_qw) {
   const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;
   const int kg = ((tile_points + max_halo) * 5 + block - 1) / block;
   return cb >= 1 && kv >= 1 && kg >= 1 && cb <= 8 && kv <= 6 && kg <= 8 &&
-         (size_t)(8 + 6 + 8) * block * 16 <= 160 * 1024;  // the largest instantiated capacity
+         (size_t)(8 + 6 + 8) * block * 16 <= LDS_MAX;  // the largest instantiated capacity
 }
 
 hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refmode, int tile_begin,
@@ -1287,52 +1157,25 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
   const int kg = ((tile_points + max_halo) * 5 + block - 1) / block;
   if (cb < 1 || kv < 1 || kg < 1) return hipErrorNotSupported;
   if (gg_fused_split && allow_split && cb <= 5 && kv <= 4 && kg <= 4) {
-    const size_t split_lds = (size_t)(5 + 4) * block * 16;
-    const bool listed = a.rowlist != nullptr, pushing = pa.tile_off != nullptr;
-#define LAUNCH_SPLIT_X(R, N, E, S, L, P)                                                                            \
-  hipLaunchKernelGGL((gg_fused_split_kernel<R, N, 5, 4, 4, 4, E, S, L, P>), dim3(ntiles), dim3(block), split_lds, stream, \
-                     a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, \
-                     gnew.a, gnew.b, dbgf, pa)
-#define LAUNCH_SPLIT_LP(R, N, E, S)                                                     \
-  do {                                                                                  \
-    if (listed) { if (pushing) LAUNCH_SPLIT_X(R, N, E, S, true, true); else LAUNCH_SPLIT_X(R, N, E, S, true, false); } \
-    else { if (pushing) LAUNCH_SPLIT_X(R, N, E, S, false, true); else LAUNCH_SPLIT_X(R, N, E, S, false, false); }      \
-  } while (0)
     if (gg_debug_flags & GG_DBG_STAMP) {  // diagnostic build of the same kernel: phase stamps (tools/phase_stamps.py)
-      if (nt) LAUNCH_SPLIT_X(false, true, true, true, true, true); else LAUNCH_SPLIT_X(false, false, true, true, true, true);
-      return hipGetLastError();
+      if (!a.rowlist) return hipErrorNotSupported;  // the stamped instantiation reads the fixed-stride row lists
+      return nt ? launch_split<false, true, true, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                : launch_split<false, false, true, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     }
-#if GG_WITH_ABLATION
-    if (gg_debug_flags & 1024) {  // timing experiment: the var rows gathered after the flux phase
-      LAUNCH_SPLIT_X(false, false, false, false, true, true);
-      return hipGetLastError();
-    }
-#endif
-    if (refmode) { if (nt) LAUNCH_SPLIT_LP(true, true, true, false); else LAUNCH_SPLIT_LP(true, false, true, false); }
-    else { if (nt) LAUNCH_SPLIT_LP(false, true, true, false); else LAUNCH_SPLIT_LP(false, false, true, false); }
-#undef LAUNCH_SPLIT_LP
-#undef LAUNCH_SPLIT_X
-    return hipGetLastError();
+    if (refmode) return nt ? launch_split_lp<true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                           : launch_split_lp<true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
+    return nt ? launch_split_lp<false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+              : launch_split_lp<false, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
   }
-#define LAUNCH_FUSED_RN(R, N, CB, KV, KG)                                                         \
-  hipLaunchKernelGGL((gg_fused_dma_kernel<R, N, CB, KV, KG>), dim3(ntiles), dim3(block), fused_lds, \
-                     stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, \
-                     a.flux, a.nown, gnew.a, gnew.b, dbgf, pa)
-#define LAUNCH_FUSED(CB, KV, KG)                                                                  \
-  do {                                                                                            \
-    const size_t fused_lds = (size_t)((CB) + (KV) + (KG)) * block * 16;                           \
-    if (fused_lds > 160 * 1024 || (size_t)(block / 64) * 8 * 21 * 8 > (size_t)(KG) * block * 16) break; \
-    if (refmode) { if (nt) LAUNCH_FUSED_RN(true, true, CB, KV, KG); else LAUNCH_FUSED_RN(true, false, CB, KV, KG); } \
-    else { if (nt) LAUNCH_FUSED_RN(false, true, CB, KV, KG); else LAUNCH_FUSED_RN(false, false, CB, KV, KG); } \
-    return hipGetLastError();                                                                     \
-  } while (0)
-  if (cb <= 5 && kv <= 3 && kg <= 4) LAUNCH_FUSED(5, 3, 4);
-  if (cb <= 5 && kv <= 4 && kg <= 4) LAUNCH_FUSED(5, 4, 4);  // 52 KiB: still three workgroups per CU
-  if (cb <= 5 && kv <= 4 && kg <= 5) LAUNCH_FUSED(5, 4, 5);
-  if (cb <= 6 && kv <= 5 && kg <= 6) LAUNCH_FUSED(6, 5, 6);
-  if (cb <= 8 && kv <= 6 && kg <= 8) LAUNCH_FUSED(8, 6, 8);
-#undef LAUNCH_FUSED
-#undef LAUNCH_FUSED_RN
+  // everything staged up front; the store slab (8 rows of 168 bytes per wave) must fit the gradient-row region
+  const size_t slab = (size_t)(block / 64) * 8 * 21 * 8;
+#define FUSED_UPFRONT(CB, KV, KG)                                                                                   \
+  if (cb <= CB && kv <= KV && kg <= KG && (size_t)(CB + KV + KG) * block * 16 <= LDS_MAX && slab <= (size_t)(KG) * block * 16) \
+    return launch_fused_upfront<CB, KV, KG>(a, gnew, refmode, nt, tile_begin, ntiles, block, stream, dbgf, pa)
+  FUSED_UPFRONT(5, 3, 4);
+  FUSED_UPFRONT(5, 4, 5);  // 56 KiB at 64-point tiles: two workgroups per CU
+  FUSED_UPFRONT(8, 6, 8);
+#undef FUSED_UPFRONT
   return hipErrorNotSupported;
 }
 
@@ -1354,147 +1197,4 @@ hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(gg_unpack_kernel, dim3(blocks), dim3(256), 0, stream, recvbuf, nrecv, grad.ghost);
   return hipGetLastError();
-}
-
-hipError_t gg_set_max_lds(size_t lds_grad, size_t lds_flux) {
-  // raise the dynamic-LDS limit of every kernel to the full 160 KiB once per device (the
-  // launchers check the per-launch size); ~100 attribute calls are too slow to repeat per plan
-  (void)lds_grad; (void)lds_flux;
-  static bool done[64] = {false};
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
-#define SET_LDS(K, B)                                                                          \
-  if (e == hipSuccess && (B) > 65536 && (B) <= 163840)                                                        \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&K),                                \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(B));
-  const size_t all = 160 * 1024;  // per-launch sizes are checked by the launchers
-  SET_LDS((gg_gradient_kernel<1, false>), all)
-  SET_LDS((gg_gradient_kernel<1, true>), all)
-  SET_LDS((gg_gradient_kernel<2, false>), all)
-  SET_LDS((gg_gradient_kernel<2, true>), all)
-  SET_LDS((gg_gradient_kernel<4, false>), all)
-  SET_LDS((gg_gradient_kernel<4, true>), all)
-  SET_LDS((gg_gradient_kernel<8, false>), all)
-  SET_LDS((gg_gradient_kernel<8, true>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, false, 2, 2>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, true, 2, 2>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, false, 3, 2>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, true, 3, 2>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, false, 4, 2>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, true, 4, 2>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, false, 6, 2>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, true, 6, 2>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, false, 3, 3>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, true, 3, 3>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, false, 4, 3>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, true, 4, 3>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, false, 6, 3>), all)
-  SET_LDS((gg_gradient_dma_kernel<8, true, 6, 3>), all)
-  SET_LDS((gg_gradient_dma_kernel<4, false, 5, 3>), all)
-  SET_LDS((gg_gradient_dma_kernel<4, true, 5, 3>), all)
-  SET_LDS((gg_gradient_dma_kernel<2, false, 10, 6>), all)
-  SET_LDS((gg_gradient_dma_kernel<2, true, 10, 6>), all)
-  SET_LDS((gg_gradient_dma_kernel<2, false, 10, 8>), all)
-  SET_LDS((gg_gradient_dma_kernel<2, true, 10, 8>), all)
-  SET_LDS((gg_gradient_dma_kernel<2, false, 12, 8>), all)
-  SET_LDS((gg_gradient_dma_kernel<2, true, 12, 8>), all)
-  SET_LDS((gg_gradient_dma_kernel<2, false, 16, 12>), all)
-  SET_LDS((gg_gradient_dma_kernel<2, true, 16, 12>), all)
-  SET_LDS((gg_gradient_dma_kernel<4, false, 5, 4>), all)
-  SET_LDS((gg_gradient_dma_kernel<4, true, 5, 4>), all)
-  SET_LDS((gg_gradient_dma_kernel<4, false, 6, 5>), all)
-  SET_LDS((gg_gradient_dma_kernel<4, true, 6, 5>), all)
-  SET_LDS((gg_gradient_dma_kernel<4, false, 8, 6>), all)
-  SET_LDS((gg_gradient_dma_kernel<4, true, 8, 6>), all)
-#define SET_LDS_FUSED(CB, KV, KG)                                \
-  SET_LDS((gg_fused_dma_kernel<false, false, CB, KV, KG>), all)  \
-  SET_LDS((gg_fused_dma_kernel<false, true, CB, KV, KG>), all)   \
-  SET_LDS((gg_fused_dma_kernel<true, false, CB, KV, KG>), all)   \
-  SET_LDS((gg_fused_dma_kernel<true, true, CB, KV, KG>), all)
-#define SET_LDS_SPLIT(R, N)                                                             \
-  SET_LDS((gg_fused_split_kernel<R, N, 5, 4, 4, 4, true, false, true, true>), all)      \
-  SET_LDS((gg_fused_split_kernel<R, N, 5, 4, 4, 4, true, false, true, false>), all)     \
-  SET_LDS((gg_fused_split_kernel<R, N, 5, 4, 4, 4, true, false, false, true>), all)     \
-  SET_LDS((gg_fused_split_kernel<R, N, 5, 4, 4, 4, true, false, false, false>), all)
-  SET_LDS_SPLIT(false, false)
-  SET_LDS_SPLIT(false, true)
-  SET_LDS_SPLIT(true, false)
-  SET_LDS_SPLIT(true, true)
-#undef SET_LDS_SPLIT
-  SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4, true, true, true, true>), all)
-  SET_LDS((gg_fused_split_kernel<false, true, 5, 4, 4, 4, true, true, true, true>), all)
-#if GG_WITH_ABLATION
-  SET_LDS((gg_fused_split_kernel<false, false, 5, 4, 4, 4, false, false, true, true>), all)
-#endif
-  SET_LDS_FUSED(5, 3, 4)
-  SET_LDS_FUSED(5, 4, 4)
-  SET_LDS_FUSED(5, 4, 5)
-  SET_LDS_FUSED(6, 5, 6)
-  SET_LDS_FUSED(8, 6, 8)
-#undef SET_LDS_FUSED
-  SET_LDS((gg_gradient_pipe_kernel<1, false>), all)
-  SET_LDS((gg_gradient_pipe_kernel<1, true>), all)
-  SET_LDS((gg_gradient_pipe_kernel<2, false>), all)
-  SET_LDS((gg_gradient_pipe_kernel<2, true>), all)
-  SET_LDS((gg_gradient_pipe_kernel<4, false>), all)
-  SET_LDS((gg_gradient_pipe_kernel<4, true>), all)
-  SET_LDS((gg_gradient_pipe_kernel<8, false>), all)
-  SET_LDS((gg_gradient_pipe_kernel<8, true>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, false, 2, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, true, 2, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, false, 2, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, true, 2, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, false, 3, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, true, 3, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, false, 3, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, true, 3, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, false, 4, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, true, 4, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, false, 4, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, true, 4, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, false, 6, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, true, 6, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, false, 6, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, true, 6, 2>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, false, 3, 3>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, true, 3, 3>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, false, 3, 3>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, true, 3, 3>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, false, 4, 3>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, true, 4, 3>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, false, 4, 3>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, true, 4, 3>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, false, 6, 3>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, true, 6, 3>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, false, 6, 3>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, true, 6, 3>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, false, 3, 4>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, true, 3, 4>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, false, 3, 4>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, true, 3, 4>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, false, 6, 4>), all)
-  SET_LDS((gg_flux_dma_kernel<8, false, true, 6, 4>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, false, 6, 4>), all)
-  SET_LDS((gg_flux_dma_kernel<8, true, true, 6, 4>), all)
-  SET_LDS((gg_flux_kernel<1, false, false>), all)
-  SET_LDS((gg_flux_kernel<1, false, true>), all)
-  SET_LDS((gg_flux_kernel<2, false, false>), all)
-  SET_LDS((gg_flux_kernel<2, false, true>), all)
-  SET_LDS((gg_flux_kernel<4, false, false>), all)
-  SET_LDS((gg_flux_kernel<4, false, true>), all)
-  SET_LDS((gg_flux_kernel<8, false, false>), all)
-  SET_LDS((gg_flux_kernel<8, false, true>), all)
-  SET_LDS((gg_flux_kernel<1, true, false>), all)
-  SET_LDS((gg_flux_kernel<1, true, true>), all)
-  SET_LDS((gg_flux_kernel<2, true, false>), all)
-  SET_LDS((gg_flux_kernel<2, true, true>), all)
-  SET_LDS((gg_flux_kernel<4, true, false>), all)
-  SET_LDS((gg_flux_kernel<4, true, true>), all)
-  SET_LDS((gg_flux_kernel<8, true, false>), all)
-  SET_LDS((gg_flux_kernel<8, true, true>), all)
-#undef SET_LDS
-  if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
-  return e;
 }

@@ -122,7 +122,6 @@ struct cfdp_gpu {
   // streams more than the cache holds; the values do not depend on the order)
   bool alternate = false;
   unsigned fused_passes = 0;
-  int pipeline = -1;           // -1: auto; 0: one workgroup per tile; k: persistent LDS-DMA kernel, <= k WG/CU
   int grad_lanes = 4, flux_lanes = 8;
   bool pending_exchange = false;
   bool streams_exported = false;  // handed to the caller: not destroyed with the context
@@ -219,7 +218,6 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
   HIP_TRY(hipSetDevice(device));
   cfdp_gpu *g = new cfdp_gpu();
   g->device = device;
-  if (const char *e = getenv("CFDP_PIPELINE")) g->pipeline = atoi(e);
   if (const char *e = getenv("CFDP_DEBUG_ABLATE")) gg_debug_flags = atoi(e);
   if (const char *e = getenv("CFDP_FUSED_SPLIT")) gg_fused_split = atoi(e);
   HIP_TRY(hipStreamCreateWithFlags(&g->s_main, hipStreamNonBlocking));
@@ -360,7 +358,6 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   HIP_TRY(hipMemset(g->d_var, 0, sizeof(double) * 8 * (size_t)p->nall));
   HIP_TRY(hipMemset(g->d_grad, 0, sizeof(double) * 21 * (size_t)p->nall));
   HIP_TRY(hipMemset(g->d_flux, 0, sizeof(double) * 3 * (size_t)p->nown));
-  HIP_TRY(gg_set_max_lds((size_t)p->lds_grad, (size_t)p->lds_flux));
   g->uploaded = true;
   if (g->fusion) return cfdp_gpu_set_fusion(g, 1);
   return 0;
@@ -533,14 +530,6 @@ int cfdp_gpu_get_flux(cfdp_gpu *g, double *flux) {
   return 0;
 }
 
-int cfdp_gpu_set_pipeline(cfdp_gpu *g, int max_wg_per_cu) {
-  if (!g) return fail("null context");
-  if (max_wg_per_cu < -1 || max_wg_per_cu > 16) return fail("pipeline depth must be in [-1,16]");
-  g->pipeline = max_wg_per_cu;
-  g->drop_graphs();
-  return 0;
-}
-
 int cfdp_gpu_set_variant(cfdp_gpu *g, int grad_lanes, int flux_lanes) {
   if (!g) return fail("null context");
   auto ok = [](int l) { return l == 1 || l == 2 || l == 4 || l == 8; };
@@ -550,14 +539,6 @@ int cfdp_gpu_set_variant(cfdp_gpu *g, int grad_lanes, int flux_lanes) {
   g->grad_lanes = grad_lanes;
   g->flux_lanes = flux_lanes;
   return 0;
-}
-
-// default: one workgroup per tile with fixed-count LDS-DMA staging (3 workgroups per CU keep
-// ~24 waves busy; measured faster than the persistent double-buffered form at every size,
-// whose single workgroup per CU cannot hide the LDS latency of the arithmetic)
-static int pipe_for(const cfdp_gpu *g, int ntiles) {
-  (void)ntiles;
-  return g->pipeline >= 0 ? g->pipeline : 0;
 }
 
 // A launch covers one tile range.  The two tile classes (boundary tiles are half-size sheets)
@@ -608,9 +589,7 @@ static int launch_grad(cfdp_gpu *g, int which, hipStream_t st, const gg_grad_vie
   gg_args a = g->args();
   if (into) a.grad = *into;
   const tile_range r = range_of(g, which);
-  const int pipe = pipe_for(g, r.n);  // (the persistent form holds halo pieces per thread: it needs the true halo bound)
-  HIP_TRY(gg_launch_gradient(a, g->grad_lanes, r.begin, r.n, r.tp, r.lds_grad, pipe ? r.max_halo : r.row_halo(), r.max_blob, pipe,
-                             g->streaming, st));
+  HIP_TRY(gg_launch_gradient(a, g->grad_lanes, r.begin, r.n, r.tp, r.lds_grad, r.row_halo(), r.max_blob, g->streaming, st));
   return 0;
 }
 

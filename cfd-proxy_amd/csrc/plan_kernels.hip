@@ -345,6 +345,12 @@ double wall() {
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+template <typename T> struct host_buf {  // malloc'd; freed unless released
+  T *p = nullptr;
+  ~host_buf() { free(p); }
+  T *release() { T *q = p; p = nullptr; return q; }
+};
+
 template <typename T> struct dev_buf {  // freed on every return path
   T *p = nullptr;
   ~dev_buf() { (void)hipFree(p); }
@@ -363,9 +369,16 @@ int exclusive_scan(const int *d_in, int n, int *d_out /*[n+1]*/) {
   return 0;
 }
 
+// CFDP_PLAN_FAIL_STAGE=1|5 (tests): the stage fails the way an out-of-memory hipMalloc would
+bool fail_injected(int stage) {
+  const char *e = getenv("CFDP_PLAN_FAIL_STAGE");
+  return e && atoi(e) == stage;
+}
+
 int stage_csr(const solver_data *sd, int **xadj_out, int **adj_face_out, int **adj_other_out, long *used_out, void *vctx) {
   stage_ctx *c = static_cast<stage_ctx *>(vctx);
   const double t0 = wall();
+  if (fail_injected(1)) return cfdp_set_error("hipMalloc failed: out of memory (injected by CFDP_PLAN_FAIL_STAGE)");
   const int nown = sd->nownpoints, nf = sd->nfaces;
   c->nown = nown;
   c->nf = nf;
@@ -385,8 +398,9 @@ int stage_csr(const solver_data *sd, int **xadj_out, int **adj_face_out, int **a
   const int blocks = 4096;
   hipLaunchKernelGGL(k_degree, dim3(blocks), dim3(256), 0, 0, fpoint.p, nf, nown, deg.p, used.p);
   PK_TRY(hipGetLastError());
-  if (exclusive_scan(deg.p, nown, c->d_xadj)) return 1;
-  int *xadj = static_cast<int *>(calloc((size_t)nown + 2, sizeof(int)));
+  if (exclusive_scan(deg.p, nown, c->d_xadj)) return 1;  // (the scan has set the error text)
+  host_buf<int> hx, hf, ho;  // freed on every failing return path, released to the caller on success
+  int *xadj = hx.p = static_cast<int *>(calloc((size_t)nown + 2, sizeof(int)));
   if (!xadj) return cfdp_set_error("out of memory");
   PK_TRY(hipMemcpy(xadj, c->d_xadj, sizeof(int) * ((size_t)nown + 1), hipMemcpyDeviceToHost));
   const int nadj = xadj[nown];
@@ -410,16 +424,16 @@ int stage_csr(const solver_data *sd, int **xadj_out, int **adj_face_out, int **a
     PK_TRY(hipGetLastError());
     PK_TRY(hipDeviceSynchronize());
   }
-  int *adj_face = static_cast<int *>(malloc(sizeof(int) * (size_t)(nadj ? nadj : 1)));
-  int *adj_other = static_cast<int *>(malloc(sizeof(int) * (size_t)(nadj ? nadj : 1)));
+  int *adj_face = hf.p = static_cast<int *>(malloc(sizeof(int) * (size_t)(nadj ? nadj : 1)));
+  int *adj_other = ho.p = static_cast<int *>(malloc(sizeof(int) * (size_t)(nadj ? nadj : 1)));
   if (!adj_face || !adj_other) return cfdp_set_error("out of memory");
   PK_TRY(hipMemcpy(adj_face, c->d_adj_face, sizeof(int) * (size_t)nadj, hipMemcpyDeviceToHost));
   PK_TRY(hipMemcpy(adj_other, c->d_adj_other, sizeof(int) * (size_t)nadj, hipMemcpyDeviceToHost));
   unsigned long long u = 0;
   PK_TRY(hipMemcpy(&u, used.p, sizeof u, hipMemcpyDeviceToHost));
-  *xadj_out = xadj;
-  *adj_face_out = adj_face;
-  *adj_other_out = adj_other;
+  *xadj_out = hx.release();
+  *adj_face_out = hf.release();
+  *adj_other_out = ho.release();
   *used_out = (long)u;
   c->seconds[0] = wall() - t0;
   return 0;
@@ -441,6 +455,10 @@ int stage_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P, void
   int cap = 64;
   while (cap < 2 * max_inc) cap *= 2;
   const size_t lds = sizeof(int) * ((size_t)np_max + 2 + 2 * (size_t)max_inc + 3 * (size_t)cap + 2 * BLOB_T);
+  if (fail_injected(5)) {
+    P->tiles = static_cast<cfdp_tile_desc *>(calloc((size_t)nt, sizeof(cfdp_tile_desc)));  // a partial output, as a late failure leaves
+    return cfdp_set_error("hipMalloc failed: out of memory (injected by CFDP_PLAN_FAIL_STAGE)");
+  }
   if (lds > 160 * 1024 || np_max > 4 * BLOB_T) return 2;  // a tile too big for the LDS hash: the host stage takes over
   dev_buf<int> order, tile_first, tile_of, old2new, cntE, cntH, cntI, bad, halo;
   dev_buf<double> fnormal;
@@ -490,9 +508,10 @@ int stage_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P, void
   PK_TRY(hipMemcpy(I.data(), cntI.p, sizeof(int) * (size_t)nt, hipMemcpyDeviceToHost));
   int isbad = 0;
   PK_TRY(hipMemcpy(&isbad, bad.p, sizeof(int), hipMemcpyDeviceToHost));
-  if (isbad) return 1;
+  if (isbad) return cfdp_set_error("device plan stage 5: a tile overflowed its LDS hash table or its 16-bit neighbour / 15-bit face slots (counting pass)");
   // sizes -> descriptors, offsets, LDS classes (as the host stage's pass A)
   P->tiles = static_cast<cfdp_tile_desc *>(calloc((size_t)nt, sizeof(cfdp_tile_desc)));
+  if (!P->tiles) return cfdp_set_error("out of memory");
   std::vector<long> h_boff((size_t)nt + 1, 0), h_hoff((size_t)nt + 1, 0);
   long lds_g[2] = {0, 0}, lds_f[2] = {0, 0}, dup_total = 0, inc_total = 0;
   for (int t = 0; t < nt; t++) {
@@ -515,7 +534,8 @@ int stage_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P, void
   }
   P->blob_bytes = h_boff[nt];
   P->nhalo_total = h_hoff[nt];
-  if (P->blob_bytes % 16 != 0 || P->blob_bytes / 16 >= 0x7FFFFFFF) return 1;
+  if (P->blob_bytes % 16 != 0 || P->blob_bytes / 16 >= 0x7FFFFFFF)
+    return cfdp_set_error("device plan stage 5: %ld bytes of tile blobs do not fit 32-bit 16-byte offsets", (long)P->blob_bytes);
   PK_TRY(blob.alloc((size_t)P->blob_bytes));
   PK_TRY(halo.alloc((size_t)P->nhalo_total));
   PK_TRY(hipMemset(blob.p, 0, (size_t)(P->blob_bytes ? P->blob_bytes : 1)));  // alignment padding is defined
@@ -530,7 +550,7 @@ int stage_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P, void
   PK_TRY(hipMemcpy(P->blob, blob.p, (size_t)P->blob_bytes, hipMemcpyDeviceToHost));
   if (P->nhalo_total) PK_TRY(hipMemcpy(P->halo_idx, halo.p, sizeof(int) * (size_t)P->nhalo_total, hipMemcpyDeviceToHost));
   PK_TRY(hipMemcpy(&isbad, bad.p, sizeof(int), hipMemcpyDeviceToHost));
-  if (isbad) return 1;
+  if (isbad) return cfdp_set_error("device plan stage 5: a tile overflowed its LDS hash table or its index slots (fill pass)");
   P->nfaces_dup = dup_total;
   P->ninc_total = inc_total;
   for (int cidx = 0; cidx < 2; cidx++) { P->lds_grad_cls[cidx] = lds_g[cidx]; P->lds_flux_cls[cidx] = lds_f[cidx]; }
@@ -540,11 +560,31 @@ int stage_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P, void
   return 0;
 }
 
+// A stage that fails says why on stderr and returns non-zero: cfdp_plan_build_with then runs the host stage, which
+// produces the same arrays bit for bit (out of device memory, a failed attribute call, a tile the kernel refuses).
+int stage_csr_logged(const solver_data *sd, int **xadj, int **adj_face, int **adj_other, long *used, void *vctx) {
+  const int rc = stage_csr(sd, xadj, adj_face, adj_other, used, vctx);
+  if (rc) {
+    fprintf(stderr, "cfdp_plan (device stage 1): %s\n", cfdp_gpu_last_error());
+    stage_ctx *c = static_cast<stage_ctx *>(vctx);  // stage 5 uploads the host's arrays instead
+    (void)hipFree(c->d_xadj); (void)hipFree(c->d_adj_face); (void)hipFree(c->d_adj_other);
+    c->d_xadj = c->d_adj_face = c->d_adj_other = nullptr;
+    c->seconds[0] = -1.0;
+    (void)hipGetLastError();
+  }
+  return rc;
+}
+
 // stage 5 with the host's code when a tile is too big for the LDS hash (rc 2 above)
 int stage_blobs_or_host(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P, void *vctx) {
   const int rc = stage_blobs(sd, tl, P, vctx);
-  if (rc != 2) return rc;
+  if (rc == 0) return 0;
   static_cast<stage_ctx *>(vctx)->blobs_on_host = true;
+  if (rc != 2) {
+    fprintf(stderr, "cfdp_plan (device stage 5): %s\n", cfdp_gpu_last_error());
+    (void)hipGetLastError();
+    return rc;  // cfdp_plan_build_with frees the partial outputs and runs the host stage
+  }
   return cfdp_plan_host_blobs(sd, tl, P);
 }
 
@@ -564,13 +604,13 @@ int cfdp_plan_build_gpu(const solver_data *sd, const comm_data *cd, const cfdp_p
   stage_ctx ctx;
   ctx.device = device;
   cfdp_plan_stages st;
-  st.csr = (which & 1) ? stage_csr : nullptr;
+  st.csr = (which & 1) ? stage_csr_logged : nullptr;
   st.blobs = (which & 2) ? stage_blobs_or_host : nullptr;
   st.ctx = &ctx;
   cfdp_plan *P = cfdp_plan_build_with(sd, cd, opts, &st);
   if (!P) return cfdp_set_error("plan build failed");
   if (stage_seconds) {
-    stage_seconds[0] = ctx.seconds[0];
+    stage_seconds[0] = ctx.seconds[0];  // -1: the stage ran on the host
     stage_seconds[1] = ctx.blobs_on_host ? -1.0 : ctx.seconds[1];
   }
   *out = P;

@@ -1,0 +1,124 @@
+/*
+ * call_election.c -- one enqueue per entry-point call, whichever threads make it.
+ *
+ * The reference calls compute_gradients_gg_<variant>() and compute_psd_flux() from EVERY thread of one
+ * `omp parallel` region, with no barrier between the two and one `omp barrier` per iteration
+ * (src/solver.c:45-55); its exchange functions elect their first / last thread (src/threads.c:142-179).
+ * On the GPU one of the callers has to enqueue the work of a call and the others must not.  Who:
+ *
+ *   * a caller OUTSIDE a parallel region (or in a team of one) performs every call it makes -- whichever
+ *     thread it is: serial hosts, pthread hosts, a host that replaces its calling thread;
+ *   * inside a team of T > 1 threads the reference's convention holds: every thread of the team makes every
+ *     call.  The first thread to make its k-th team call performs call k; the others find it done.  Threads
+ *     may run ahead of each other (gradients and flux are not separated by a barrier), so the ordinal is
+ *     counted per thread;
+ *   * a team that does NOT follow the convention -- calls issued from `omp single` sections, which a varying
+ *     thread executes -- cannot be told from a late team mate when the call arrives; it is detected from the
+ *     attendance of earlier calls: when call k is performed, every call up to k - CFDP_ELECT_GRACE must have
+ *     been attended by its whole team (the reference's per-iteration barrier guarantees that after two calls).
+ *     (A team in which ONE thread makes all calls -- omp master -- loses nothing and is left alone.  A team whose
+ *     calls rotate evenly over all its T threads produces exactly the arrivals of T late team mates and cannot be
+ *     told apart by anything the library sees: such a host has to select CFDP_CALLS_EVERY itself.)
+ *     The run then stops with a message naming the fix (cfdp_set_call_mode(CFDP_CALLS_EVERY) or
+ *     CFDP_CALL_MODE=every: no election, every call is performed) instead of returning stale gradients.
+ *     A thread whose own ordinal points at a call everybody has attended already (it sat out a region run by a
+ *     smaller team) is moved forward to the first call that is still open.
+ */
+#include "call_election.h"
+
+#include <omp.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static int g_mode = -1; /* -1: read CFDP_CALL_MODE on first use */
+
+void cfdp_set_call_mode(int mode) { g_mode = mode; }
+
+int cfdp_get_call_mode(void) {
+  if (g_mode < 0) {
+    const char *e = getenv("CFDP_CALL_MODE");
+    g_mode = CFDP_CALLS_AUTO;
+    if (e && !strcmp(e, "every")) g_mode = CFDP_CALLS_EVERY;
+    else if (e && !strcmp(e, "team")) g_mode = CFDP_CALLS_TEAM;
+    else if (e && *e && strcmp(e, "auto")) {
+      fprintf(stderr, "Error: CFDP_CALL_MODE=%s (one of auto, team, every)\n", e);
+      exit(EXIT_FAILURE);
+    }
+  }
+  return g_mode;
+}
+
+#define CFDP_TLS_SLOTS 16
+static __thread struct { unsigned long id, n; } tls_calls[CFDP_TLS_SLOTS];
+static unsigned long g_ids = 0;
+
+void cfdp_elect_init(cfdp_election *el) {
+  memset(el, 0, sizeof(*el));
+  pthread_mutex_init(&el->mtx, NULL);
+  el->id = __atomic_add_fetch(&g_ids, 1, __ATOMIC_RELAXED);
+}
+
+void cfdp_elect_destroy(cfdp_election *el) { pthread_mutex_destroy(&el->mtx); }
+
+static void violation(const cfdp_election *el, unsigned long k, unsigned long late) {
+  fprintf(stderr,
+          "Error: compute_gradients_gg_* / compute_psd_flux are called from inside a parallel region of %d threads, but not "
+          "by every thread of the team: call %lu is being made while call %lu has been attended by %d of %d threads.  "
+          "Inside a parallel region the reference's convention is expected (every thread makes every call, "
+          "src/solver.c:45-55).  For calls made by one thread at a time (omp single / master sections) select "
+          "\"every call is performed\": cfdp_set_call_mode(CFDP_CALLS_EVERY) or CFDP_CALL_MODE=every.\n",
+          el->ring[late % CFDP_ELECT_RING].team, k, late, el->ring[late % CFDP_ELECT_RING].attended,
+          el->ring[late % CFDP_ELECT_RING].team);
+  exit(EXIT_FAILURE);
+}
+
+int cfdp_elect_begin(cfdp_election *el, int kind) {
+  const int mode = cfdp_get_call_mode();
+  const int team = (mode != CFDP_CALLS_EVERY && omp_in_parallel()) ? omp_get_num_threads() : 1;
+  if (team <= 1) { /* serial caller: it performs what it calls */
+    pthread_mutex_lock(&el->mtx);
+    el->serial_calls++;
+    return 1;
+  }
+  int slot = -1, spare = 0;
+  unsigned long oldest = ~0ul;
+  for (int i = 0; i < CFDP_TLS_SLOTS && slot < 0; i++) {
+    if (tls_calls[i].id == el->id) slot = i;
+    else if (tls_calls[i].id < oldest) { oldest = tls_calls[i].id; spare = i; }
+  }
+  if (slot < 0) { /* first team call of this thread on this election; recycle the oldest one's slot */
+    slot = spare;
+    tls_calls[slot].id = el->id;
+    tls_calls[slot].n = 0;
+  }
+  pthread_mutex_lock(&el->mtx);
+  if (!el->have_first) {
+    el->first = pthread_self();
+    el->have_first = 1;
+  } else if (!pthread_equal(el->first, pthread_self())) {
+    el->several = 1;
+  }
+  unsigned long k = tls_calls[slot].n + 1;
+  /* calls that left the ring are closed; so is a call its whole team has attended: this thread was not part of it */
+  if (k + CFDP_ELECT_RING <= el->team_calls) k = el->team_calls - CFDP_ELECT_RING + 1;
+  while (k <= el->team_calls && el->ring[k % CFDP_ELECT_RING].attended >= el->ring[k % CFDP_ELECT_RING].team) k++;
+  tls_calls[slot].n = k;
+  if (k <= el->team_calls) { /* a team mate has performed call k; this thread attends it */
+    el->ring[k % CFDP_ELECT_RING].attended++;
+    if (mode == CFDP_CALLS_AUTO && el->ring[k % CFDP_ELECT_RING].kind != kind) violation(el, el->team_calls, k);
+    pthread_mutex_unlock(&el->mtx);
+    return 0;
+  }
+  /* call k is new: this thread performs it */
+  el->team_calls = k;
+  el->ring[k % CFDP_ELECT_RING].attended = 1;
+  el->ring[k % CFDP_ELECT_RING].team = team;
+  el->ring[k % CFDP_ELECT_RING].kind = kind;
+  if (mode == CFDP_CALLS_AUTO && el->several) /* (one thread making all calls -- omp master -- loses none) */
+    for (unsigned long j = k > CFDP_ELECT_RING - 1 ? k - (CFDP_ELECT_RING - 1) : 1; j + CFDP_ELECT_GRACE <= k; j++)
+      if (el->ring[j % CFDP_ELECT_RING].attended < el->ring[j % CFDP_ELECT_RING].team) violation(el, k, j);
+  return 1;
+}
+
+void cfdp_elect_end(cfdp_election *el) { pthread_mutex_unlock(&el->mtx); }

@@ -17,6 +17,7 @@
  * RCCL) lives in the Python host (cfd-proxy_amd/__init__.py) and shares the same C ABI.
  */
 #include "cfdproxy_hip.h"
+#include "call_election.h"
 #include "host_util.h"
 
 #include <pthread.h>
@@ -38,48 +39,13 @@ typedef struct cfdp_solver { /* what solver_data.gpu points to */
   int rank;
   int external; /* partners live in other processes: 1 = RCCL (cfdp_attach_rccl), 2 = xGMI write + notify */
   /* the reference calls compute_gradients_gg_* / compute_psd_flux from EVERY thread of one
-   * `omp parallel` region (src/solver.c:45-55); one of them must enqueue -- see call_begin()   */
-  pthread_mutex_t mtx;
-  unsigned long id;          /* unique per init_threads(): keys the callers' thread-local call counts */
-  unsigned long calls_done;  /* entry-point calls already performed for this partition            */
+   * `omp parallel` region (src/solver.c:45-55); one of them must enqueue -- host/call_election.c */
+  cfdp_election calls;
   int final_pending;         /* the last compute_gradients_gg_* carried final = 1                 */
 } cfdp_solver;
 
-/* ---- one enqueue per entry-point call, whichever threads make it ---------------------------
- * Every calling thread makes the same sequence of entry-point calls on a solver_data (the
- * reference's harness: gradients, flux, barrier, per iteration).  The FIRST thread to make its
- * k-th call performs call k (the reference elects its first/last thread the same way,
- * src/threads.c:142-179); the others find it done and return.  Calls are serialised by the
- * solver's mutex, so call k+1 is enqueued after call k whichever threads perform them.  No
- * OpenMP runtime is consulted: pthreads, any OpenMP implementation and plain serial callers all
- * work; the one requirement is the reference's own -- every thread of the team makes every
- * call (a thread that joins later only ever finds its calls done).                            */
-#define CFDP_TLS_SLOTS 16
-static __thread struct { unsigned long id, n; } tls_calls[CFDP_TLS_SLOTS];
-static unsigned long g_solver_ids = 0;
-
-static int call_begin(cfdp_solver *sv) { /* 1: this thread performs the call and holds sv->mtx */
-  int slot = -1, spare = 0;
-  unsigned long oldest = ~0ul;
-  for (int i = 0; i < CFDP_TLS_SLOTS && slot < 0; i++) {
-    if (tls_calls[i].id == sv->id) slot = i;
-    else if (tls_calls[i].id < oldest) { oldest = tls_calls[i].id; spare = i; }
-  }
-  if (slot < 0) { /* first call of this thread on this solver; recycle the oldest solver's slot */
-    slot = spare;
-    tls_calls[slot].id = sv->id;
-    tls_calls[slot].n = 0;
-  }
-  const unsigned long k = ++tls_calls[slot].n;
-  pthread_mutex_lock(&sv->mtx);
-  if (k <= sv->calls_done) {
-    pthread_mutex_unlock(&sv->mtx);
-    return 0;
-  }
-  sv->calls_done = k;
-  return 1;
-}
-static void call_end(cfdp_solver *sv) { pthread_mutex_unlock(&sv->mtx); }
+static int call_begin(cfdp_solver *sv, int kind) { return cfdp_elect_begin(&sv->calls, kind); }
+static void call_end(cfdp_solver *sv) { cfdp_elect_end(&sv->calls); }
 
 #define GPU_OK(call)                                                                       \
   do {                                                                                     \
@@ -132,7 +98,7 @@ void cfdp_group_destroy(cfdp_group *grp) {
   for (int r = 0; r < grp->G; r++) {
     if (grp->gpus[r]) cfdp_gpu_destroy(grp->gpus[r]);
     if (grp->sds[r] && grp->sds[r]->gpu) {
-      pthread_mutex_destroy(&((cfdp_solver *)grp->sds[r]->gpu)->mtx);
+      cfdp_elect_destroy(&((cfdp_solver *)grp->sds[r]->gpu)->calls);
       free(grp->sds[r]->gpu);
       grp->sds[r]->gpu = NULL;
     }
@@ -193,8 +159,7 @@ void init_threads(comm_data *cd, solver_data *sd, int NTHREADS) {
   grp->gpus[rank] = gpu;
   cfdp_solver *sv = cfdp_calloc(1, sizeof(*sv));
   sv->gpu = gpu; sv->group = grp; sv->rank = rank;
-  pthread_mutex_init(&sv->mtx, NULL);
-  sv->id = __atomic_add_fetch(&g_solver_ids, 1, __ATOMIC_RELAXED);
+  cfdp_elect_init(&sv->calls);
   sd->gpu = sv;
   cfdp_sync_fields_to_device(sd);
   /* one rank per process: set up (and validate) the data path to the partner ranks' GPUs */
@@ -254,7 +219,7 @@ cfdp_gpu *cfdp_dropin_context(solver_data *sd) { return solver_of(sd)->gpu; }
  * reference's does (src/solver.c:43,57) -- times finished work, not enqueue calls.           */
 static void gradients(solver_data *sd, int with_exchange, int overlap, int final) {
   cfdp_solver *sv = solver_of(sd);
-  if (!call_begin(sv)) return;
+  if (!call_begin(sv, 1 + 2 * with_exchange + 4 * overlap)) return;
   sv->final_pending = final != 0;
   if (sv->external == 2) { /* gradients, push, notify, wait; compute_psd_flux closes the step */
     GPU_OK(cfdp_gpu_step_ipc_pre(sv->gpu, with_exchange, overlap));
@@ -300,7 +265,7 @@ ASYNC(compute_gradients_gg_mpipscw_async)
 
 void compute_psd_flux(solver_data *sd) {
   cfdp_solver *sv = solver_of(sd);
-  if (!call_begin(sv)) return;
+  if (!call_begin(sv, 64)) return;
   if (sv->external == 2) GPU_OK(cfdp_gpu_step_ipc_post(sv->gpu, 1, sv->group->flux_mode));
   else if (sv->external) GPU_OK(cfdp_gpu_step_post(sv->gpu, 1, sv->group->flux_mode));
   else GPU_OK(cfdp_gpu_rank_flux(sv->group->gpus, sv->group->G, sv->rank, 1, sv->group->flux_mode));

@@ -221,11 +221,10 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
   memset(id, 0, sizeof id);
   int ok = cfdp_rccl_load(getenv("CFDP_RCCL_LIB")) == 0;
   if (ok && r == 0) ok = cfdp_rccl_unique_id(id) == 0;
-  int all_ok = 0;
-  MPI_Bcast(&ok, 1, MPI_INT, 0, MPI_COMM_WORLD);
+  int all_ok = 0; /* every rank's own result counts: a rank whose RCCL did not load must not be masked by rank 0's */
   MPI_Allreduce(&ok, &all_ok, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
   if (!all_ok) {
-    if (r == 0) fprintf(stderr, "Error: no data path between the ranks' GPUs: RCCL unavailable (%s)\n", cfdp_gpu_last_error());
+    if (!ok) fprintf(stderr, "Error (rank %d): no data path between the ranks' GPUs: RCCL unavailable (%s)\n", r, cfdp_gpu_last_error());
     MPI_Abort(MPI_COMM_WORLD, EXIT_FAILURE);
   }
   MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);

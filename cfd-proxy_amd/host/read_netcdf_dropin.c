@@ -75,9 +75,13 @@ static cfdp_ncfile *nc_lookup(int ncid) {
 }
 
 int nc_close(int ncid) {
-  cfdp_ncfile *f = nc_lookup(ncid);
+  cfdp_ncfile *f = NULL;
+#pragma omp critical(cfdp_nc_table)
+  {
+    f = nc_lookup(ncid);
+    if (f) g_open[ncid - 1] = NULL;
+  }
   if (!f) return CFDP_NC_EBADID;
-  g_open[ncid - 1] = NULL;
   cfdp_ncfile_close(f);
   return 0;
 }

@@ -389,8 +389,14 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
   int *xadj = NULL, *adj_face = NULL, *adj_other = NULL;
   long used = 0;
   {
-    const int rc = stages && stages->csr ? stages->csr(sd, &xadj, &adj_face, &adj_other, &used, stages->ctx)
-                                         : host_csr(sd, &xadj, &adj_face, &adj_other, &used, NULL);
+    int rc = stages && stages->csr ? stages->csr(sd, &xadj, &adj_face, &adj_other, &used, stages->ctx) : -1;
+    if (rc != 0) { /* no provider, or the provider failed (it has said why and freed what it had): the host stage
+                      produces the same arrays, bit for bit */
+      if (rc > 0) fprintf(stderr, "cfdp_plan: the device stage 'point->face CSR' failed (%d); using the host stage\n", rc);
+      xadj = adj_face = adj_other = NULL;
+      used = 0;
+      rc = host_csr(sd, &xadj, &adj_face, &adj_other, &used, NULL);
+    }
     CFDP_ASSERT(rc == 0 && xadj && adj_face && adj_other);
   }
   P->nfaces_used = used;
@@ -592,7 +598,14 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
   /* ---- 5. per-tile face copies, halo lists, incidence lists: host or device ---- */
   {
     cfdp_tiling tl = {xadj, adj_face, adj_other, T.order, T.tile_first, T.tile_of};
-    const int rc = stages && stages->blobs ? stages->blobs(sd, &tl, P, stages->ctx) : host_blobs(sd, &tl, P, NULL);
+    int rc = stages && stages->blobs ? stages->blobs(sd, &tl, P, stages->ctx) : -1;
+    if (rc != 0) { /* as above: the host stage takes over from a provider that failed */
+      if (rc > 0) fprintf(stderr, "cfdp_plan: the device stage 'tile blobs' failed (%d); using the host stage\n", rc);
+      free(P->tiles); free(P->blob); free(P->halo_idx);
+      P->tiles = NULL; P->blob = NULL; P->halo_idx = NULL;
+      P->blob_bytes = 0; P->nhalo_total = 0;
+      rc = host_blobs(sd, &tl, P, NULL);
+    }
     CFDP_ASSERT(rc == 0); /* tile too large for 16-bit neighbour / 15-bit face slots, or an internal error */
   }
   PLAN_STAGE("tile blobs");

@@ -163,6 +163,19 @@ void free_communication_ressources(comm_data *cd);
  * tiling (cfdp_plan) for this partition and uploads it to the device.                  */
 void init_threads(comm_data *cd, solver_data *sd, int NTHREADS);
 
+/* ---- who enqueues a compute_gradients_gg_* / compute_psd_flux call (host/call_election.c).  The reference calls
+ * them from EVERY thread of one `omp parallel` region (src/solver.c:45-55) and elects its first / last thread
+ * inside (src/threads.c:142-179); here one caller per call enqueues the GPU work:
+ *   CFDP_CALLS_AUTO  (default) outside a parallel region the caller performs every call it makes; inside a team of
+ *                    T > 1 threads every thread must make every call, the first to arrive performs it -- a team that
+ *                    does not (calls from omp single sections) is detected from the attendance of earlier calls and
+ *                    the run stops with a message
+ *   CFDP_CALLS_TEAM  the same without the attendance check
+ *   CFDP_CALLS_EVERY no election: every call is performed (hosts that call from ONE thread at a time inside a region)
+ * Environment: CFDP_CALL_MODE=auto|team|every (read at the first call unless cfdp_set_call_mode was called). */
+enum { CFDP_CALLS_AUTO = 0, CFDP_CALLS_TEAM = 1, CFDP_CALLS_EVERY = 2 };
+void cfdp_set_call_mode(int mode);
+
 /* ---- reference src/threads.h:13-24: callback types of the colour iterator.  Kept for
  * source compatibility; the GPU path orders pack/exchange by stream events instead.    */
 typedef void (*send_fn)(RangeList *color, comm_data *cd, double *data, int dim2);

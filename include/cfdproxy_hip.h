@@ -98,10 +98,6 @@ int  cfdp_gpu_get_flux(cfdp_gpu *g, double *psd_flux);
 
 /* launches (asynchronous) */
 int  cfdp_gpu_set_variant(cfdp_gpu *g, int grad_lanes, int flux_lanes);
-/* gradient kernel form.  -1: choose by launch size (default); 0: one workgroup per tile,
- * staged through registers; k > 0: persistent workgroups (<= k per CU) with two LDS
- * buffers, the next tile streaming in by LDS-DMA while the current one is computed       */
-int  cfdp_gpu_set_pipeline(cfdp_gpu *g, int max_wg_per_cu);
 int  cfdp_gpu_gradients(cfdp_gpu *g, int which_tiles, void *stream);
 int  cfdp_gpu_flux(cfdp_gpu *g, int mode, void *stream);
 int  cfdp_gpu_pack(cfdp_gpu *g, void *stream);   /* grad rows of send points -> send arena */

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -138,3 +139,37 @@ def test_reference_main_links_unchanged_against_the_dropin(tmp_path):
     r = subprocess.run([exe, "-lvl", "2", "dualgrid"], env=dict(os.environ, OMP_NUM_THREADS="2"), cwd=str(tmp_path),
                        capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "no HIP device" in r.stderr, r.stdout + r.stderr
+
+
+def _build_call_election_host(tmp_path):
+    exe = str(tmp_path / "host_call_election")
+    lib = os.path.join(ROOT, "cfd-proxy_amd", "lib")
+    r = subprocess.run(["gcc", "-std=gnu99", "-O1", "-Wall", "-Werror", "-fopenmp", os.path.join(ROOT, "tests", "host_call_election.c"),
+                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "cfd-proxy_amd", "host"),
+                        "-L" + lib, "-lcfdproxy_host", "-Wl,-rpath," + lib, "-lpthread", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+@pytest.mark.parametrize("scenario", ["team", "serial_threads", "mixed", "master"])
+def test_entry_point_calls_are_performed_exactly_once(pkg, tmp_path, scenario):
+    """host/call_election.c: which caller of compute_gradients_gg_* / compute_psd_flux enqueues the work.  The
+    reference's harness (every thread of a team of 4 makes every call, team mates running ahead, src/solver.c:45-55),
+    serial callers on ever new threads, serial calls mixed with teams of 4 and 2, and one thread of a team making
+    all calls: every call is performed exactly once, in the order it was issued"""
+    exe = _build_call_election_host(tmp_path)
+    env = {k: v for k, v in os.environ.items() if k != "CFDP_CALL_MODE"}
+    r = subprocess.run([exe, scenario], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "order broken" not in r.stdout, r.stdout + r.stderr
+
+
+def test_calls_from_omp_single_sections_are_never_lost_silently(pkg, tmp_path):
+    """a team that does not follow the reference's convention (calls from omp single sections): either nothing is
+    lost, or the run stops with the message that names the fix -- and with that fix every call is performed"""
+    exe = _build_call_election_host(tmp_path)
+    env = {k: v for k, v in os.environ.items() if k != "CFDP_CALL_MODE"}
+    r = subprocess.run([exe, "single"], capture_output=True, text=True, timeout=120, env=env)
+    assert (r.returncode == 0 and "performed 80 of 80" in r.stdout) or \
+        (r.returncode == 1 and "not by every thread of the team" in r.stderr and "CFDP_CALL_MODE=every" in r.stderr), r.stdout + r.stderr
+    r = subprocess.run([exe, "single"], capture_output=True, text=True, timeout=120, env=dict(env, CFDP_CALL_MODE="every"))
+    assert r.returncode == 0 and "performed 80 of 80" in r.stdout, r.stdout + r.stderr

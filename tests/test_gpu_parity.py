@@ -14,10 +14,9 @@ pytestmark = pytest.mark.gpu
 LANES = [1, 2, 4, 8]
 
 
-def run_partition(pkg, dom, tile_points, lanes, flux_mode=0, flux_lanes=None, pipeline=-1):
+def run_partition(pkg, dom, tile_points, lanes, flux_mode=0, flux_lanes=None):
     part = pkg.GpuPartition(dom, tile_points=tile_points, grad_lanes=lanes,
                             flux_lanes=lanes if flux_lanes is None else flux_lanes)
-    part.set_pipeline(pipeline)
     part.gradients()
     part.flux(flux_mode)
     part.pull_fields()
@@ -38,44 +37,6 @@ def test_gradients_match_compiled_reference(gpu, orc, name, lanes, tile_points):
         assert rel_err(orc, g, fx[key], fp, fn, vol, var, nown) <= TOL, key
     gold_f = fx["flux_comm_free_t1_d0"]
     assert np.abs(f - gold_f)[:nown].max() <= TOL * np.abs(gold_f[:nown]).max()
-    dom.free()
-
-
-@pytest.mark.parametrize("name", ["g1_7x6x5", "g1_one_9x9x9"])
-@pytest.mark.parametrize("lanes", [1, 4, 8])
-@pytest.mark.parametrize("pipeline", [1, 2, 4])
-def test_pipelined_lds_dma_kernel_matches_compiled_reference(gpu, orc, name, lanes, pipeline):
-    """the persistent double-buffered LDS-DMA form of the gradient kernel (forced on; by default it is
-    only chosen for long launches), including runs of several tiles per workgroup and partial tiles"""
-    pkg = gpu
-    fx = load_golden(name)
-    dom = golden_domain(pkg, fx, 0)
-    fp, fn, vol, var, nown = dom.fpoint.copy(), dom.fnormal.copy(), dom.pvolume.copy(), dom.var.copy(), dom.nown
-    for tile_points in (8, 24):
-        dom.grad[:] = 1.0
-        g, _ = run_partition(pkg, dom, tile_points, lanes, pipeline=pipeline)
-        for key in [k for k in fx.files if k.startswith("grad_comm_free")]:
-            assert rel_err(orc, g, fx[key], fp, fn, vol, var, nown) <= TOL, (key, tile_points)
-    dom.free()
-
-
-def test_pipelined_kernel_many_tiles_per_workgroup(gpu, orc):
-    """more tiles than a persistent grid has workgroups: every workgroup walks a run of tiles"""
-    pkg = gpu
-    dims = (48, 40, 36)
-    gp = pkg.gen_params(*dims, ndomains=1)
-    dom = pkg.gen_domain(gp, 0)
-    pkg.fill_var(dom, None, pkg.VAR_HASH, *dims)
-    var = dom.var.copy()
-    ref = orc.CpuRef(dom.fpoint, dom.fnormal, dom.pvolume, dom.nown, nthreads=8)
-    g_ref = ref.gradients(var)
-    ref.close()
-    for tp, pipe in ((16, 1), (16, 3), (32, 2)):
-        dom.grad[:] = 1.0
-        g, _ = run_partition(pkg, dom, tp, 8, pipeline=pipe)
-        assert rel_err(orc, g, g_ref, dom.fpoint, dom.fnormal, dom.pvolume, var, dom.nown) <= TOL, (tp, pipe)
-        g0, _ = run_partition(pkg, dom, tp, 8, pipeline=0)
-        assert np.array_equal(g, g0)  # both kernel forms add a point's faces in the same order
     dom.free()
 
 
@@ -887,6 +848,27 @@ def test_device_built_plan_equals_host_plan(gpu, which):
         dev.free()
     for dom in [d, hub] + doms:
         dom.free()
+
+
+@pytest.mark.parametrize("stage", [1, 5])
+def test_device_plan_stage_that_fails_hands_over_to_the_host_stage(gpu, stage, monkeypatch, capfd):
+    """a device stage that fails (here: an injected out-of-memory) says why and the host stage -- bit-identical
+    by the test above -- takes over: no assertion, no abort, the same plan"""
+    pkg = gpu
+    d = pkg.gen_domain(pkg.gen_params(20, 18, 16, ndomains=1), 0)
+    host = pkg.Plan(d, tile_points=64)
+    monkeypatch.setenv("CFDP_PLAN_FAIL_STAGE", str(stage))
+    dev = pkg.Plan(d, tile_points=64, device_stages=3)
+    monkeypatch.delenv("CFDP_PLAN_FAIL_STAGE")
+    a, b = _plan_bytes(pkg, host), _plan_bytes(pkg, dev)
+    for k in a:
+        assert a[k] == b[k], (stage, k)
+    assert dev.stage_seconds[0 if stage == 1 else 1] == -1.0  # that stage ran on the host
+    err = capfd.readouterr().err
+    assert "injected by CFDP_PLAN_FAIL_STAGE" in err and "using the host stage" in err
+    host.free()
+    dev.free()
+    d.free()
 
 
 def test_partition_built_from_a_device_plan_computes_the_same(gpu, orc):

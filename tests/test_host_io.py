@@ -138,3 +138,20 @@ def test_single_domain_file_has_no_comm_tables(pkg, tmp_path):
     dom = pkg.load_domain(prefix, 0, 3)
     assert dom.cd.ndomains == 1 and dom.nown == dom.nall == 125 and dom.partners == []
     dom.free()
+
+
+def test_loader_keeps_its_own_reader_beside_foreign_netcdf_symbols(pkg, tmp_path):
+    """an application that defines functions with libnetcdf's names (or links a real libnetcdf) and its own now():
+    the library's loader calls bind to the library's own reader (-Bsymbolic-functions), not to the application's"""
+    import subprocess
+    gp = pkg.gen_params(6, 5, 4, ndomains=1)
+    prefix = str(tmp_path / "m")
+    pkg.write_mesh(gp, prefix, 2)
+    exe = str(tmp_path / "host_foreign_symbols")
+    lib = os.path.join(ROOT, "cfd-proxy_amd", "lib")
+    r = subprocess.run(["gcc", "-std=gnu99", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "host_foreign_symbols.c"),
+                        "-I" + os.path.join(ROOT, "include"), "-L" + lib, "-lcfdproxy_host", "-Wl,-rpath," + lib, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, prefix + "_domain_0_lvl_2"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.split()[1] == "120" and r.stdout.split()[2] == "120", r.stdout + r.stderr

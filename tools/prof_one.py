@@ -4,11 +4,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
 m = load_package()
 n = int(os.environ.get("N", "128")); tp = int(os.environ.get("TP", "128")); L = int(os.environ.get("L", "4"))
-pipe = int(os.environ.get("PIPE", "1")); iters = int(os.environ.get("ITERS", "5"))
+iters = int(os.environ.get("ITERS", "5"))
 gp = m.gen_params(n, ndomains=1); dom = m.gen_domain(gp, 0); m.fill_var(dom, None, m.VAR_HASH)
-part = m.GpuPartition(dom, tile_points=tp, grad_lanes=L, flux_lanes=8); part.set_pipeline(pipe)
+part = m.GpuPartition(dom, tile_points=tp, grad_lanes=L, flux_lanes=8)
 g, f = part.time_kernels(iters)
-print("n", n, "tp", tp, "L", L, "pipe", pipe, "grad us", g * 1e3, "flux us", f * 1e3, flush=True)
+print("n", n, "tp", tp, "L", L, "grad us", g * 1e3, "flux us", f * 1e3, flush=True)
 if os.environ.get("FUSED", "1") != "0":
     part.set_fusion(True)
     print("fused pass us", part.time_fused(iters) * 1e3, flush=True)
