@@ -24,9 +24,10 @@
  *     A thread whose own ordinal points at a call everybody has attended already (it sat out a region run by a
  *     smaller team) is moved forward to the first call that is still open.
  */
+#define _GNU_SOURCE
 #include "call_election.h"
 
-#include <omp.h>
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -47,6 +48,45 @@ int cfdp_get_call_mode(void) {
     }
   }
   return g_mode;
+}
+
+/* ---- "is the caller inside a parallel team, and how large is it?"
+ * A process can hold MORE than one OpenMP runtime (a gcc-built host brings libgomp, a library linked by hipcc brings
+ * LLVM's libomp; both export omp_in_parallel, and which one an unqualified call reaches is decided by symbol
+ * versions, not by who created the region): the only runtime that knows the caller's team is the one the HOST's
+ * `#pragma omp parallel` went to.  So every OpenMP runtime that is ALREADY LOADED is asked through its own handle
+ * (dlopen RTLD_NOLOAD: nothing is loaded for the question); a host without any OpenMP runtime has no teams.
+ * cfdp_set_call_team(T) overrides the answer for hosts whose team is not an OpenMP team (pthreads).           */
+typedef int (*omp_int_fn)(void);
+static struct { omp_int_fn in_parallel, num_threads; } g_omp[4];
+static int g_nomp = -1, g_team_override = 0;
+
+void cfdp_set_call_team(int nthreads) { g_team_override = nthreads > 0 ? nthreads : 0; }
+
+static void probe_openmp_runtimes(void) {
+  static const char *names[] = {"libgomp.so.1", "libomp.so", "libomp.so.5", "libiomp5.so"};
+  int n = 0;
+  for (unsigned i = 0; i < sizeof names / sizeof names[0] && n < 4; i++) {
+    void *h = dlopen(names[i], RTLD_NOLOAD | RTLD_LAZY);
+    if (!h) continue;
+    omp_int_fn a = (omp_int_fn)dlsym(h, "omp_in_parallel"), b = (omp_int_fn)dlsym(h, "omp_get_num_threads");
+    int dup = 0;
+    for (int j = 0; j < n; j++) dup = dup || g_omp[j].in_parallel == a;
+    if (a && b && !dup) { g_omp[n].in_parallel = a; g_omp[n].num_threads = b; n++; }
+  }
+  __atomic_store_n(&g_nomp, n, __ATOMIC_RELEASE);
+}
+
+static int caller_team_size(void) {
+  if (g_team_override) return g_team_override;
+  if (__atomic_load_n(&g_nomp, __ATOMIC_ACQUIRE) <= 0) probe_openmp_runtimes(); /* (again while none is loaded) */
+  int team = 1;
+  for (int i = 0; i < g_nomp; i++)
+    if (g_omp[i].in_parallel()) {
+      const int t = g_omp[i].num_threads();
+      if (t > team) team = t;
+    }
+  return team;
 }
 
 #define CFDP_TLS_SLOTS 16
@@ -74,8 +114,10 @@ static void violation(const cfdp_election *el, unsigned long k, unsigned long la
 }
 
 int cfdp_elect_begin(cfdp_election *el, int kind) {
-  const int mode = cfdp_get_call_mode();
-  const int team = (mode != CFDP_CALLS_EVERY && omp_in_parallel()) ? omp_get_num_threads() : 1;
+  /* a team the host has declared itself (cfdp_set_call_team) is taken at its word: no attendance check, which
+   * presumes the reference's barrier per iteration */
+  const int mode = g_team_override && cfdp_get_call_mode() == CFDP_CALLS_AUTO ? CFDP_CALLS_TEAM : cfdp_get_call_mode();
+  const int team = mode != CFDP_CALLS_EVERY ? caller_team_size() : 1;
   if (team <= 1) { /* serial caller: it performs what it calls */
     pthread_mutex_lock(&el->mtx);
     el->serial_calls++;

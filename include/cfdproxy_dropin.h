@@ -172,9 +172,13 @@ void init_threads(comm_data *cd, solver_data *sd, int NTHREADS);
  *                    the run stops with a message
  *   CFDP_CALLS_TEAM  the same without the attendance check
  *   CFDP_CALLS_EVERY no election: every call is performed (hosts that call from ONE thread at a time inside a region)
- * Environment: CFDP_CALL_MODE=auto|team|every (read at the first call unless cfdp_set_call_mode was called). */
+ * Environment: CFDP_CALL_MODE=auto|team|every (read at the first call unless cfdp_set_call_mode was called).
+ * The team is the caller's OpenMP team, asked of every OpenMP runtime loaded in the process (a host may bring a
+ * different one than this library); cfdp_set_call_team(T) states the team size for hosts whose callers are not an
+ * OpenMP team (T pthreads that all make every call); 0 = ask OpenMP again. */
 enum { CFDP_CALLS_AUTO = 0, CFDP_CALLS_TEAM = 1, CFDP_CALLS_EVERY = 2 };
 void cfdp_set_call_mode(int mode);
+void cfdp_set_call_team(int nthreads);
 
 /* ---- reference src/threads.h:13-24: callback types of the colour iterator.  Kept for
  * source compatibility; the GPU path orders pack/exchange by stream events instead.    */

@@ -41,6 +41,16 @@ static void *serial_thread(void *arg) {
   return NULL;
 }
 
+static void *pthread_member(void *arg) {
+  (void)arg;
+  for (int i = 0; i < 50; i++) {
+    call(1);
+    call(64);
+    if (i % 7 == 0) usleep(100);
+  }
+  return NULL;
+}
+
 int main(int argc, char **argv) {
   const char *sc = argc > 1 ? argv[1] : "team";
   int calls = 0;
@@ -63,6 +73,13 @@ int main(int argc, char **argv) {
     serial_thread(NULL);
     team_iterations(4, 30, 0);
     calls = 2 + 60 + 34 + 2 + 60;
+  } else if (!strcmp(sc, "pthread_team")) { /* a team that is not an OpenMP team: 4 pthreads, each makes every call */
+    cfdp_set_call_team(4);
+    pthread_t t[4];
+    for (int i = 0; i < 4; i++) pthread_create(&t[i], NULL, pthread_member, NULL);
+    for (int i = 0; i < 4; i++) pthread_join(t[i], NULL);
+    cfdp_set_call_team(0);
+    calls = 100;
   } else if (!strcmp(sc, "master")) { /* one thread of a team of 4 makes all calls */
 #pragma omp parallel num_threads(4)
     for (int i = 0; i < 40; i++) {

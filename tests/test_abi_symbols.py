@@ -141,23 +141,26 @@ def test_reference_main_links_unchanged_against_the_dropin(tmp_path):
     assert r.returncode != 0 and "no HIP device" in r.stderr, r.stdout + r.stderr
 
 
-def _build_call_election_host(tmp_path):
+def _build_call_election_host(tmp_path, lib_name="cfdproxy_host"):
     exe = str(tmp_path / "host_call_election")
     lib = os.path.join(ROOT, "cfd-proxy_amd", "lib")
     r = subprocess.run(["gcc", "-std=gnu99", "-O1", "-Wall", "-Werror", "-fopenmp", os.path.join(ROOT, "tests", "host_call_election.c"),
                         "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "cfd-proxy_amd", "host"),
-                        "-L" + lib, "-lcfdproxy_host", "-Wl,-rpath," + lib, "-lpthread", "-o", exe], capture_output=True, text=True)
+                        "-L" + lib, "-l" + lib_name, "-Wl,-rpath," + lib, "-lpthread", "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
 
 
-@pytest.mark.parametrize("scenario", ["team", "serial_threads", "mixed", "master"])
-def test_entry_point_calls_are_performed_exactly_once(pkg, tmp_path, scenario):
+@pytest.mark.parametrize("lib_name", ["cfdproxy_host", "cfdproxy_hip"])
+@pytest.mark.parametrize("scenario", ["team", "serial_threads", "mixed", "master", "pthread_team"])
+def test_entry_point_calls_are_performed_exactly_once(pkg, tmp_path, scenario, lib_name):
     """host/call_election.c: which caller of compute_gradients_gg_* / compute_psd_flux enqueues the work.  The
     reference's harness (every thread of a team of 4 makes every call, team mates running ahead, src/solver.c:45-55),
-    serial callers on ever new threads, serial calls mixed with teams of 4 and 2, and one thread of a team making
-    all calls: every call is performed exactly once, in the order it was issued"""
-    exe = _build_call_election_host(tmp_path)
+    serial callers on ever new threads, serial calls mixed with teams of 4 and 2, one thread of a team making all
+    calls, and a team of pthreads: every call is performed exactly once, in the order it was issued.  Against
+    libcfdproxy_hip.so the process holds TWO OpenMP runtimes (the gcc host's libgomp and the libomp hipcc links): the
+    team is the one the HOST's runtime knows"""
+    exe = _build_call_election_host(tmp_path, lib_name)
     env = {k: v for k, v in os.environ.items() if k != "CFDP_CALL_MODE"}
     r = subprocess.run([exe, scenario], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0 and "order broken" not in r.stdout, r.stdout + r.stderr

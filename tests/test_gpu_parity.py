@@ -673,6 +673,35 @@ def test_full_size_fused_iterations_match_separate_kernels(gpu, n, flux_mode):
     dom.free()
 
 
+@pytest.mark.parametrize("label,n,nd", [("dualgrid.12 lvl 2 (bench.py --gpus 1)", 64, 12),
+                                        ("dualgrid.384 finest level (bench.py finest_level)", 128, 384)])
+def test_exact_bench_path_full_field_against_the_oracle(gpu, orc, label, n, nd):
+    """the path bench.py times, at full size, every value checked: nd dualgrid domain FILES -> the drop-in loader ->
+    merged into one partition -> device-built plan -> 103 fused iterations replayed from hipGraphs (what
+    `run_iterations(K, fused, graph)` runs in the timed loop; reference loop src/solver.c:42-58).  EVERY own row of
+    grad and psd_flux against the C oracle on the merged mesh: per-component criterion of SURVEY 8c, 1e-10."""
+    pkg = gpu
+    from cfd_proxy_amd import multigpu as mg
+    gp = pkg.gen_params(n, ndomains=nd)
+    part, st = mg.build_rank_partition(gp, nd, 1, 0, via_files=True)
+    assert st["nown"] == n ** 3 and st["nghost"] == 0 and st["domains"] == nd
+    fp, fn_, vol, var, nown = part.fpoint, part.fnormal, part.pvolume, part.var.copy(), part.nown
+    g = pkg.GpuPartition(part)  # (device-built plan: the default)
+    assert g.stats["plan_stage_seconds"] is not None and min(g.stats["plan_stage_seconds"]) >= 0.0
+    g.set_fusion(True)
+    g.run_iterations(103, True, pkg.FLUX_CONSISTENT, use_graph=True)
+    g.pull_fields()
+    g.close()
+    ref = orc.CpuRef(fp, fn_, vol, nown, nthreads=min(16, os.cpu_count() or 1))
+    g_ref = ref.gradients(var)
+    f_ref = ref.flux(g_ref, mode=0)
+    ref.close()
+    assert rel_err(orc, part.grad, g_ref, fp, fn_, vol, var, nown) <= TOL, label
+    assert np.abs(part.psd_flux - f_ref)[:nown].max() <= TOL * np.abs(f_ref[:nown]).max(), label
+    assert np.abs(g_ref).max() > 0 and np.abs(f_ref).max() > 0
+    part.free()
+
+
 # ------------------------------------------------------------------ BASELINE.json configs 3-5
 @pytest.mark.parametrize("label,n,nd,G", [
     ("dualgrid.48 lvl 2 on 4 ranks", 64, 48, 4),
