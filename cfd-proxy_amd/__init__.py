@@ -208,6 +208,8 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_bind_grad.argtypes = [vp, vp]
     lib.cfdp_gpu_bind_sendbuf.argtypes = [vp, vp]
     lib.cfdp_gpu_set_fusion.argtypes = [vp, C.c_int]
+    lib.cfdp_gpu_set_resident.argtypes = [vp, C.c_int]
+    lib.cfdp_gpu_resident_qualifies.argtypes = [vp, P(C.c_char_p)]
     lib.cfdp_gpu_bind_grad_alt.argtypes = [vp, vp]
     lib.cfdp_gpu_time_fused.argtypes = [vp, C.c_int, C.c_int, P(C.c_float)]
     for n in ("set_var", "set_grad", "set_flux", "get_grad", "get_flux"):
@@ -797,6 +799,16 @@ class GpuPartition:
         g, f = C.c_float(), C.c_float()
         self._ck(self.lib.cfdp_gpu_time_kernels(self.h, iters, flux_mode, C.byref(g), C.byref(f)))
         return g.value, f.value
+
+    def set_resident(self, mode: int) -> None:
+        """tile-resident iterations (cfdp_gpu_set_resident): 0 off, 1 on where the partition qualifies, 2 staleness test"""
+        self._ck(self.lib.cfdp_gpu_set_resident(self.h, int(mode)))
+
+    def resident_qualifies(self):
+        """(True, None) or (False, reason)"""
+        why = C.c_char_p()
+        ok = self.lib.cfdp_gpu_resident_qualifies(self.h, C.byref(why))
+        return bool(ok), (why.value.decode() if why.value else None)
 
     def run_iterations(self, iters: int, with_flux: bool = True, flux_mode: int = FLUX_CONSISTENT,
                        use_graph: bool = True) -> float:

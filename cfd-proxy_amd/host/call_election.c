@@ -113,12 +113,20 @@ static void violation(const cfdp_election *el, unsigned long k, unsigned long la
   exit(EXIT_FAILURE);
 }
 
+static int trace_on(void) { /* CFDP_CALL_TRACE=1: one line per entry-point call on stderr (diagnostics) */
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("CFDP_CALL_TRACE"); on = e && *e && *e != '0'; }
+  return on;
+}
+
 int cfdp_elect_begin(cfdp_election *el, int kind) {
   /* a team the host has declared itself (cfdp_set_call_team) is taken at its word: no attendance check, which
    * presumes the reference's barrier per iteration */
   const int mode = g_team_override && cfdp_get_call_mode() == CFDP_CALLS_AUTO ? CFDP_CALLS_TEAM : cfdp_get_call_mode();
+  const int resync = mode == CFDP_CALLS_AUTO;
   const int team = mode != CFDP_CALLS_EVERY ? caller_team_size() : 1;
   if (team <= 1) { /* serial caller: it performs what it calls */
+    if (trace_on()) fprintf(stderr, "cfdp call: thread %lx kind %d serial caller -> performs\n", (unsigned long)pthread_self(), kind);
     pthread_mutex_lock(&el->mtx);
     el->serial_calls++;
     return 1;
@@ -141,25 +149,42 @@ int cfdp_elect_begin(cfdp_election *el, int kind) {
   } else if (!pthread_equal(el->first, pthread_self())) {
     el->several = 1;
   }
+  /* Whether this thread performs is decided by its ordinal alone: call k is new iff k > team_calls.  The ring of
+   * recent calls (an entry is trusted only while it still carries its call's ordinal) serves two things: a thread
+   * whose ordinal points at a call its whole team has attended was not part of that team and moves forward to the
+   * first call still open; and the attendance check of CFDP_CALLS_AUTO.  Threads of a declared team (or of
+   * CFDP_CALLS_TEAM) may be any distance apart (no barrier in the host): the one behind finds its calls done. */
   unsigned long k = tls_calls[slot].n + 1;
-  /* calls that left the ring are closed; so is a call its whole team has attended: this thread was not part of it */
-  if (k + CFDP_ELECT_RING <= el->team_calls) k = el->team_calls - CFDP_ELECT_RING + 1;
-  while (k <= el->team_calls && el->ring[k % CFDP_ELECT_RING].attended >= el->ring[k % CFDP_ELECT_RING].team) k++;
+#define ENTRY(j) el->ring[(j) % CFDP_ELECT_RING]
+  /* an OpenMP team (not one the host declared): re-synchronise threads that were not part of earlier teams.  A
+   * thread that has never called (an OpenMP runtime replaces pool threads when teams shrink and grow) starts at the
+   * oldest call still remembered; every thread passes over calls their whole team has attended */
+  if (resync) {
+    if (tls_calls[slot].n == 0 && el->team_calls >= CFDP_ELECT_RING) k = el->team_calls - CFDP_ELECT_RING + 1;
+    while (k <= el->team_calls && ENTRY(k).ordinal == k && ENTRY(k).attended >= ENTRY(k).team) k++;
+  }
   tls_calls[slot].n = k;
+  if (trace_on())
+    fprintf(stderr, "cfdp call: thread %lx kind %d team %d ordinal %lu of %lu -> %s\n", (unsigned long)pthread_self(), kind, team, k,
+            el->team_calls, k <= el->team_calls ? "done by a team mate" : "performs");
   if (k <= el->team_calls) { /* a team mate has performed call k; this thread attends it */
-    el->ring[k % CFDP_ELECT_RING].attended++;
-    if (mode == CFDP_CALLS_AUTO && el->ring[k % CFDP_ELECT_RING].kind != kind) violation(el, el->team_calls, k);
+    if (ENTRY(k).ordinal == k) {
+      ENTRY(k).attended++;
+      if (mode == CFDP_CALLS_AUTO && ENTRY(k).kind != kind) violation(el, el->team_calls, k);
+    }
     pthread_mutex_unlock(&el->mtx);
     return 0;
   }
   /* call k is new: this thread performs it */
   el->team_calls = k;
-  el->ring[k % CFDP_ELECT_RING].attended = 1;
-  el->ring[k % CFDP_ELECT_RING].team = team;
-  el->ring[k % CFDP_ELECT_RING].kind = kind;
+  ENTRY(k).ordinal = k;
+  ENTRY(k).attended = 1;
+  ENTRY(k).team = team;
+  ENTRY(k).kind = kind;
   if (mode == CFDP_CALLS_AUTO && el->several) /* (one thread making all calls -- omp master -- loses none) */
     for (unsigned long j = k > CFDP_ELECT_RING - 1 ? k - (CFDP_ELECT_RING - 1) : 1; j + CFDP_ELECT_GRACE <= k; j++)
-      if (el->ring[j % CFDP_ELECT_RING].attended < el->ring[j % CFDP_ELECT_RING].team) violation(el, k, j);
+      if (ENTRY(j).ordinal == j && ENTRY(j).attended < ENTRY(j).team) violation(el, k, j);
+#undef ENTRY
   return 1;
 }
 
