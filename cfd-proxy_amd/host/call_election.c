@@ -31,6 +31,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 static int g_mode = -1; /* -1: read CFDP_CALL_MODE on first use */
 
@@ -52,41 +53,31 @@ int cfdp_get_call_mode(void) {
 
 /* ---- "is the caller inside a parallel team, and how large is it?"
  * A process can hold MORE than one OpenMP runtime (a gcc-built host brings libgomp, a library linked by hipcc brings
- * LLVM's libomp; both export omp_in_parallel, and which one an unqualified call reaches is decided by symbol
- * versions, not by who created the region): the only runtime that knows the caller's team is the one the HOST's
- * `#pragma omp parallel` went to.  So every OpenMP runtime that is ALREADY LOADED is asked through its own handle
- * (dlopen RTLD_NOLOAD: nothing is loaded for the question); a host without any OpenMP runtime has no teams.
- * cfdp_set_call_team(T) overrides the answer for hosts whose team is not an OpenMP team (pthreads).           */
+ * LLVM's libomp; both export omp_in_parallel, and which one a link-time reference of THIS library reaches is decided
+ * by symbol versions, not by who created the region).  The runtime that knows the caller's team is the one the HOST's
+ * `#pragma omp parallel` went to: the first in the process's global lookup order, which is what dlsym(RTLD_DEFAULT)
+ * returns -- asked at run time, by name.  No other runtime is touched: a call into a runtime the host does not use
+ * would INITIALISE it (LLVM's libomp then installs fork handlers and helper threads in a process that never asked
+ * for them -- a Python host's next subprocess call hung on exactly that).  No OpenMP runtime in the global scope
+ * (a ctypes host, a pthread host): no teams.  cfdp_set_call_team(T) states the team for hosts whose team is not an
+ * OpenMP team.                                                                                                    */
 typedef int (*omp_int_fn)(void);
-static struct { omp_int_fn in_parallel, num_threads; } g_omp[4];
-static int g_nomp = -1, g_team_override = 0;
+static omp_int_fn g_in_parallel = NULL, g_num_threads = NULL;
+static int g_team_override = 0;
 
 void cfdp_set_call_team(int nthreads) { g_team_override = nthreads > 0 ? nthreads : 0; }
 
-static void probe_openmp_runtimes(void) {
-  static const char *names[] = {"libgomp.so.1", "libomp.so", "libomp.so.5", "libiomp5.so"};
-  int n = 0;
-  for (unsigned i = 0; i < sizeof names / sizeof names[0] && n < 4; i++) {
-    void *h = dlopen(names[i], RTLD_NOLOAD | RTLD_LAZY);
-    if (!h) continue;
-    omp_int_fn a = (omp_int_fn)dlsym(h, "omp_in_parallel"), b = (omp_int_fn)dlsym(h, "omp_get_num_threads");
-    int dup = 0;
-    for (int j = 0; j < n; j++) dup = dup || g_omp[j].in_parallel == a;
-    if (a && b && !dup) { g_omp[n].in_parallel = a; g_omp[n].num_threads = b; n++; }
-  }
-  __atomic_store_n(&g_nomp, n, __ATOMIC_RELEASE);
-}
-
 static int caller_team_size(void) {
   if (g_team_override) return g_team_override;
-  if (__atomic_load_n(&g_nomp, __ATOMIC_ACQUIRE) <= 0) probe_openmp_runtimes(); /* (again while none is loaded) */
-  int team = 1;
-  for (int i = 0; i < g_nomp; i++)
-    if (g_omp[i].in_parallel()) {
-      const int t = g_omp[i].num_threads();
-      if (t > team) team = t;
-    }
-  return team;
+  omp_int_fn a = __atomic_load_n(&g_in_parallel, __ATOMIC_ACQUIRE), b = __atomic_load_n(&g_num_threads, __ATOMIC_ACQUIRE);
+  if (!a || !b) { /* (looked up again while absent: a host may load its runtime later) */
+    a = (omp_int_fn)dlsym(RTLD_DEFAULT, "omp_in_parallel");
+    b = (omp_int_fn)dlsym(RTLD_DEFAULT, "omp_get_num_threads");
+    if (!a || !b) return 1;
+    __atomic_store_n(&g_num_threads, b, __ATOMIC_RELEASE);
+    __atomic_store_n(&g_in_parallel, a, __ATOMIC_RELEASE);
+  }
+  return a() ? b() : 1;
 }
 
 #define CFDP_TLS_SLOTS 16
@@ -110,7 +101,9 @@ static void violation(const cfdp_election *el, unsigned long k, unsigned long la
           "\"every call is performed\": cfdp_set_call_mode(CFDP_CALLS_EVERY) or CFDP_CALL_MODE=every.\n",
           el->ring[late % CFDP_ELECT_RING].team, k, late, el->ring[late % CFDP_ELECT_RING].attended,
           el->ring[late % CFDP_ELECT_RING].team);
-  exit(EXIT_FAILURE);
+  /* (team mates are inside GPU calls right now: exit() would run the runtimes' exit handlers under them) */
+  fflush(NULL);
+  _exit(EXIT_FAILURE);
 }
 
 static int trace_on(void) { /* CFDP_CALL_TRACE=1: one line per entry-point call on stderr (diagnostics) */

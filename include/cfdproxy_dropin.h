@@ -173,9 +173,9 @@ void init_threads(comm_data *cd, solver_data *sd, int NTHREADS);
  *   CFDP_CALLS_TEAM  the same without the attendance check
  *   CFDP_CALLS_EVERY no election: every call is performed (hosts that call from ONE thread at a time inside a region)
  * Environment: CFDP_CALL_MODE=auto|team|every (read at the first call unless cfdp_set_call_mode was called).
- * The team is the caller's OpenMP team, asked of every OpenMP runtime loaded in the process (a host may bring a
- * different one than this library); cfdp_set_call_team(T) states the team size for hosts whose callers are not an
- * OpenMP team (T pthreads that all make every call); 0 = ask OpenMP again. */
+ * The team is the caller's OpenMP team as the HOST's OpenMP runtime sees it (the first one in the process's global
+ * symbol order -- a host may bring a different runtime than this library links); cfdp_set_call_team(T) states the team
+ * size for hosts whose callers are not an OpenMP team (T pthreads that all make every call); 0 = ask OpenMP again. */
 enum { CFDP_CALLS_AUTO = 0, CFDP_CALLS_TEAM = 1, CFDP_CALLS_EVERY = 2 };
 void cfdp_set_call_mode(int mode);
 void cfdp_set_call_team(int nthreads);

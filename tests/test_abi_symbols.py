@@ -159,7 +159,7 @@ def test_entry_point_calls_are_performed_exactly_once(pkg, tmp_path, scenario, l
     serial callers on ever new threads, serial calls mixed with teams of 4 and 2, one thread of a team making all
     calls, and a team of pthreads: every call is performed exactly once, in the order it was issued.  Against
     libcfdproxy_hip.so the process holds TWO OpenMP runtimes (the gcc host's libgomp and the libomp hipcc links): the
-    team is the one the HOST's runtime knows"""
+    team is the one the HOST's runtime knows, and the other runtime is never called (never initialised)"""
     exe = _build_call_election_host(tmp_path, lib_name)
     env = {k: v for k, v in os.environ.items() if k != "CFDP_CALL_MODE"}
     r = subprocess.run([exe, scenario], capture_output=True, text=True, timeout=120, env=env)

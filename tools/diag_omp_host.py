@@ -15,11 +15,10 @@ r = subprocess.run(["gcc", "-std=gnu99", "-O1", "-g", "-fopenmp", os.path.join(R
                     "-L" + lib, "-lcfdproxy_hip", "-Wl,-rpath," + lib, "-Wl,--allow-shlib-undefined", "-o", exe], capture_output=True, text=True)
 print("build", r.returncode, r.stderr[-500:], flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-for label, env in (("t1", dict(OMP_NUM_THREADS="1")), ("t4_every", dict(OMP_NUM_THREADS="4", CFDP_CALL_MODE="every")),
-                   ("t4_team", dict(OMP_NUM_THREADS="4", CFDP_CALL_MODE="team")), ("t4_auto", dict(OMP_NUM_THREADS="4"))):
-    for fusion in ("0", "1"):
+for label, env in (("t4_auto", dict(OMP_NUM_THREADS="4")), ("t4_auto_notrace", dict(OMP_NUM_THREADS="4", CFDP_CALL_TRACE="0"))):
+    for fusion in ("1", "0"):
         out = os.path.join(ROOT, "gpurun_out", f"diag_omp_{label}_f{fusion}")
         with open(out + ".out", "w") as so, open(out + ".err", "w") as se:
-            rc = subprocess.run(["timeout", "-k", "5", "40", exe, prefix, "2", "3", os.path.join(tmp, "o"), "comm_free", "mpi_async"],
-                                env=dict(os.environ, CFDP_FUSION=fusion, CFDP_CALL_TRACE="1", **env), stdout=so, stderr=se).returncode
+            rc = subprocess.run(["timeout", "-k", "5", "40", exe, prefix, "2", "3", os.path.join(tmp, "o")],
+                                env=dict(dict(os.environ, CFDP_FUSION=fusion, CFDP_CALL_TRACE="1"), **env), stdout=so, stderr=se).returncode
         print(label, "fusion", fusion, "rc", rc, flush=True)
