@@ -13,6 +13,7 @@
  */
 #include "nc_classic.h"
 
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -31,8 +32,11 @@ void get_nc_int(int ncid, const char *name, int *array);
 int get_nc_val(int ncid, const char *name);
 
 /* ------------------------------------------------------------------ ncid handle table */
+/* (a pthread mutex, not `omp critical`: a process may hold two OpenMP runtimes -- the host's and the one this library
+ * was linked with -- and a named critical section is a word both would interpret their own way) */
 #define MAX_OPEN 256
 static cfdp_ncfile *g_open[MAX_OPEN];
+static pthread_mutex_t g_open_mtx = PTHREAD_MUTEX_INITIALIZER;
 
 #define CFDP_NC_EBADID (-33)  /* libnetcdf's NC_EBADID */
 #define CFDP_NC_ENFILE (-34)  /* libnetcdf's NC_ENFILE */
@@ -43,12 +47,11 @@ int nc_open(const char *path, int mode, int *ncidp) {
   cfdp_ncfile *f = NULL;
   int rc = cfdp_ncfile_open(path, &f);
   if (rc) return rc;
-#pragma omp critical(cfdp_nc_table)
-  {
-    rc = -1;
-    for (int i = 0; i < MAX_OPEN; i++)
-      if (!g_open[i]) { g_open[i] = f; rc = i; break; }
-  }
+  pthread_mutex_lock(&g_open_mtx);
+  rc = -1;
+  for (int i = 0; i < MAX_OPEN; i++)
+    if (!g_open[i]) { g_open[i] = f; rc = i; break; }
+  pthread_mutex_unlock(&g_open_mtx);
   if (rc < 0) { cfdp_ncfile_close(f); return CFDP_NC_ENFILE; }
   *ncidp = rc + 1; /* ncid > 0 */
   return 0;
@@ -76,11 +79,10 @@ static cfdp_ncfile *nc_lookup(int ncid) {
 
 int nc_close(int ncid) {
   cfdp_ncfile *f = NULL;
-#pragma omp critical(cfdp_nc_table)
-  {
-    f = nc_lookup(ncid);
-    if (f) g_open[ncid - 1] = NULL;
-  }
+  pthread_mutex_lock(&g_open_mtx);
+  f = nc_lookup(ncid);
+  if (f) g_open[ncid - 1] = NULL;
+  pthread_mutex_unlock(&g_open_mtx);
   if (!f) return CFDP_NC_EBADID;
   cfdp_ncfile_close(f);
   return 0;

@@ -721,21 +721,25 @@ def _resident_case(pkg, which):
     return parts[0]
 
 
-@pytest.mark.parametrize("which", ["whole 40x32x32", ("dualgrid.48", 4), ("dualgrid.192", 8)])
+@pytest.mark.parametrize("which", ["whole 40x32x32", ("dualgrid.192", 8), ("dualgrid.384", 8)])
 @pytest.mark.parametrize("flux_mode", [0, 1])
 def test_tile_resident_iterations_are_bit_identical(gpu, which, flux_mode):
     """K iterations in ONE launch (one workgroup per tile stays; the iteration boundary is a drained-flag hand-off
     between neighbouring tiles) against the fused one-launch-per-pass path: gradients and flux bit for bit, for a
-    whole small mesh and for rank 0's partition of the 48-domain / 4-rank and 192-domain / 8-rank decompositions
-    (BASELINE configs 3-4; iterations without exchange, ghost rows as they are)"""
+    whole small mesh and for rank 0's partition of the 192-domain / 8-rank decomposition (BASELINE config 4:
+    iterations without exchange, ghost rows as they are).  Rank 0 of dualgrid.384 / 8 (4096+ tiles) does not qualify:
+    there the mode must leave the run to the one-launch-per-pass path, with the same values"""
     pkg = gpu
     dom = _resident_case(pkg, which)
     rng = np.random.default_rng(11)
     dom.grad[:] = rng.normal(size=dom.grad.shape)  # (ghost rows of a partition with partners: arbitrary but fixed)
-    g = pkg.GpuPartition(dom)
+    # flux_lanes=4: the run's LAST flux comes from the separate flux kernel in the one-launch-per-pass path; with 4 lanes
+    # per point it splits a point's faces over lanes exactly as the flux phase of the fused pass (and of the resident
+    # kernel) does, so even that last flux is bit-identical (the default 8-lane kernel differs by rounding only)
+    g = pkg.GpuPartition(dom, flux_lanes=4)
     g.set_fusion(True)
     ok, why = g.resident_qualifies()
-    assert ok, why
+    assert ok == (which != ("dualgrid.384", 8)), why
     for K in (1, 2, 7, 40):
         g.set_resident(0)
         g.push_fields()
