@@ -375,6 +375,15 @@ def main() -> None:
         out["roofline"] = {"bound": "hbm", "kernel": "gg_fused_split_kernel", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            **fracs(bg + bf, bg + bf - 32.0 * nfaces_part, traffic.get("gg_fused"), ms_fu),
                            "gradient_kernel": grad_k, "flux_kernel": flux_k}
+        # the floor: the same pass with neither face loop (every load and every store; a diagnostic instantiation of
+        # the kernel) -- what the pass takes beyond it is arithmetic and latency the resident tiles do not hide
+        try:
+            mv = solver.gpu.time_fused_movement(1000)
+            out["roofline"]["movement_only_us"] = mv * 1e3
+            out["roofline"]["exposed_beyond_movement_us"] = (ms_fu - mv) * 1e3
+        except Exception as e:
+            out["roofline"]["movement_only_us"] = None
+            out["roofline"]["movement_only_note"] = str(e)[:160]
     out["roofline"]["traffic_source"] = traffic_src
 
     # ---- --gpus 2 / 4: the weak-scaling point of the same run (262,144 owned points per GPU) ----
@@ -437,6 +446,12 @@ def main() -> None:
                   "gradient_kernel": fracs(b1, b1, tr1.get("gg_gradient"), g1), "flux_kernel": fracs(b1f, b1f, tr1.get("gg_flux"), f1)}
             if fu1:
                 fl["fused"] = fracs(b1 + b1f, b1 + b1f - 32.0 * d1.nfaces, tr1.get("gg_fused"), fu1)
+                try:
+                    mv1 = p1.time_fused_movement(50)
+                    fl["fused"]["movement_only_us"] = mv1 * 1e3
+                    fl["fused"]["exposed_beyond_movement_us"] = (fu1 - mv1) * 1e3
+                except Exception as e:
+                    fl["fused"]["movement_only_us"] = None
             out["finest_level"] = fl
             p1.close()
             d1.free()

@@ -212,6 +212,7 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_resident_qualifies.argtypes = [vp, P(C.c_char_p)]
     lib.cfdp_gpu_bind_grad_alt.argtypes = [vp, vp]
     lib.cfdp_gpu_time_fused.argtypes = [vp, C.c_int, C.c_int, P(C.c_float)]
+    lib.cfdp_gpu_time_fused_movement.argtypes = [vp, C.c_int, P(C.c_float)]
     for n in ("set_var", "set_grad", "set_flux", "get_grad", "get_flux"):
         getattr(lib, "cfdp_gpu_" + n).argtypes = [vp, P(C.c_double)]
     lib.cfdp_gpu_set_variant.argtypes = [vp, C.c_int, C.c_int]
@@ -793,6 +794,12 @@ class GpuPartition:
     def time_fused(self, iters: int, flux_mode: int = FLUX_CONSISTENT) -> float:
         ms = C.c_float()
         self._ck(self.lib.cfdp_gpu_time_fused(self.h, iters, flux_mode, C.byref(ms)))
+        return ms.value
+
+    def time_fused_movement(self, iters: int) -> float:
+        """milliseconds per pass of the fused pass's data movement alone (every load, every store, no face loop)"""
+        ms = C.c_float()
+        self._ck(self.lib.cfdp_gpu_time_fused_movement(self.h, iters, C.byref(ms)))
         return ms.value
 
     def time_kernels(self, iters: int, flux_mode: int = FLUX_CONSISTENT):

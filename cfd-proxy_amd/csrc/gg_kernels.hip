@@ -102,6 +102,8 @@ template <bool NT> __device__ __forceinline__ void st_row(double v, double *p) {
 // kernels of a timed run contain none of it -- merely compiled in and switched off it cost 1-2.5 %): thread 0 of
 // every workgroup writes shader-clock stamps of its phase boundaries, 8 per tile, to a buffer of its own
 #define GG_DBG_STAMP 0x20000
+// a third instantiation of the same pass: every load and every store, neither face loop (the data-movement floor)
+#define GG_DBG_MOVE 0x40000
 #ifndef GG_DEEP_BATCH
 #define GG_DEEP_BATCH 7
 #endif
@@ -182,7 +184,9 @@ __device__ __forceinline__ void st8_sc1(double *p, double v) {
 // one-launch-per-pass kernels.  1: part A (the rows neighbouring tiles re-read) write-through, 16 bytes per lane;
 // part B plain -- the form of the tile-resident kernel, whose readers run in the same launch.  `scale` multiplies
 // the rows (1.0 except in the staleness test of the tile-resident kernel).
-template <int LPP, bool NT, bool SYNC = false, int ST = 0>
+// MOVE (the data-movement floor, a diagnostic instantiation): no incidence is walked -- every row is stored as zeros
+// through the same slab and the same store instructions.
+template <int LPP, bool NT, bool SYNC = false, int ST = 0, bool MOVE = false>
 __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, const cfdp_tile_desc &td,
                                                   int tid, double *__restrict__ gradA,
                                                   double *__restrict__ gradB,
@@ -214,7 +218,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     for (int j = 0; j < NE; j++) vs[j] = var_l[li * 8 + eq0 + j];
     ks = (int)ioff[li];
     ke0 = (int)ioff[li + 1];
-    const int ke = ke0;
+    const int ke = MOVE ? ks : ke0;
     const double *var_eq0 = var_l + eq0;
     int k = ks;
     if constexpr (NE <= 2)  // few registers per incidence: deeper batches (a point has ~14 incidences)
@@ -807,7 +811,9 @@ __device__ __forceinline__ void gg_stamp_wave(int dbg, int ntiles, int tile, int
 // LISTED: the fixed-stride row lists exist (gg_args::rowlist); PUSH: an exchange rides in the pass (the boundary
 // tiles wait for the previous exchange, push their rows, notify) -- both compile-time, so the pass that runs one
 // partition on one GPU carries neither the other path's code nor its registers
-template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, bool STAMP = false, bool LISTED = true, bool PUSH = true>
+// DIAG: 0 = the timed kernel; 1 = phase stamps (tools/phase_stamps.py); 2 = data movement only: every load and every
+// store of the pass, neither face loop (cfdp_gpu_time_fused_movement: the floor bench.py reports beside the pass)
+template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, int DIAG = 0, bool LISTED = true, bool PUSH = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
@@ -819,6 +825,7 @@ void gg_fused_split_kernel(
   static_assert(KX >= KV && KX >= KG, "the shared row region must hold either set of rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LPP = 4;
+  constexpr bool STAMP = DIAG == 1;
   const int t = tile_begin + xcd_tile_bfirst(blockIdx.x, gridDim.x, PUSH && pa.tile_off && tile_begin == 0 ? pa.nbtiles : 0,
                                             (dbg & GG_DBG_REVERSE) != 0);
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -912,7 +919,11 @@ void gg_fused_split_kernel(
   }
   __syncthreads();
   if constexpr (STAMP) gg_stamp(dbg, t, 2);  // blob + gradient rows (+ var rows in registers) have landed
-  flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
+  if constexpr (DIAG == 2) {
+    if (tid < td.npts * 3) flux[(size_t)td.pstart * 3 + tid] = 0.0;  // the flux rows leave as they do in the real pass
+  } else {
+    flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
+  }
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 1);  // this wave is through its flux phase
   __syncthreads();  // every wave is done with the gradient rows: the region takes the var rows
   if constexpr (STAMP) gg_stamp(dbg, t, 3);  // flux phase done
@@ -920,8 +931,8 @@ void gg_fused_split_kernel(
   for (int k = 0; k < KV; k++) *reinterpret_cast<u32x4 *>(xbuf + (size_t)(tid + k * nthr) * 16) = vr[k];
   __syncthreads();  // vmcnt(0) + barrier
   if constexpr (STAMP) gg_stamp(dbg, t, 4);  // var rows in place
-  grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
-                                   CB * nthr * 16, PUSH ? &pa : nullptr, t);
+  grad_tile_compute<LPP, NT, true, 0, DIAG == 2>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
+                                                 CB * nthr * 16, PUSH ? &pa : nullptr, t);
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 2);  // this wave is through its gradient phase (stores issued)
   if constexpr (STAMP) gg_stamp(dbg, t, 5);  // gradient arithmetic done, row stores issued (wave 0)
   if constexpr (STAMP) {
@@ -1217,20 +1228,20 @@ template <bool R, int CB, int KV> hipError_t launch_flux_dma(const gg_args &a, b
   return launch(gg_flux_dma_kernel<8, R, false, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown);
 }
 
-template <bool R, bool N, bool S, bool L, bool P>
+template <bool R, bool N, int D, bool L, bool P>
 hipError_t launch_split(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
                         int dbgf, const gg_push_args &pa) {
-  return launch(gg_fused_split_kernel<R, N, 5, 4, 4, 4, S, L, P>, ntiles, block, (size_t)(5 + 4) * block * 16, stream, a.tiles, tile_begin,
+  return launch(gg_fused_split_kernel<R, N, 5, 4, 4, 4, D, L, P>, ntiles, block, (size_t)(5 + 4) * block * 16, stream, a.tiles, tile_begin,
                 a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa);
 }
 template <bool R, bool N>
 hipError_t launch_split_lp(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
                            int dbgf, const gg_push_args &pa) {
   const bool listed = a.rowlist != nullptr, pushing = pa.tile_off != nullptr;
-  if (listed) return pushing ? launch_split<R, N, false, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
-                             : launch_split<R, N, false, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
-  return pushing ? launch_split<R, N, false, false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
-                 : launch_split<R, N, false, false, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
+  if (listed) return pushing ? launch_split<R, N, 0, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                             : launch_split<R, N, 0, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
+  return pushing ? launch_split<R, N, 0, false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                 : launch_split<R, N, 0, false, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
 }
 
 template <int CB, int KV, int KG>
@@ -1333,14 +1344,20 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
   if (gg_fused_split && allow_split && cb <= 5 && kv <= 4 && kg <= 4) {
     if (gg_debug_flags & GG_DBG_STAMP) {  // diagnostic build of the same kernel: phase stamps (tools/phase_stamps.py)
       if (!a.rowlist) return hipErrorNotSupported;  // the stamped instantiation reads the fixed-stride row lists
-      return nt ? launch_split<false, true, true, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
-                : launch_split<false, false, true, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
+      return nt ? launch_split<false, true, 1, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                : launch_split<false, false, 1, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
+    }
+    if (gg_debug_flags & GG_DBG_MOVE) {  // data movement only (cfdp_gpu_time_fused_movement): results are zeros
+      if (!a.rowlist) return hipErrorNotSupported;
+      return nt ? launch_split<false, true, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                : launch_split<false, false, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     }
     if (refmode) return nt ? launch_split_lp<true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                            : launch_split_lp<true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     return nt ? launch_split_lp<false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
               : launch_split_lp<false, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
   }
+  if (gg_debug_flags & (GG_DBG_MOVE | GG_DBG_STAMP)) return hipErrorNotSupported;  // diagnostics exist for the phase-split form only
   // everything staged up front; the store slab (8 rows of 168 bytes per wave) must fit the gradient-row region
   const size_t slab = (size_t)(block / 64) * 8 * 21 * 8;
 #define FUSED_UPFRONT(CB, KV, KG)                                                                                   \

@@ -1049,6 +1049,60 @@ int cfdp_gpu_resident_qualifies(cfdp_gpu *g, const char **why) {
   return resident_qualifies(g, why) ? 1 : 0;
 }
 
+// The data-movement floor of the fused pass: the same kernel with neither face loop (a diagnostic instantiation:
+// every load, every store, zeros as results), timed exactly as cfdp_gpu_time_fused times the real pass.  What the
+// real pass takes beyond it is arithmetic and latency its resident tiles do not hide.  Leaves grad / flux holding one
+// correct iteration again.
+int cfdp_gpu_time_fused_movement(cfdp_gpu *g, int iters, float *ms_pass) {
+  NEED_UPLOAD(g);
+  if (iters < 1) return fail("iters must be >= 1");
+  if (!g->fusion || !g->d_grad_alt) return fail("fusion is off");
+  if (!g->d_rowlist) return fail("no fixed-stride row lists: the movement-only instantiation needs them");
+  if (flush_flux(g)) return 1;
+  hipStream_t st = g->s_main;
+  const int dbg0 = gg_debug_flags;
+  gg_debug_flags |= 0x40000;  // GG_DBG_MOVE
+  auto pass = [&]() -> int {
+    g->flux_pending = CFDP_FLUX_CONSISTENT;
+    if (launch_fused(g, CFDP_TILES_ALL, st)) return 1;
+    fused_done(g);
+    return 0;
+  };
+  int rc = 0;
+  for (int w = 0; w < 2 && !rc; w++) rc = pass();
+  iters += iters & 1;
+  hipGraph_t gr = nullptr;
+  hipGraphExec_t ge = nullptr;
+  hipError_t ec = hipSuccess;
+  if (!rc) {
+    ec = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (ec == hipSuccess) {
+      for (int i = 0; i < iters && !rc; i++) rc = pass();
+      ec = hipStreamEndCapture(st, &gr);
+    }
+  }
+  gg_debug_flags = dbg0;
+  g->flux_pending = -1;
+  if (rc) { if (gr) (void)hipGraphDestroy(gr); return 1; }
+  HIP_TRY(ec);
+  HIP_TRY(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+  HIP_TRY(hipGraphDestroy(gr));
+  g->main_marked = false;
+  HIP_TRY(hipGraphLaunch(ge, st));
+  HIP_TRY(hipEventRecord(g->ev_a, st));
+  HIP_TRY(hipGraphLaunch(ge, st));
+  HIP_TRY(hipEventRecord(g->ev_b, st));
+  HIP_TRY(hipEventSynchronize(g->ev_b));
+  HIP_TRY(hipGraphExecDestroy(ge));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, g->ev_a, g->ev_b));
+  if (ms_pass) *ms_pass = ms / (float)iters;
+  g->drop_graphs();
+  if (launch_grad(g, CFDP_TILES_ALL, st)) return 1;  // real values again
+  g->flux_pending = CFDP_FLUX_CONSISTENT;
+  return flush_flux(g);
+}
+
 // K iterations of one partition, replayed from hipGraphs whatever K is.
 // Fused mode: gradients(1), K-1 fused passes (flux(i) + gradients(i+1)), flux(K).  The passes are cut
 // into whole chunks of 50 (one graph, replayed), a remainder graph with the even part of what is left

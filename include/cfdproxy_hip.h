@@ -209,6 +209,10 @@ int  cfdp_gpu_time_schedule(cfdp_gpu *g, int steps, int with_exchange, int overl
  * any K runs without per-kernel stream launches; ms_total: device time of the K iterations      */
 int  cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode,
                              int use_graph, float *ms_total);
+/* the data-movement floor of the fused pass: the same kernel without its two face loops (every load and every store of
+ * the pass; a diagnostic instantiation), timed as cfdp_gpu_time_fused times the real one; ms_pass = milliseconds per
+ * pass.  grad / flux hold one correct iteration afterwards.                                                       */
+int  cfdp_gpu_time_fused_movement(cfdp_gpu *g, int iters, float *ms_pass);
 /* Tile-resident iterations (small partitions: the strong-scaling regime of the reference, README.txt:39-40 -- "everything
  * lives in cache"; the coarse levels of a V cycle).  mode 1: cfdp_gpu_run_iterations runs ALL its iterations in ONE launch
  * when the partition qualifies -- every tile co-resident on the device (<= 4 workgroups per CU), fused iterations on

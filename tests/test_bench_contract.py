@@ -25,6 +25,7 @@ def test_bench_line(gpu):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     # the three fractions side by side; the fused pass streams the face data once, so its unique bytes are fewer
     assert 0 < rf["frac_unique"] < rf["frac"] and rf["unique_bytes_per_launch"] < rf["algorithmic_bytes_per_launch"]
+    assert 0 < rf["movement_only_us"] < rf["us_per_launch"]  # the pass without its face loops: the data-movement floor
     assert "traffic_source" in rf and (rf["traffic"] is None or rf["traffic_source"]["file"].startswith("profiles/"))
     assert out["config"]["baseline_config"] == "dualgrid.12" and out["scaling"] == "strong"
     cb = out["cpu_baseline"]

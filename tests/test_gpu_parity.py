@@ -702,6 +702,26 @@ def test_exact_bench_path_full_field_against_the_oracle(gpu, orc, label, n, nd):
     part.free()
 
 
+def test_movement_only_instantiation_is_a_floor_and_leaves_real_values(gpu):
+    """cfdp_gpu_time_fused_movement: the fused pass without its face loops (what bench.py reports as
+    roofline.movement_only_us) is faster than the real pass, and grad / flux hold real values again afterwards"""
+    pkg = gpu
+    dom = pkg.gen_domain(pkg.gen_params(48, 40, 36, ndomains=1), 0)
+    pkg.fill_var(dom, None, pkg.VAR_HASH)
+    g = pkg.GpuPartition(dom)
+    g.set_fusion(True)
+    g.run_iterations(3, True, 0, use_graph=True)
+    g.pull_fields()
+    g0, f0 = dom.grad.copy(), dom.psd_flux.copy()
+    t_real = min(g.time_fused(40) for _ in range(3))
+    t_move = min(g.time_fused_movement(40) for _ in range(3))
+    assert 0.0 < t_move < t_real, (t_move, t_real)
+    g.pull_fields()
+    assert np.array_equal(dom.grad, g0) and np.array_equal(dom.psd_flux[: dom.nown], f0[: dom.nown])
+    g.close()
+    dom.free()
+
+
 # ------------------------------------------------------------------ tile-resident iterations (one launch for K iterations)
 def _resident_case(pkg, which):
     """partitions whose tiles are all co-resident on the device"""
@@ -769,7 +789,7 @@ def test_tile_resident_iterations_never_read_a_stale_row(gpu):
     pkg = gpu
     dom = pkg.gen_domain(pkg.gen_params(32, 32, 32, ndomains=1), 0)
     pkg.fill_var(dom, None, pkg.VAR_HASH)
-    g = pkg.GpuPartition(dom)
+    g = pkg.GpuPartition(dom, flux_lanes=4)  # (the lane split of the fused / resident flux phase: see the test above)
     g.set_fusion(True)
     g.run_iterations(1, True, 0, use_graph=False)
     g.pull_fields()
