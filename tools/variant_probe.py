@@ -1,10 +1,10 @@
-"""round-2 exploration (development helper): fused-pass / gradient / flux kernel times of one mesh for a
+"""development helper: fused-pass / gradient / flux kernel times of one mesh for a
 list of environment variations, all in one process.  CONFIGS="label:K=V,K=V;label2:..." SIZES=64,128"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
 m = load_package()
-out = open(os.environ.get("PROBE_OUT", "gpurun_out/r02_probe.log"), "a")
+out = open(os.environ.get("PROBE_OUT", "gpurun_out/variant_probe.log"), "a")
 def log(*a):
     s = " ".join(str(x) for x in a); print(s, flush=True); out.write(s + "\n"); out.flush()
 cfgs = []
