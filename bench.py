@@ -307,6 +307,7 @@ def main() -> None:
                 "transport": solver.transport if world > 1 else "none (one partition)",
                 "transport_probe_us_per_iteration": solver.probe if world > 1 else {},
                 "transport_probe_rows_arrived": solver.checks if world > 1 else {},
+                "transport_probe_validation": solver.validation if world > 1 else {},
                 "mesh_iterations_per_s": its, "via_dualgrid_files": not args.no_files,
                 "tiles": solver.gpu.stats["ntiles"], "tile_points": solver.gpu.stats["tile_points"],
                 "setup_s": round(t_setup, 2),

@@ -192,6 +192,10 @@ class RankSolver:
         self.available: List[str] = []
         self.probe: Dict[str, float] = {}
         self.checks: Dict[str, bool] = {}   # choose_transport: did every row arrive in its slot, per transport
+        # what the set-up validation of every attempted transport saw (all ranks hold the same all-reduced evidence):
+        # {"ipc / as configured": {"ok": False, "failed": "stale rows", "wait_timeouts": 0, "worst_mismatch": 0.31}, ...}
+        # -- the datum that says WHICH check a transport failed on a machine nobody could test on before
+        self.validation: Dict[str, dict] = {}
         if transport in ("ipc", "auto") and world > 1:
             import sys
             # a second attempt with a fine-grained landing block (every rank fails or passes alike:
@@ -201,11 +205,13 @@ class RankSolver:
                     if os.environ.get("CFDP_IPC_FINEGRAINED", "0") not in ("", "0"):
                         break
                     os.environ["CFDP_IPC_FINEGRAINED"] = "1"
+                self._validating = f"ipc / {attempt}"
                 try:
                     self._init_ipc()
                     self.available.append("ipc")
                     break
                 except Exception as e:
+                    self.validation.setdefault(self._validating, {"ok": False, "failed": f"setup: {e}"[:160]})
                     print(f"[rank {rank}] xGMI write+notify setup failed ({attempt}: {e})", file=sys.stderr)
             if "ipc" not in self.available and transport == "ipc":
                 transport = "rccl"
@@ -217,7 +223,9 @@ class RankSolver:
             try:
                 self._init_own_communicator()
                 self.available.append("rccl")
+                self.validation["rccl"] = {"ok": True, "failed": None, "check": "communicator created (values: exchange_check after the run)"}
             except Exception as e:  # keep going on the torch.distributed transport
+                self.validation["rccl"] = {"ok": False, "failed": f"setup: {e}"[:160]}
                 import sys
                 print(f"[rank {rank}] own RCCL communicator failed ({e}); using torch.distributed P2P", file=sys.stderr)
                 if transport == "rccl":
@@ -395,6 +403,7 @@ class RankSolver:
         var0 = part.var.copy()
         lib = self.gpu.lib
         lib.cfdp_ipc_set_wait_seconds(2.0)  # a broken mapping must not cost half a minute per iteration here
+        timeouts, worst, nothing_sent = 0, 0.0, False
         for scale in (1.0, 2.0, 1.0):
             part.var[:] = var0 * scale
             self.gpu._ck(self.gpu.lib.cfdp_gpu_set_var(self.gpu.h, part.sd.var))
@@ -405,8 +414,19 @@ class RankSolver:
                               float(self.gpu.ipc_error() != 0)], dtype=torch.float64, device=self._coll_device())
             dist.all_reduce(t)
             sent, got, err = (float(x) for x in t)
+            timeouts += int(err)
+            nothing_sent = nothing_sent or not sent > 0
+            if sent > 0:
+                worst = max(worst, abs(sent - got) / sent)
             good = good and err == 0 and sent > 0 and abs(sent - got) <= 1e-9 * sent
         lib.cfdp_ipc_set_wait_seconds(float(os.environ.get("CFDP_IPC_WAIT_SECONDS", "30")))
+        # WHICH check failed: a wait that gave up (the partner's flag never arrived: mapping / ordering), rows that
+        # arrived late or not at all although every flag did (stale rows: the L2 question of a coarse-grained block),
+        # or nothing to send
+        failed = None if good else ("wait timeout" if timeouts else "nothing sent" if nothing_sent else "stale rows")
+        self.validation[getattr(self, "_validating", self.transport)] = {
+            "ok": bool(good), "failed": failed, "wait_timeouts": timeouts, "worst_sum_mismatch": worst,
+            "check": "sum |sent rows| vs sum |ghost rows| over all ranks, 4 iterations each with var, 2 var, var"}
         return good
 
     def _init_own_communicator(self) -> None:

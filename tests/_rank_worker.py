@@ -90,6 +90,9 @@ def main():
             return
         for fusion in (False, True):
             solver = mg.RankSolver(part, rank, world, device, dist, transport=args.transport, tile_points=32, fusion=fusion)
+            if rank == 0:  # what the set-up validation saw, and which check a rejected transport failed
+                import json
+                print("VALIDATION " + json.dumps(solver.validation), flush=True)
             assert solver.transport == args.transport, solver.transport  # no silent fallback in the tests
             if args.soak:
                 solver.run_steps(args.soak, with_exchange=True, overlap=True)

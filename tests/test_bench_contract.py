@@ -168,8 +168,11 @@ def test_bench_gpus2_started_plainly_launches_two_ranks(gpu):
     """`python bench.py --gpus 2 --steps 20 --warmup 3` with NO rank environment (how the driver starts it): the
     process launches its two ranks itself -- sharing this box's one GPU -- and rank 0's line says n_gpus 2, the
     exchange check holds, the overlap report and the CPU baseline are there"""
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env["CFDP_SHARED_GPU"] = "1"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CFDP_SHARED_GPU")}
+    import torch
+    shared = torch.cuda.device_count() < 2
+    if shared:
+        env["CFDP_SHARED_GPU"] = "1"  # (on a box with >= 2 devices this is the real thing: one rank per GPU over xGMI)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
                         "--no-weak", "--cpu-samples", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
@@ -179,3 +182,8 @@ def test_bench_gpus2_started_plainly_launches_two_ranks(gpu):
     assert out["config"]["baseline_config"] == "dualgrid.24" and out["config"]["ghost_points_per_gpu"] > 0
     cb = out["cpu_baseline"]
     assert cb["value"] > 0 and "whole 64^3 mesh of this config as one domain" in cb["sample"]
+    # what the set-up validation of every attempted transport saw, and which check a rejected one failed
+    val = out["config"]["transport_probe_validation"]
+    assert any(k.startswith("ipc") and v["ok"] and v["failed"] is None for k, v in val.items()), val
+    if not shared:
+        assert "rccl" in val, val

@@ -37,7 +37,21 @@ for label, transport, env in cases:
         ok = ok and p.returncode == 0 and f"RANK_OK {r}" in out
         tails.append(out[-800:])
     results[label] = ok
-    print(f"{label:24s} {'PASSED' if ok else 'FAILED'}", flush=True)
+    # one line per transport: ok, or WHICH check failed (stale rows: every flag arrived, rows did not -- the question of
+    # a coarse-grained landing block behind another device's stores; wait timeout: a partner's flag never arrived)
+    why = ""
+    for line in tails[0].splitlines() if tails else []:
+        if line.startswith("VALIDATION "):
+            import json
+            try:
+                val = json.loads(line[len("VALIDATION "):])
+                bad = {k: v for k, v in val.items() if not v.get("ok")}
+                if bad:
+                    why = "; ".join(f"{k}: {v.get('failed')} (wait timeouts {v.get('wait_timeouts', '-')}, worst mismatch "
+                                    f"{v.get('worst_sum_mismatch', '-')})" for k, v in bad.items())
+            except Exception:
+                pass
+    print(f"{label:24s} {'PASSED' if ok else 'FAILED'}" + (f"  [{why}]" if why else ""), flush=True)
     if not ok:
         print("\n".join(tails), flush=True)
 sys.exit(0 if all(results.values()) else 1)
