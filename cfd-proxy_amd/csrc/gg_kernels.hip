@@ -813,7 +813,7 @@ __device__ __forceinline__ void gg_stamp_wave(int dbg, int ntiles, int tile, int
 // partition on one GPU carries neither the other path's code nor its registers
 // DIAG: 0 = the timed kernel; 1 = phase stamps (tools/phase_stamps.py); 2 = data movement only: every load and every
 // store of the pass, neither face loop (cfdp_gpu_time_fused_movement: the floor bench.py reports beside the pass)
-template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, int DIAG = 0, bool LISTED = true, bool PUSH = true, int ST = 0>
+template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, int DIAG = 0, bool LISTED = true, bool PUSH = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
@@ -931,7 +931,7 @@ void gg_fused_split_kernel(
   for (int k = 0; k < KV; k++) *reinterpret_cast<u32x4 *>(xbuf + (size_t)(tid + k * nthr) * 16) = vr[k];
   __syncthreads();  // vmcnt(0) + barrier
   if constexpr (STAMP) gg_stamp(dbg, t, 4);  // var rows in place
-  grad_tile_compute<LPP, NT, true, ST, DIAG == 2>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
+  grad_tile_compute<LPP, NT, true, 0, DIAG == 2>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
                                                  CB * nthr * 16, PUSH ? &pa : nullptr, t);
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 2);  // this wave is through its gradient phase (stores issued)
   if constexpr (STAMP) gg_stamp(dbg, t, 5);  // gradient arithmetic done, row stores issued (wave 0)
@@ -1346,12 +1346,6 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
       if (!a.rowlist) return hipErrorNotSupported;  // the stamped instantiation reads the fixed-stride row lists
       return nt ? launch_split<false, true, 1, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                 : launch_split<false, false, 1, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
-    }
-    if ((gg_debug_flags & 0x80000) && a.rowlist && !pa.tile_off && !refmode) {  // experiment: part-A rows stored sc1, 16 B per lane
-      if (nt) return launch(gg_fused_split_kernel<false, true, 5, 4, 4, 4, 0, true, false, 1>, ntiles, block, (size_t)(5 + 4) * block * 16, stream, a.tiles, tile_begin,
-                a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa);
-      return launch(gg_fused_split_kernel<false, false, 5, 4, 4, 4, 0, true, false, 1>, ntiles, block, (size_t)(5 + 4) * block * 16, stream, a.tiles, tile_begin,
-                a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa);
     }
     if (gg_debug_flags & GG_DBG_MOVE) {  // data movement only (cfdp_gpu_time_fused_movement): results are zeros
       if (!a.rowlist) return hipErrorNotSupported;
