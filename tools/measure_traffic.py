@@ -31,7 +31,7 @@ for n, label in ((64, "dualgrid.12 lvl 2 stand-in (64^3)"), (128, "dualgrid.384 
         d = os.path.join(out_dir, f"n{n}_{counters[0]}")
         cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                "python3", os.path.join(ROOT, "tools", "prof_one.py")]
-        e = dict(env, N=str(n), TP="0", L="0", PIPE="-1", ITERS="5")
+        e = dict(env, N=str(n), TP="0", L="0", ITERS="5")
         r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
         print(r.stdout[-300:], flush=True)
         f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
