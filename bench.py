@@ -161,9 +161,9 @@ def launch_ranks(n: int, argv: list, ndev: int, child_cmd=None, timeout: float =
                 p.wait(timeout=10)
             except Exception:
                 pass
-    if out0:
-        sys.stdout.write(out0)
-        sys.stdout.flush()
+    for line in out0.splitlines():  # the ONE JSON line goes to stdout; anything else rank 0 printed (library chatter) to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
     if rc == 0 and not any(l.startswith("{") for l in out0.splitlines()):
         print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
         rc = 1

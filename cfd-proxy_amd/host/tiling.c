@@ -147,6 +147,176 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
   }
 }
 
+/* EXPERIMENT (CFDP_GROW_FRONTS=M > 1; SURVEY section 8f-1 "tile growth on the device"): the growth a frontier-parallel
+ * device kernel would perform -- M tiles grow AT THE SAME TIME, one point per tile and round, a point joining the tile
+ * that claims it first -- run sequentially here so that its tiles can be measured (halo rows, face duplication, LDS
+ * class, kernel time) against the one-front growth above before anything is moved to the device.  Same budgets per
+ * tile; halo accounting by a per-front hash set.  The result is deterministic (fronts take turns in order). */
+typedef struct { int *key; unsigned *gen; unsigned cur; int mask; int count; } hset;
+static void hset_init(hset *h, int max_keys) {
+  int cap = 64;
+  while (cap < 4 * max_keys) cap *= 2;
+  h->key = cfdp_malloc((size_t)cap * sizeof(int));
+  h->gen = cfdp_calloc((size_t)cap, sizeof(unsigned));
+  h->cur = 1; h->mask = cap - 1; h->count = 0;
+}
+static void hset_reset(hset *h) {
+  if (++h->cur == 0) { memset(h->gen, 0, (size_t)(h->mask + 1) * sizeof(unsigned)); h->cur = 1; }
+  h->count = 0;
+}
+static int hset_has(const hset *h, int k) {
+  unsigned x = ((unsigned)k * 2654435761u) >> 7;
+  for (;;) {
+    x &= (unsigned)h->mask;
+    if (h->gen[x] != h->cur) return 0;
+    if (h->key[x] == k) return 1;
+    x++;
+  }
+}
+static void hset_add(hset *h, int k) {
+  unsigned x = ((unsigned)k * 2654435761u) >> 7;
+  for (;;) {
+    x &= (unsigned)h->mask;
+    if (h->gen[x] != h->cur) { h->gen[x] = h->cur; h->key[x] = k; h->count++; return; }
+    if (h->key[x] == k) return;
+    x++;
+  }
+}
+typedef struct {
+  int active, t, cnt, head, tail, first;  /* first: where the tile's points start in the front's member list */
+  long ninc, ninternal;
+  int *q;      /* BFS queue of this front: candidates in discovery order */
+  int *members;
+  hset seen;   /* members + halo points of the tile */
+} front;
+
+static void tiler_pass_multifront(tiler *T, const unsigned char *mask, int want, int TP, int M) {
+  const int nown = T->nown;
+  int remaining = 0;
+  for (int p = 0; p < nown; p++)
+    if (T->tile_of[p] < 0 && (!mask || mask[p] == want)) remaining++;
+  T->cursor = 0;
+  const int qcap = 64 * TP + 4096;
+  front *F = cfdp_calloc((size_t)M, sizeof(front));
+  for (int i = 0; i < M; i++) {
+    F[i].q = cfdp_malloc((size_t)qcap * sizeof(int));
+    F[i].members = cfdp_malloc((size_t)TP * sizeof(int));
+    hset_init(&F[i].seen, 40 * TP);
+  }
+  /* tiles are numbered when they OPEN; their points are appended to T->order when they CLOSE, so T->tile_first is
+   * rebuilt at the end from the closing order */
+  int *close_tile = cfdp_malloc(((size_t)nown + 1) * sizeof(int)), nclosed = 0;
+  int *close_first = cfdp_malloc(((size_t)nown + 2) * sizeof(int));
+  const int t_base = T->ntiles;
+  int opened = 0;
+  while (remaining > 0) {
+    int progressed = 0;
+    for (int i = 0; i < M && remaining > 0; i++) {
+      front *f = &F[i];
+      if (!f->active) { /* open a tile from a seed */
+        int seed = -1;
+        while (T->sq_head < T->sq_tail) {
+          int q = T->seedq[T->sq_head++];
+          if (T->tile_of[q] < 0 && (!mask || mask[q] == want)) { seed = q; break; }
+        }
+        while (seed < 0 && T->cursor < nown) {
+          int q = T->cursor++;
+          if (T->tile_of[q] < 0 && (!mask || mask[q] == want)) seed = q;
+        }
+        if (seed < 0) continue;
+        f->active = 1; f->t = t_base + opened++; f->cnt = 0; f->head = 0; f->tail = 0; f->ninc = f->ninternal = 0;
+        hset_reset(&f->seen);
+        f->q[f->tail++] = seed;
+      }
+      /* one point for this front: the next unclaimed candidate */
+      int took = 0, close = 0;
+      while (f->head < f->tail && !took) {
+        const int p = f->q[f->head++];
+        if (T->tile_of[p] >= 0) continue; /* claimed by another front meanwhile */
+        int internal_add = 0, newrows = hset_has(&f->seen, p) ? 0 : 1;
+        for (int e = T->xadj[p]; e < T->xadj[p + 1]; e++) {
+          const int q = T->adj_other[e];
+          if (q < nown && q != p && T->tile_of[q] == f->t) internal_add++;
+          if (!hset_has(&f->seen, q)) newrows++;
+        }
+        if (T->blob_cap > 0 && f->cnt >= 1) {
+          const long I2 = f->ninc + (T->xadj[p + 1] - T->xadj[p]), E2 = I2 - (f->ninternal + internal_add);
+          const long blob = cfdp_blob_fn_bytes((int)E2) + cfdp_blob_inc_bytes((int)I2) + cfdp_blob_off_bytes(f->cnt + 1);
+          if (blob > T->blob_cap || f->seen.count + newrows > T->rows_cap) {
+            f->head--; /* p stays un-tiled and seeds a later tile */
+            close = 1;
+            break;
+          }
+        }
+        T->tile_of[p] = f->t;
+        f->members[f->cnt++] = p;
+        remaining--;
+        f->ninc += T->xadj[p + 1] - T->xadj[p];
+        f->ninternal += internal_add;
+        hset_add(&f->seen, p);
+        for (int e = T->xadj[p]; e < T->xadj[p + 1]; e++) {
+          const int q = T->adj_other[e];
+          hset_add(&f->seen, q);
+          if (q >= nown || T->tile_of[q] >= 0) continue;
+          if (mask && mask[q] != want) continue;
+          if (f->tail < qcap) f->q[f->tail++] = q; /* (duplicates are skipped when popped) */
+        }
+        took = 1;
+        progressed = 1;
+      }
+      if (!took && !close) close = 1; /* the front ran dry */
+      if (f->cnt >= TP) close = 1;
+      if (f->cnt >= 4 && f->seen.count - f->cnt > T->halo_cap) close = 1;
+      if (close) {
+        if (f->cnt > 0) {
+          close_tile[nclosed] = f->t;
+          close_first[nclosed] = T->norder;
+          for (int k = 0; k < f->cnt; k++) T->order[T->norder++] = f->members[k];
+          nclosed++;
+        } else {
+          opened--; /* (the tile number is given back only if it was the last one opened; else it stays empty) */
+          if (f->t != t_base + opened) { opened++; close_tile[nclosed] = f->t; close_first[nclosed] = T->norder; nclosed++; }
+        }
+        for (int k = f->head; k < f->tail; k++) { /* its frontier seeds later tiles */
+          const int q = f->q[k];
+          if (T->tile_of[q] < 0 && T->sq_tail < 2 * nown) T->seedq[T->sq_tail++] = q;
+        }
+        f->active = 0;
+        progressed = 1;
+      }
+    }
+    if (!progressed) break;
+  }
+  for (int i = 0; i < M; i++) /* close what is still open */
+    if (F[i].active && F[i].cnt > 0) {
+      close_tile[nclosed] = F[i].t;
+      close_first[nclosed] = T->norder;
+      for (int k = 0; k < F[i].cnt; k++) T->order[T->norder++] = F[i].members[k];
+      nclosed++;
+    }
+  CFDP_ASSERT(remaining == 0);
+  /* renumber the tiles of this pass in closing order (the order their points were appended in) */
+  int *renum = cfdp_malloc(((size_t)opened + 1) * sizeof(int));
+  for (int k = 0; k < opened; k++) renum[k] = -1;
+  int nt = 0;
+  for (int k = 0; k < nclosed; k++) {
+    const int next_first = k + 1 < nclosed ? close_first[k + 1] : T->norder;
+    if (next_first == close_first[k]) continue; /* an empty tile */
+    renum[close_tile[k] - t_base] = t_base + nt;
+    tiler_open_tile(T);
+    T->tile_first[T->ntiles] = close_first[k];
+    T->ntiles++;
+    nt++;
+  }
+  for (int i = 0; i < nown; i++)
+    if (T->tile_of[i] >= t_base && T->tile_of[i] - t_base < opened && renum[T->tile_of[i] - t_base] >= 0 &&
+        (!mask || mask[i] == want))
+      T->tile_of[i] = renum[T->tile_of[i] - t_base];
+  free(renum); free(close_tile); free(close_first);
+  for (int i = 0; i < M; i++) { free(F[i].q); free(F[i].members); free(F[i].seen.key); free(F[i].seen.gen); }
+  free(F);
+}
+
 /* small open-addressing map key -> first-touch index, cleared in O(1) by a generation count */
 typedef struct { int *key, *val; unsigned *gen; unsigned cur; int mask; } lmap;
 static void lmap_init(lmap *m, int max_keys) {
@@ -446,6 +616,11 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
     const char *hc = getenv("CFDP_HALO_CAP"); /* experiments */
     if (hc && atoi(hc) > 0) T.halo_cap = atoi(hc);
   }
+  int grow_fronts = 1; /* experiment: tiles grown at the same time (what a frontier-parallel device growth does) */
+  {
+    const char *e = getenv("CFDP_GROW_FRONTS");
+    if (e && atoi(e) > 1) grow_fronts = atoi(e);
+  }
   if (any_send && o.boundary_first) {
     int btp = o.tile_points / 2 < 8 ? 8 : o.tile_points / 2; /* sheets have big halos */
     tiler_pass(&T, is_send, 1, btp);
@@ -456,9 +631,11 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
      * push the kernels into the next LDS capacity class and down to 2 workgroups per CU) */
     memset(T.seeded, 0, (size_t)nown);
     T.sq_head = T.sq_tail = 0;
-    tiler_pass(&T, is_send, 0, o.tile_points);
+    if (grow_fronts > 1) tiler_pass_multifront(&T, is_send, 0, o.tile_points, grow_fronts);
+    else tiler_pass(&T, is_send, 0, o.tile_points);
   } else {
-    tiler_pass(&T, NULL, 0, o.tile_points);
+    if (grow_fronts > 1) tiler_pass_multifront(&T, NULL, 0, o.tile_points, grow_fronts);
+    else tiler_pass(&T, NULL, 0, o.tile_points);
     P->nbtiles = 0;
   }
   CFDP_ASSERT(T.norder == nown);
