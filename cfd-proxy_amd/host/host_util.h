@@ -48,5 +48,6 @@ static inline double cfdp_u01(uint64_t key) { /* (0,1) */
 }
 
 double cfdp_now(void); /* seconds, monotonic */
+int cfdp_host_threads(void); /* threads for the library's own OpenMP regions: the cores really granted (dualgrid_gen.c) */
 
 #endif

@@ -352,7 +352,7 @@ static int host_csr(const solver_data *sd, int **xadj_out, int **adj_face_out, i
   const int nown = sd->nownpoints, nf = sd->nfaces;
   int *xadj = cfdp_calloc((size_t)nown + 2, sizeof(int));
   long used = 0;
-#pragma omp parallel reduction(+ : used)
+#pragma omp parallel reduction(+ : used) num_threads(cfdp_host_threads())
   {
     const int nth = omp_get_num_threads(), th = omp_get_thread_num();
     const int lo = (int)((long)nown * th / nth), hi = (int)((long)nown * (th + 1) / nth);
@@ -369,7 +369,7 @@ static int host_csr(const solver_data *sd, int **xadj_out, int **adj_face_out, i
   int *adj_other = cfdp_malloc((size_t)(nadj ? nadj : 1) * sizeof(int));
   int *fill = cfdp_malloc((size_t)nown * sizeof(int));
   memcpy(fill, xadj, (size_t)nown * sizeof(int));
-#pragma omp parallel
+#pragma omp parallel num_threads(cfdp_host_threads())
   {
     const int nth = omp_get_num_threads(), th = omp_get_thread_num();
     const int lo = (int)((long)nown * th / nth), hi = (int)((long)nown * (th + 1) / nth);
@@ -416,7 +416,7 @@ static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P
       P->blob = cfdp_malloc((size_t)(P->blob_bytes ? P->blob_bytes : 16));
       P->halo_idx = cfdp_malloc((size_t)(P->nhalo_total ? P->nhalo_total : 1) * sizeof(int));
     }
-#pragma omp parallel reduction(+ : dup_total, inc_total) reduction(| : bad)
+#pragma omp parallel reduction(+ : dup_total, inc_total) reduction(| : bad) num_threads(cfdp_host_threads())
     {
       lmap fmap, hmap;
       lmap_init(&fmap, max_inc);
@@ -663,19 +663,29 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
         memcpy(tfill, txadj, (size_t)nt * sizeof(int));
         for (int t = 0; t < nt; t++) tstamp[t] = -1;
       }
-      for (int t = 0; t < nt; t++)
-        for (int i = T.tile_first[t]; i < T.tile_first[t + 1]; i++) {
-          int p = T.order[i];
-          for (int e = xadj[p]; e < xadj[p + 1]; e++) {
-            int q = adj_other[e];
-            if (q >= nown) continue;
-            int u = T.tile_of[q];
-            if (u == t || tstamp[u] == t) continue;
-            tstamp[u] = t;
-            if (pass == 0) txadj[t + 1]++;
-            else tadj[tfill[t]++] = u;
+      /* (tiles are independent here: every thread keeps its own stamp array; a tile's neighbours are found in
+       * the same order whatever the thread count, so the plan does not depend on it) */
+#pragma omp parallel num_threads(cfdp_host_threads())
+      {
+        int *st = cfdp_malloc((size_t)nt * sizeof(int));
+        for (int t = 0; t < nt; t++) st[t] = -1;
+#pragma omp for schedule(static)
+        for (int t = 0; t < nt; t++)
+          for (int i = T.tile_first[t]; i < T.tile_first[t + 1]; i++) {
+            int p = T.order[i];
+            for (int e = xadj[p]; e < xadj[p + 1]; e++) {
+              int q = adj_other[e];
+              if (q >= nown) continue;
+              int u = T.tile_of[q];
+              if (u == t || st[u] == t) continue;
+              st[u] = t;
+              if (pass == 0) txadj[t + 1]++;
+              else tadj[tfill[t]++] = u;
+            }
           }
-        }
+        free(st);
+      }
+      PLAN_STAGE(pass == 0 ? "  (tile graph: count)" : "  (tile graph: fill)");
       if (pass == 1) {
         tiler S;
         memset(&S, 0, sizeof S);
@@ -694,6 +704,7 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
         S.sq_head = S.sq_tail = 0;
         tiler_pass(&S, cls, 0, o.supertile);
         CFDP_ASSERT(S.norder == nt);
+        PLAN_STAGE("  (supertile growth)");
         /* rebuild the point order, tile starts and tile_of for the new tile sequence */
         int *norder = cfdp_malloc((size_t)nown * sizeof(int));
         int *nfirst = cfdp_malloc((size_t)(nt + 1) * sizeof(int));
