@@ -263,8 +263,9 @@ def main() -> None:
                 solver.gpu.run_iterations(steps, with_flux=True, use_graph=True)
             else:
                 solver.run_steps(steps, **kw)
-            solver.synchronize()
-            barrier()
+            solver.synchronize()   # device sync (+ torch.cuda.synchronize): every rank's K steps are done ...
+            if dist is not None:
+                dist.barrier()     # ... on every rank (nothing is in flight any more: no second sync behind it)
             dt = time.perf_counter() - t
             if dist is not None:
                 tt = torch.tensor([dt], dtype=torch.float64, device=coll_device)
