@@ -388,30 +388,20 @@ def main() -> None:
             out["roofline"]["movement_only_note"] = str(e)[:160]
     out["roofline"]["traffic_source"] = traffic_src
 
-    # ---- --gpus 2 / 4: the weak-scaling point of the same run (262,144 owned points per GPU) ----
-    if world in (2, 4) and cfg["name"] != "weak" and not args.no_weak:
-        solver.close()
-        part.free()
-        solver = part = None
-        try:
-            wres, _, _ = measure(mg.bench_config("weak", world))
-            out["weak_scaling"] = {k: wres[k] for k in ("value", "ms_per_step", "scaling", "config", "exchange_check", "overlap")
-                                   if k in wres}
-        except Exception as e:  # the extra must never cost the line
-            out["weak_scaling"] = {"error": repr(e)[:300]}
-
-    # ---- --gpus 8: BASELINE config 4 (dualgrid.192 lvl 2, ~33 k points per GPU: the strong-scaling point) rides along ----
-    if world == 8 and cfg["name"] != "dualgrid.192" and not args.no_strong:
+    # ---- what rides along: --gpus 2 / 4 the weak-scaling point of the same run (262,144 owned points per GPU);
+    # --gpus 8 BASELINE config 4 (dualgrid.192 lvl 2, ~33 k points per GPU: the strong-scaling point) ----
+    extra = mg.bench_extra(cfg["name"], world)
+    if extra and not (args.no_weak if extra[0] == "weak_scaling" else args.no_strong):
         if solver is not None:
             solver.close()
             part.free()
             solver = part = None
         try:
-            sres, _, _ = measure(mg.bench_config("dualgrid.192", world))
-            out["strong_scaling"] = {k: sres[k] for k in ("value", "ms_per_step", "scaling", "config", "exchange_check", "overlap")
-                                     if k in sres}
+            xres, _, _ = measure(mg.bench_config(extra[1], world))
+            out[extra[0]] = {k: xres[k] for k in ("value", "ms_per_step", "scaling", "config", "exchange_check", "overlap")
+                             if k in xres}
         except Exception as e:  # the extra must never cost the line
-            out["strong_scaling"] = {"error": repr(e)[:300]}
+            out[extra[0]] = {"error": repr(e)[:300]}
 
     if world > 1:
         # the other ranks are done: the CPU baseline below runs on rank 0's host cores alone

@@ -77,6 +77,17 @@ def default_bench_config(n_ranks: int) -> str:
     return {1: "dualgrid.12", 2: "dualgrid.24", 4: "dualgrid.48", 8: "dualgrid.384"}.get(n_ranks, "weak")
 
 
+def bench_extra(name: str, n_ranks: int):
+    """the measurement that rides along with a bench run of config `name` on n_ranks GPUs, as (key of the JSON line,
+    config): the weak-scaling point at 2 / 4 GPUs, BASELINE config 4 (dualgrid.192, the strong-scaling point at ~33 k
+    points per GPU) at 8; None otherwise"""
+    if n_ranks in (2, 4) and name != "weak":
+        return "weak_scaling", "weak"
+    if n_ranks == 8 and name != "dualgrid.192":
+        return "strong_scaling", "dualgrid.192"
+    return None
+
+
 def bench_config(name: str, n_ranks: int) -> dict:
     """one bench workload: lattice, number of domains (whole domains per GPU), the text of
     config.workload and the scaling label of the series the run belongs to"""

@@ -46,6 +46,11 @@ def test_bench_configs_name_the_baseline_workloads(pkg):
     c = mg.bench_config("dualgrid.384", 8)
     assert c["dims"] == (128, 128, 128) and "48 per GPU" in c["workload"] and c["scaling"] == "weak"
     assert mg.bench_config("weak", 4)["dims"] == (128, 128, 64)
+    # what rides along with a run: the weak point at 2 / 4 GPUs, BASELINE config 4 at 8 (and nothing twice)
+    assert mg.bench_extra("dualgrid.24", 2) == ("weak_scaling", "weak") and mg.bench_extra("dualgrid.48", 4) == ("weak_scaling", "weak")
+    assert mg.bench_extra("dualgrid.384", 8) == ("strong_scaling", "dualgrid.192")
+    assert mg.bench_extra("dualgrid.192", 8) is None and mg.bench_extra("weak", 4) is None and mg.bench_extra("dualgrid.12", 1) is None
+    assert mg.bench_config(mg.bench_extra("dualgrid.384", 8)[1], 8)["ndomains"] == 192
     with pytest.raises(ValueError):
         mg.bench_config("dualgrid.12", 8)  # 12 domains do not divide over 8 GPUs
     with pytest.raises(ValueError):
