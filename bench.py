@@ -274,7 +274,9 @@ def main() -> None:
             return dt
 
         def exchange_check() -> dict:
-            return solver.exchange_check()
+            # after the timed region: every sent row in its slot, no wait gave up, and -- 50 more steps in the scaled
+            # field -- no flux phase read a ghost row of an earlier exchange (a constant field would hide that)
+            return solver.exchange_check(stale_read_steps=50)
 
         # warmup (untimed), then EXACTLY K timed steps; a transport whose rows did not all arrive is dropped
         # and the measurement repeated on the next one (every rank sees the same gathered check)

@@ -196,6 +196,12 @@ def _declare_host(lib: C.CDLL) -> None:
     lib.cfdp_host_version.restype = C.c_char_p
 
 
+class ScaledCheck(C.Structure):
+    """cfdp_scaled_check (cfdproxy_hip.h): the evidence of a scaled-field validation run"""
+    _fields_ = [("iterations", C.c_int), ("flux_checks", C.c_int), ("mismatches", C.c_int), ("first_iteration", C.c_int),
+                ("first_point", C.c_int), ("first_component", C.c_int), ("seen", C.c_double), ("expected", C.c_double)]
+
+
 def _declare_hip(lib: C.CDLL) -> None:
     P = C.POINTER
     vp = C.c_void_p
@@ -242,6 +248,8 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_time_kernels.argtypes = [vp, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]
     lib.cfdp_gpu_run_iterations.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]
     lib.cfdp_gpu_prepare_iterations.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.cfdp_gpu_scaled_check_begin.argtypes = [vp]
+    lib.cfdp_gpu_scaled_check_end.argtypes = [vp, P(ScaledCheck)]
     lib.cfdp_rccl_load.argtypes = [C.c_char_p]
     lib.cfdp_rccl_unique_id.argtypes = [vp]
     lib.cfdp_gpu_rccl_init.argtypes = [vp, vp, C.c_int, C.c_int, P(C.c_int)]
@@ -251,6 +259,9 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_ipc_export.argtypes = [vp, vp, P(C.c_size_t)]
     lib.cfdp_gpu_ipc_connect.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_size_t]
     lib.cfdp_gpu_ipc_ready.argtypes = [vp]
+    lib.cfdp_gpu_ipc_export_flags.argtypes = [vp, vp]
+    lib.cfdp_gpu_ipc_connect_flags.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.cfdp_gpu_ipc_mode.argtypes = [vp]
     lib.cfdp_gpu_ipc_enable.argtypes = [vp, C.c_int]
     lib.cfdp_gpu_ipc_disconnect.argtypes = [vp]
     lib.cfdp_gpu_ipc_error.argtypes = [vp]
@@ -756,6 +767,23 @@ class GpuPartition:
         self._ck(self.lib.cfdp_gpu_ipc_connect(self.h, slot, C.create_string_buffer(handle, 64), land_off0, land_off1,
                                                flag_off))
 
+    def ipc_export_flags(self) -> bytes:
+        """handle of the block holding this rank's flag words (the main block's again unless CFDP_IPC_MODE=split)"""
+        buf = C.create_string_buffer(64)
+        self._ck(self.lib.cfdp_gpu_ipc_export_flags(self.h, buf))
+        return buf.raw
+
+    def ipc_connect_flags(self, slot: int, flags_handle: bytes, flag_off: int) -> None:
+        self._ck(self.lib.cfdp_gpu_ipc_connect_flags(self.h, slot, C.create_string_buffer(flags_handle, 64), flag_off))
+
+    def ipc_mode(self) -> dict:
+        m = self.lib.cfdp_gpu_ipc_mode(self.h)
+        if m < 0:
+            return {}
+        return {"push": "in the fused pass" if m & 1 else "push kernel", "wait": "in the fused pass" if m & 2 else "wait kernel",
+                "notify": "per partner" if m & 4 else "all partners by the last boundary tile",
+                "memory": ("coarse-grained", "fine-grained", "split: fine-grained flags, coarse-grained arenas")[(m >> 4) & 3]}
+
     def ipc_ready(self) -> None:
         self._ck(self.lib.cfdp_gpu_ipc_ready(self.h))
 
@@ -827,6 +855,16 @@ class GpuPartition:
     def prepare_iterations(self, iters: int, with_flux: bool = True, flux_mode: int = FLUX_CONSISTENT) -> None:
         """capture the hipGraphs run_iterations(iters) replays, without executing anything"""
         self._ck(self.lib.cfdp_gpu_prepare_iterations(self.h, iters, int(with_flux), flux_mode))
+
+    def scaled_check_begin(self) -> None:
+        """the flux held now becomes the reference; from here every step ends with the validation kernel (compare the
+        flux with reference * 2^e, then var *= 2, 2, 1/4, ...): cfdp_gpu_scaled_check_begin"""
+        self._ck(self.lib.cfdp_gpu_scaled_check_begin(self.h))
+
+    def scaled_check_end(self) -> dict:
+        r = ScaledCheck()
+        self._ck(self.lib.cfdp_gpu_scaled_check_end(self.h, C.byref(r)))
+        return {k: getattr(r, k) for k, _ in ScaledCheck._fields_}
 
     def close(self) -> None:
         if self.h:

@@ -23,8 +23,11 @@ struct gg_grad_view {
 // xGMI write + notify done by the tiles themselves (fused pass): per boundary tile t the entries
 // [tile_off[t], tile_off[t+1]) name its send rows -- ent = tile-local point | partner slot << 16,
 // ent_row = row in that partner's landing slice; dst[slot] = that slice (this iteration's parity).
-// `done` counts finished boundary tiles; the last one raises the iteration counter in every
-// partner's flag word.  tile_off == nullptr: no push.
+// done[0] counts finished boundary tiles (the last one moves hdr[GG_IPC_ITER]); tile_off == nullptr: no push.
+// Notification, coarse protocol (need == nullptr): the last boundary tile raises the iteration counter in EVERY
+// partner's flag word.  Per-partner protocol: done[1 + s] counts the finished tiles that hold send rows for partner
+// slot s, need[s] of them exist; the one that completes s raises s's flag at once; tile_mask[t] = the partner slots
+// boundary tile t sends to (bit s) = the flags it waits for at the top of the next pass.
 struct gg_push_args {
   const int *tile_off;
   const int *ent;
@@ -33,7 +36,10 @@ struct gg_push_args {
   int *hdr;
   int *const *rflag;
   int *done;
+  const int *need;
+  const unsigned long long *tile_mask;
   int nbtiles, nslots;
+  int inv_after_flag;  // explicit buffer_inv sc0 sc1 once a tile has seen its partners' flags
   // > 0: the boundary tiles (the only ones that read ghost rows) first wait -- bounded -- until every partner's
   // rows of the PREVIOUS exchange have arrived: the job of gg_wait_kernel done at the top of the next pass, so
   // that an iteration is ONE launch (no wait kernel, no kernel boundary behind it)
@@ -82,6 +88,14 @@ hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row
                           const gg_grad_view &grad, double *const *dst, hipStream_t stream);
 hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, hipStream_t stream);
 hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, hipStream_t stream);
+// scaled-field validation of an exchange (gg_validate_kernel): words of its device-side state block (16 ints, 8-byte
+// aligned): gradient launches so far, flux fields compared, mismatching values (64 bit), first mismatch (claimed,
+// iteration, seen, expected, index into flux[nown][3]), the ticket of the last-block election
+enum { GG_V_ITER = 0, GG_V_CHECKS = 1, GG_V_BAD = 2, GG_V_CLAIM = 4, GG_V_FIRST_ITER = 5, GG_V_SEEN = 6, GG_V_EXPECT = 8,
+       GG_V_FIRST_IDX = 10, GG_V_TICKET = 11, GG_V_WORDS = 16 };
+hipError_t gg_launch_validate(double *var, int nall, const double *flux, const double *fref, const unsigned char *skip,
+                              int nown, int lag, bool do_scale, int *state, hipStream_t stream);
+hipError_t gg_launch_scale_var(double *var, int nall, double factor, hipStream_t stream);
 // tile-resident iterations (gg_resident_kernel): K iterations in ONE launch, one workgroup per tile staying for all
 // of them; the iteration boundary is a drained-flag hand-off between neighbouring tiles
 struct gg_resident_args {

@@ -319,12 +319,20 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
 }
 
 // The wait for the previous exchange, at the top of a boundary tile of the next pass (see gg_push_args::
-// wait_polls; the protocol is gg_wait_kernel's).  hdr[GG_IPC_ITER] = exchanges this rank has announced so far:
-// it only changes when the LAST boundary tile of a launch has finished, i.e. after every tile's wait here.
-__device__ __forceinline__ void wait_previous_exchange(const gg_push_args &pa, int tile, int tid) {
+// wait_polls; the protocol is gg_wait_kernel's).  iter0 = hdr[GG_IPC_ITER] = exchanges this rank has announced so
+// far, read once at the top of the pass: it only changes when the LAST boundary tile of a launch has finished, i.e.
+// after every tile's wait here.
+// Per-partner protocol (pa.need != nullptr; the reference's receiving thread waits only for the partners it needs,
+// src/exchange_data_gaspi.c:389-416): the tile polls the flags of the partners it SENDS to (pa.tile_mask).  Those
+// are the partners whose ghost rows it may read (the host has checked: a tile reads ghost rows only of partners it
+// holds send points for), and their flag k also says that they are done reading what this tile is about to overwrite
+// in their arena of the same parity (a partner raises its flag k towards this rank only when all its tiles that hold
+// send rows for -- hence may read ghost rows from -- this rank have finished pass k).
+__device__ __forceinline__ void wait_previous_exchange(const gg_push_args &pa, int tile, int tid, int iter0) {
   if (!pa.tile_off || pa.wait_polls <= 0 || tile >= pa.nbtiles) return;  // uniform per workgroup
-  if (tid < pa.nslots && !pa.hdr[GG_IPC_ERR]) {
-    const int need = pa.hdr[GG_IPC_ITER];
+  const bool mine = tid < pa.nslots && (!pa.need || ((pa.tile_mask[tile] >> tid) & 1ull));
+  if (mine && !pa.hdr[GG_IPC_ERR]) {
+    const int need = iter0;
     bool ok = false;
     for (long k = 0; k < pa.wait_polls && !ok; k++) {
       ok = __hip_atomic_load(&pa.hdr[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
@@ -338,22 +346,44 @@ __device__ __forceinline__ void wait_previous_exchange(const gg_push_args &pa, i
       atomicAdd(&pa.hdr[GG_IPC_ERR + 4], 1);
     }
   }
+  // rows in a coarse-grained arena behind flags another device raised: drop whatever this CU's L1 / this XCD's L2
+  // still hold of them before the first row is requested (the acquire loads above imply it; said once more, by name)
+  if (pa.inv_after_flag && tid < 64) asm volatile("buffer_inv sc0 sc1" ::: "memory");
   __syncthreads();
 }
 
-// After the pushes of a boundary tile: count it; the last one of the launch raises this rank's
-// iteration counter in every partner's flag word (gg_notify_kernel's job, done in place).  Every
-// thread has made its remote stores visible (system-scope fence) before the tile is counted.
-__device__ __forceinline__ void push_tile_done(const gg_push_args &pa, int tile, int tid) {
+// After the pushes of a boundary tile: count it.  Every thread has made its remote stores visible (system-scope
+// fence) before the tile is counted.
+// Coarse protocol (pa.need == nullptr): ONE counter; the last boundary tile of the launch raises this rank's iteration
+// counter in every partner's flag word (gg_notify_kernel's job, done in place).
+// Per-partner protocol: one counter per partner slot, need[s] = the boundary tiles that hold send rows for partner s;
+// the tile that completes partner s's rows raises s's flag AT ONCE -- the reference's thread that completes partner
+// k's buffer fires k's send (src/threads.c:268-311) -- while other boundary tiles are still computing.
+__device__ __forceinline__ void push_tile_done(const gg_push_args &pa, int tile, int tid, int iter0) {
   if (!pa.tile_off || tile >= pa.nbtiles) return;  // uniform per workgroup
   __threadfence_system();
   __syncthreads();
+  const int it = iter0 + 1;
+  if (pa.need) {  // lane s of wave 0 looks after partner slot s (at most GG_IPC_MAXSLOTS = 48 of them)
+    if (tid < pa.nslots && ((pa.tile_mask[tile] >> tid) & 1ull)) {
+      if (atomicAdd(&pa.done[1 + tid], 1) == pa.need[tid] - 1) {
+        pa.done[1 + tid] = 0;  // nobody counts this slot again before the next launch
+        __threadfence();
+        __hip_atomic_store(pa.rflag[tid], it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    // (same wave, program order: the slot counters above are taken before the tile counts itself finished)
+    if (tid == 0 && atomicAdd(&pa.done[0], 1) == pa.nbtiles - 1) {
+      pa.done[0] = 0;
+      pa.hdr[GG_IPC_ITER] = it;
+    }
+    return;
+  }
   if (tid == 0) {
-    const int old = atomicAdd(pa.done, 1);
+    const int old = atomicAdd(&pa.done[0], 1);
     if (old == pa.nbtiles - 1) {
       __threadfence();
-      *pa.done = 0;  // nobody counts again before the next launch
-      const int it = pa.hdr[GG_IPC_ITER] + 1;
+      pa.done[0] = 0;  // nobody counts again before the next launch
       for (int s = 0; s < pa.nslots; s++)
         __hip_atomic_store(pa.rflag[s], it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       pa.hdr[GG_IPC_ITER] = it;
@@ -710,7 +740,8 @@ void gg_fused_dma_kernel(
   const cfdp_tile_desc td = tiles[t];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
-  wait_previous_exchange(pa, t, tid);  // before any ghost row is requested
+  const int iter0 = pa.tile_off && t < pa.nbtiles ? pa.hdr[GG_IPC_ITER] : 0;  // uniform: a scalar load
+  wait_previous_exchange(pa, t, tid, iter0);  // before any ghost row is requested
   const int *hid = halo_idx + td.halo_off;
   const int hmax = td.nhalo > 0 ? td.nhalo - 1 : 0;
   // (1) halo row numbers of this thread's var pieces (4 per row) and gradient pieces (5 per row)
@@ -771,7 +802,7 @@ void gg_fused_dma_kernel(
   flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(gbuf), dbg,
                                    CB * nthr * 16, &pa, t);
-  push_tile_done(pa, t, tid);
+  push_tile_done(pa, t, tid, iter0);
 }
 
 // --------------------------------------------------------------------------- pack/unpack
@@ -835,7 +866,11 @@ void gg_fused_split_kernel(
   if ((dbg & GG_DBG_STAMP) && tid == 0 && gg_stamp_buf)  // which CU: HW_ID (cu, sh, se) and XCC_ID
     gg_stamp_buf[(size_t)t * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                                      (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-  if constexpr (PUSH) wait_previous_exchange(pa, t, tid);  // before any ghost row is requested
+  int iter0 = 0;
+  if constexpr (PUSH) {
+    if (pa.tile_off && t < pa.nbtiles) iter0 = pa.hdr[GG_IPC_ITER];  // uniform: a scalar load
+    wait_previous_exchange(pa, t, tid, iter0);  // before any ghost row is requested
+  }
   int hv[KV], hg[KG], part[KG], rloc[KG];
   // with a fixed-stride row list the row numbers are requested before the descriptor is even here:
   // descriptor -> blob and row list -> rows are two chains of two round trips instead of one of three
@@ -939,7 +974,7 @@ void gg_fused_split_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     gg_stamp(dbg, t, 6);  // wave 0's stores acknowledged
   }
-  if constexpr (PUSH) push_tile_done(pa, t, tid);
+  if constexpr (PUSH) push_tile_done(pa, t, tid, iter0);
 }
 
 // ------------------------------------------------------------------ tile-resident iterations
@@ -1141,6 +1176,82 @@ __global__ void gg_wait_kernel(int *__restrict__ hdr, int nslots, long max_polls
   hdr[GG_IPC_ERR + 2] = need;
   hdr[GG_IPC_ERR + 3] = __hip_atomic_load(&hdr[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
   atomicAdd(&hdr[GG_IPC_ERR + 4], 1);
+}
+
+// ------------------------------------------------- scaled-field validation of an exchange
+// The benchmark's field is constant in time, so a ghost row read one exchange too early -- the landing arenas
+// alternate, the row of two exchanges ago sits at the same address -- has the same value and no comparison of final
+// states can see it.  The reference asserts flag / stage lock-step at every receive (src/exchange_data_mpi.c:189,439,
+// src/exchange_data_gaspi.c:389-416); the analogue here makes the VALUES carry the iteration number.  Everything is
+// linear in var: after every iteration's gradient launch this kernel multiplies var by 2, 2, 1/4, 2, 2, 1/4, ...
+// (exact in fp64), so the gradients, ghost rows and flux of iteration k are those of the first iteration times
+// 2^((k-1) mod 3) EXACTLY, and the exponents of iterations k and k-2 always differ: a flux computed from a ghost row
+// of two exchanges ago is off by a factor 2 or 4 in that row's terms.  The same kernel compares the flux the step
+// has just produced with reference * 2^e, bit for bit.  All state lives on the device (state[GG_V_ITER] counts the
+// gradient launches), so the kernel replays from a hipGraph like the steps it rides with.
+//   lag  : d_flux holds the flux of iteration ITER + 1 - lag (1: fused mode, the pass computed the PREVIOUS
+//          iteration's flux; 0: the step's own flux kernel has run; < 0: no flux to compare)
+//   skip : optional, per owned point: its flux row is never written (a point without faces)
+__global__ __launch_bounds__(256) void gg_validate_kernel(double *__restrict__ var, int nvar,
+                                                          const double *__restrict__ flux, const double *__restrict__ fref,
+                                                          const unsigned char *__restrict__ skip, int nflux, int lag,
+                                                          int do_scale, int *__restrict__ state) {
+  const int c = state[GG_V_ITER];  // read by every thread before its block takes a ticket: the last ticket moves it
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+  const bool check = lag >= 0 && c - lag >= 0;
+  if (check) {
+    const int e = (c - lag) % 3;
+    const double s = e == 0 ? 1.0 : (e == 1 ? 2.0 : 4.0);
+    int bad = 0;
+    for (int i = gtid; i < nflux; i += gsz) {
+      if (skip && skip[i / 3]) continue;
+      const double want = fref[i] * s, got = flux[i];
+      if (!(got == want)) {
+        bad++;
+        if (atomicCAS(&state[GG_V_CLAIM], 0, 1) == 0) {  // the first one found is kept for the report
+          state[GG_V_FIRST_ITER] = c - lag + 1;
+          state[GG_V_FIRST_IDX] = i;
+          *reinterpret_cast<double *>(&state[GG_V_SEEN]) = got;
+          *reinterpret_cast<double *>(&state[GG_V_EXPECT]) = want;
+        }
+      }
+    }
+    if (bad) atomicAdd(reinterpret_cast<unsigned long long *>(&state[GG_V_BAD]), (unsigned long long)bad);
+  }
+  if (do_scale) {
+    const double f = (c % 3) == 2 ? 0.25 : 2.0;
+    for (int i = gtid; i < nvar; i += gsz)
+      if ((i & 7) != 7) var[i] *= f;  // slot 7 of a var row is the dual volume
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&state[GG_V_TICKET], 1) == (int)gridDim.x - 1) {
+    state[GG_V_TICKET] = 0;
+    if (check) state[GG_V_CHECKS]++;
+    if (do_scale) state[GG_V_ITER] = c + 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void gg_scale_var_kernel(double *__restrict__ var, int nvar, double f) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nvar; i += gridDim.x * blockDim.x)
+    if ((i & 7) != 7) var[i] *= f;
+}
+
+hipError_t gg_launch_validate(double *var, int nall, const double *flux, const double *fref, const unsigned char *skip,
+                              int nown, int lag, bool do_scale, int *state, hipStream_t stream) {
+  const int nvar = nall * 8, nflux = nown * 3;
+  int blocks = ((nvar > nflux ? nvar : nflux) + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(gg_validate_kernel, dim3(blocks), dim3(256), 0, stream, var, nvar, flux, fref, skip, nflux, lag,
+                     do_scale ? 1 : 0, state);
+  return hipGetLastError();
+}
+
+hipError_t gg_launch_scale_var(double *var, int nall, double factor, hipStream_t stream) {
+  int blocks = (nall * 8 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(gg_scale_var_kernel, dim3(blocks), dim3(256), 0, stream, var, nall * 8, factor);
+  return hipGetLastError();
 }
 
 hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row, const int *send_off,

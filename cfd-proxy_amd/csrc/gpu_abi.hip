@@ -88,6 +88,16 @@ struct cfdp_gpu {
   struct ipc_state {
     bool on = false;
     unsigned char *block = nullptr;
+    // memory of the block (CFDP_IPC_MODE; ipc_mode_from_env): 0 coarse-grained (system-scope loads / fences in the
+    // kernels), 1 fine-grained, 2 split: the flag words in a small fine-grained block of their own (`flags`), the
+    // landing arenas coarse-grained, and an explicit cache invalidate once a tile has seen its partners' flags
+    int mode = 0;
+    unsigned char *flags = nullptr;
+    unsigned char my_handle[64] = {0};
+    // notification: per partner (done[1 + s] / need[s] / tile_mask[t], gg_push_args) or one counter for all partners
+    bool per_partner = false;
+    int *d_done = nullptr, *d_need = nullptr;
+    unsigned long long *d_tile_mask = nullptr;
     size_t land_bytes = 0;
     long xiter = 0;
     std::vector<void *> opened;                  // partner blocks (hipIpcOpenMemHandle)
@@ -104,6 +114,10 @@ struct cfdp_gpu {
     // touches ghost rows first enqueues the wait kernel (ipc_settle)
     bool wait_pending = false;
     bool wait_inkernel = true;
+    // FAULT INJECTION (tests only, CFDP_IPC_FAULT=skip_wait): the boundary tiles of a pushing pass do NOT wait for
+    // the previous exchange -- they read whatever the landing arena holds.  Exists so that a test can show that the
+    // scaled-field validation sees a ghost row read one exchange early, and that a comparison of final states does not
+    bool fault_skip_wait = false;
     hipGraphExec_t graph = nullptr, graph_rem = nullptr;  // main chunk; what is left after whole chunks
     int graph_n = 0, graph_rem_n = 0;
     int g_exch = -1, g_overlap = -1, g_flux = -1, g_mode = -1, g_xpar = -1;
@@ -112,11 +126,22 @@ struct cfdp_gpu {
   double *land(int parity) const {
     return reinterpret_cast<double *>(ipc.block + GG_IPC_HDR_BYTES + (size_t)parity * ipc.land_bytes);
   }
-  int *ipc_hdr() const { return reinterpret_cast<int *>(ipc.block); }
+  int *ipc_hdr() const { return reinterpret_cast<int *>(ipc.flags ? ipc.flags : ipc.block); }
   long iter = 0;               // phase-1 calls so far (in-process rank groups run in lockstep)
   std::vector<int> new2old, partner, send_off, recv_off, send_idx_host;
   std::vector<cfdp_tile_desc> h_tiles;
   bool interior_reads_ghosts = false;  // some tile without send points has a ghost in its halo
+  std::vector<unsigned long long> tile_recv_mask;  // [nbtiles] partner slots (bit s) whose ghost rows a boundary tile reads
+  // scaled-field validation of the exchange (cfdp_gpu_scaled_check_begin / _end; gg_validate_kernel): the reference
+  // flux, the device-side state block, which flux rows no kernel ever writes (points without faces)
+  struct scaled_state {
+    bool on = false;
+    int saved_flux_lanes = 0;
+    int *d_state = nullptr;
+    double *d_fref = nullptr;
+    unsigned char *d_skip = nullptr;
+  } sc;
+  std::vector<int> faceless;           // owned points without faces, device numbering
   bool faceless_send = false;          // some send point has no faces: its stored row travels, no tile computes one
   std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
   int max_halo[2] = {0, 0}, max_blob[2] = {0, 0};  // per tile class: halo rows, blob 16-byte units
@@ -129,6 +154,7 @@ struct cfdp_gpu {
   bool alternate = false;
   unsigned fused_passes = 0;
   int grad_lanes = 4, flux_lanes = 8;
+  int last_flux_mode = CFDP_FLUX_CONSISTENT;  // of the latest flux launch (fused or not)
   bool pending_exchange = false;
   bool streams_exported = false;  // handed to the caller: not destroyed with the context
   // hipGraphs of cfdp_gpu_run_iterations: [0] the main chunk (50 fused passes / 25 iterations), [1] what
@@ -254,6 +280,8 @@ static void free_device(cfdp_gpu *g) {
   (void)hipFree(g->d_var); (void)hipFree(g->d_flux);
   (void)hipFree(g->d_nbr_off); (void)hipFree(g->d_nbr); (void)hipFree(g->d_resident_state);
   g->d_nbr_off = g->d_nbr = g->d_resident_state = nullptr;
+  (void)hipFree(g->sc.d_state); (void)hipFree(g->sc.d_fref); (void)hipFree(g->sc.d_skip);
+  g->sc = cfdp_gpu::scaled_state();
   if (g->own_grad) (void)hipFree(g->d_grad);
   if (g->own_grad_alt) (void)hipFree(g->d_grad_alt);
   if (g->own_sendbuf) (void)hipFree(g->d_sendbuf);
@@ -317,6 +345,17 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
     g->send_off.assign(p->send_off, p->send_off + p->npartners + 1);
     g->recv_off.assign(p->recv_off, p->recv_off + p->npartners + 1);
   }
+  g->tile_recv_mask.assign((size_t)p->nbtiles, 0ull);
+  if (p->npartners && p->npartners <= 64)
+    for (int t = 0; t < p->nbtiles; t++)
+      for (int h = 0; h < p->tiles[t].nhalo; h++) {
+        const int gi = p->halo_idx[p->tiles[t].halo_off + h] - p->nown;  // ghost rows are grouped by partner, message order
+        if (gi < 0) continue;
+        int s = 0;
+        while (s + 1 < p->npartners && gi >= p->recv_off[s + 1]) s++;
+        if (gi < p->recv_off[p->npartners]) g->tile_recv_mask[(size_t)t] |= 1ull << s;
+        else g->tile_recv_mask[(size_t)t] = ~0ull;  // a ghost nobody sends: never matches a send mask
+      }
   const size_t nsend = (size_t)g->send_off.back();
   HIP_TRY(hipMalloc(&g->d_tiles, sizeof(cfdp_tile_desc) * (size_t)p->ntiles));
   HIP_TRY(hipMalloc(&g->d_blob, (size_t)p->blob_bytes + 16));
@@ -384,6 +423,9 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   g->faceless_send = false;
   for (size_t j = 0; j < nsend && p->degree; j++)
     if (p->degree[p->send_idx[j]] == 0) g->faceless_send = true;
+  g->faceless.clear();
+  for (int i = 0; i < p->nown && p->degree; i++)
+    if (p->degree[i] == 0) g->faceless.push_back(i);
   if (nsend)
     HIP_TRY(hipMemcpy(g->d_sendidx, p->send_idx, sizeof(int) * nsend, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(g->d_var, 0, sizeof(double) * 8 * (size_t)p->nall));
@@ -436,6 +478,18 @@ static int ipc_settle(cfdp_gpu *g) {
   return 0;
 }
 
+// scaled-field validation (cfdp_gpu_scaled_check_begin): at the end of a step, on the main stream once it has joined
+// the comm stream -- every reader of var of this iteration is ahead of it, the next gradient launch behind it.
+// lag: see gg_validate_kernel.  scale = false: compare only (the deferred flux of a run's last iteration).
+static int scaled_tail(cfdp_gpu *g, int lag, bool scale, hipStream_t st) {
+  if (!g->sc.on) return 0;
+  g->main_marked = false;
+  HIP_TRY(gg_launch_validate(g->d_var, g->nall, g->d_flux, g->sc.d_fref, g->sc.d_skip, g->nown, lag, scale, g->sc.d_state, st));
+  return 0;
+}
+// the lag of the flux a step leaves in d_flux when it closes with (with_flux, fused deferral or not)
+static int scaled_lag(const cfdp_gpu *g, int with_flux) { return !with_flux ? -1 : (g->fusion && g->d_grad_alt ? 1 : 0); }
+
 // run the deferred flux of the last fused-mode iteration, if any
 static int flush_flux(cfdp_gpu *g, bool record = true, hipStream_t st = nullptr) {
   if (ipc_settle(g)) return 1;
@@ -443,6 +497,7 @@ static int flush_flux(cfdp_gpu *g, bool record = true, hipStream_t st = nullptr)
   const int mode = g->flux_pending;
   g->flux_pending = -1;
   if (launch_flux(g, mode, st ? st : g->s_main)) return 1;
+  if (scaled_tail(g, 1, false, st ? st : g->s_main)) return 1;
   if (record) {
     HIP_TRY(hipEventRecord(g->ev_fluxdone, st ? st : g->s_main));
     g->main_marked = !st || st == g->s_main;
@@ -626,6 +681,7 @@ static int launch_grad(cfdp_gpu *g, int which, hipStream_t st, const gg_grad_vie
 
 static int launch_flux_tiles(cfdp_gpu *g, int mode, int which, hipStream_t st) {
   g->main_marked = false;
+  g->last_flux_mode = mode;
   const gg_args a = g->args();
   const tile_range r = range_of(g, which);
   HIP_TRY(gg_launch_flux(a, g->flux_lanes, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.lds_flux, r.row_halo(),
@@ -645,6 +701,7 @@ static int launch_fused(cfdp_gpu *g, int which, hipStream_t st, const gg_push_ar
   const gg_args a = g->args();
   const gg_grad_view gnew = g->alt_view();
   const int mode = g->flux_pending;
+  g->last_flux_mode = mode;
   const tile_range r = range_of(g, which);
   if (push && !gg_fused_fits(r.tp, r.row_halo(), r.max_blob)) return 2;
   const bool reverse = g->alternate && which == CFDP_TILES_ALL && !push && (g->fused_passes++ & 1u);
@@ -792,6 +849,7 @@ int cfdp_gpu_step_post(cfdp_gpu *g, int with_flux, int flux_mode) {
     if (g->fusion && g->d_grad_alt) g->flux_pending = flux_mode;  // rides with the next gradients (or the next sync)
     else if (launch_flux(g, flux_mode, g->s_main)) return 1;
   }
+  if (scaled_tail(g, scaled_lag(g, with_flux), true, g->s_main)) return 1;
   return mark_main(g);
 }
 
@@ -869,6 +927,7 @@ int cfdp_gpu_rank_flux(cfdp_gpu **ranks, int G, int b, int with_flux, int flux_m
     if (gb->fusion && gb->d_grad_alt) gb->flux_pending = flux_mode;
     else if (launch_flux(gb, flux_mode, gb->s_main)) return 1;
   }
+  if (scaled_tail(gb, scaled_lag(gb, with_flux), true, gb->s_main)) return 1;
   return mark_main(gb);
 }
 
@@ -884,6 +943,84 @@ int cfdp_gpu_iteration_group(cfdp_gpu **ranks, int G, int with_exchange, int ove
 int cfdp_gpu_sync_group(cfdp_gpu **ranks, int G) {
   for (int a = 0; a < G; a++)
     if (cfdp_gpu_sync(ranks[a])) return 1;
+  return 0;
+}
+
+// ----------------------------------------------------- scaled-field validation of the exchange
+// See gg_validate_kernel.  begin: the flux the context holds NOW (from an iteration whose exchange the caller knows to be
+// complete: device syncs and a barrier between the ranks, then one step without exchange) becomes the reference; from
+// then on every step entry point (cfdp_gpu_step_post, _step_ipc*, _run_steps_*, _rank_flux; the drop-in layer's
+// compute_psd_flux) ends with the validation kernel: compare the flux the step produced with reference * 2^e, then
+// var *= 2, 2, 1/4, ...  Every step must exchange and compute the flux while the mode is on.  end: the deferred flux of
+// the last iteration is compared too, var is restored exactly, the evidence is returned.
+static void drop_ipc_graphs(cfdp_gpu *g) {
+  auto &I = g->ipc;
+  if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
+  if (I.graph_rem) { (void)hipGraphExecDestroy(I.graph_rem); I.graph_rem = nullptr; }
+  I.graph_n = I.graph_rem_n = 0;
+}
+
+int cfdp_gpu_scaled_check_begin(cfdp_gpu *g) {
+  NEED_UPLOAD(g);
+  if (g->sc.on) return fail("the scaled-field validation is already on");
+  if (flush_flux(g)) return 1;
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t nf = (size_t)g->nown * 3;
+  if (!g->sc.d_state) HIP_TRY(hipMalloc(&g->sc.d_state, GG_V_WORDS * sizeof(int)));
+  if (!g->sc.d_fref) HIP_TRY(hipMalloc(&g->sc.d_fref, (nf + 1) * sizeof(double)));
+  if (!g->sc.d_skip && !g->faceless.empty()) {
+    std::vector<unsigned char> skip((size_t)g->nown, 0);
+    for (int i : g->faceless) skip[(size_t)i] = 1;
+    HIP_TRY(hipMalloc(&g->sc.d_skip, skip.size()));
+    HIP_TRY(hipMemcpy(g->sc.d_skip, skip.data(), skip.size(), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMemset(g->sc.d_state, 0, GG_V_WORDS * sizeof(int)));
+  // bit for bit: the reference must come from the kernel form the steps will use.  The flux phase of the fused pass
+  // sums a point's faces on 4 lanes, the separate flux kernel by default on 8 (another association): with fused
+  // iterations on, the separate kernel -- reference now, last iteration's deferred flux later -- runs on 4 as well
+  g->sc.saved_flux_lanes = g->flux_lanes;
+  if (g->fusion && g->d_grad_alt) g->flux_lanes = 4;
+  if (launch_flux(g, g->last_flux_mode, g->s_main)) return 1;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(g->sc.d_fref, g->d_flux, nf * sizeof(double), hipMemcpyDeviceToDevice));
+  g->sc.on = true;
+  g->drop_graphs();  // graphs captured without the validation kernel
+  drop_ipc_graphs(g);
+  return 0;
+}
+
+int cfdp_gpu_scaled_check_end(cfdp_gpu *g, cfdp_scaled_check *out) {
+  NEED_UPLOAD(g);
+  if (!g->sc.on) return fail("the scaled-field validation is not on");
+  const int rc = flush_flux(g);  // compares the last iteration's flux as well
+  g->sc.on = false;
+  g->flux_lanes = g->sc.saved_flux_lanes;
+  g->drop_graphs();
+  drop_ipc_graphs(g);
+  if (rc) return 1;
+  HIP_TRY(hipDeviceSynchronize());
+  int st[GG_V_WORDS];
+  HIP_TRY(hipMemcpy(st, g->sc.d_state, sizeof st, hipMemcpyDeviceToHost));
+  const int m = st[GG_V_ITER] % 3;  // var holds var0 * 2^m
+  if (m) {
+    HIP_TRY(gg_launch_scale_var(g->d_var, g->nall, m == 1 ? 0.5 : 0.25, g->s_main));
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  if (out) {
+    unsigned long long bad = 0;
+    memcpy(&bad, &st[GG_V_BAD], sizeof bad);
+    out->iterations = st[GG_V_ITER];
+    out->flux_checks = st[GG_V_CHECKS];
+    out->mismatches = bad > 0x7FFFFFFFull ? 0x7FFFFFFF : (int)bad;
+    out->first_iteration = st[GG_V_CLAIM] ? st[GG_V_FIRST_ITER] : 0;
+    out->first_point = st[GG_V_CLAIM] ? g->new2old[(size_t)(st[GG_V_FIRST_IDX] / 3)] : -1;
+    out->first_component = st[GG_V_CLAIM] ? st[GG_V_FIRST_IDX] % 3 : -1;
+    out->seen = out->expected = 0.0;
+    if (st[GG_V_CLAIM]) {
+      memcpy(&out->seen, &st[GG_V_SEEN], sizeof(double));
+      memcpy(&out->expected, &st[GG_V_EXPECT], sizeof(double));
+    }
+  }
   return 0;
 }
 
@@ -1447,6 +1584,9 @@ void ipc_release(cfdp_gpu *g) {
   (void)hipFree(I.d_tile_off); (void)hipFree(I.d_ent); (void)hipFree(I.d_ent_row);
   I.d_slot_of_row = I.d_send_off = I.d_tile_off = I.d_ent = I.d_ent_row = nullptr;
   I.inkernel = false;
+  (void)hipFree(I.d_done); (void)hipFree(I.d_need); (void)hipFree(I.d_tile_mask);
+  I.d_done = I.d_need = nullptr; I.d_tile_mask = nullptr; I.per_partner = false;
+  (void)hipFree(I.flags); I.flags = nullptr;
   (void)hipFree(I.block); I.block = nullptr;
   I.on = false; I.xiter = 0;
 }
@@ -1476,9 +1616,11 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
       // fork/join between two streams costs 8-18 us per iteration inside a hipGraph.)
       gg_push_args pa;
       pa.tile_off = I.d_tile_off; pa.ent = I.d_ent; pa.ent_row = I.d_ent_row; pa.dst = I.d_dst[par];
-      pa.hdr = g->ipc_hdr(); pa.rflag = I.d_rflag; pa.done = g->ipc_hdr() + GG_IPC_DONE;
+      pa.hdr = g->ipc_hdr(); pa.rflag = I.d_rflag; pa.done = I.d_done;
+      pa.need = I.per_partner ? I.d_need : nullptr; pa.tile_mask = I.per_partner ? I.d_tile_mask : nullptr;
       pa.nbtiles = g->nbtiles; pa.nslots = nslots;
-      pa.wait_polls = I.wait_pending && I.wait_inkernel ? (long)ipc_max_polls() : 0;
+      pa.inv_after_flag = I.mode == 2 ? 1 : 0;
+      pa.wait_polls = I.wait_pending && I.wait_inkernel && !I.fault_skip_wait ? (long)ipc_max_polls() : 0;
       const int rc = launch_fused(g, CFDP_TILES_ALL, g->s_main, &pa);
       if (rc == 1) return 1;
       pushed = rc == 0;
@@ -1525,12 +1667,41 @@ int ipc_post(cfdp_gpu *g, int with_flux, int flux_mode) {
     if (g->fusion && g->d_grad_alt) g->flux_pending = flux_mode;
     else if (launch_flux(g, flux_mode, g->s_main)) return 1;
   }
+  if (scaled_tail(g, scaled_lag(g, with_flux), true, g->s_main)) return 1;
   // no end-of-iteration marker here (each costs ~5 us on the device): a later step that needs to
   // fork its comm stream records one itself (fork_comm), and the single-stream schedules need none
   g->main_marked = false;
   return 0;
 }
 }  // namespace
+
+// CFDP_IPC_MODE = coarse | split | fine (CFDP_IPC_FINEGRAINED=1 is the older spelling of fine)
+static int ipc_mode_from_env() {
+  if (const char *m = getenv("CFDP_IPC_MODE")) {
+    if (!strcmp(m, "fine")) return 1;
+    if (!strcmp(m, "split")) return 2;
+    if (!strcmp(m, "coarse")) return 0;
+  }
+  const char *fg = getenv("CFDP_IPC_FINEGRAINED");
+  return fg && atoi(fg) != 0 ? 1 : 0;
+}
+
+// a partner's block (or flag block), mapped once per handle
+static int ipc_open(cfdp_gpu *g, const void *handle64, unsigned char **base_out) {
+  auto &I = g->ipc;
+  void *base = nullptr;
+  for (size_t i = 0; i < I.opened.size(); i++)
+    if (!memcmp(I.opened_handle[i].data(), handle64, 64)) base = I.opened[i];
+  if (!base) {
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof h);
+    HIP_TRY(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+    I.opened.push_back(base);
+    I.opened_handle.emplace_back((const unsigned char *)handle64, (const unsigned char *)handle64 + 64);
+  }
+  *base_out = static_cast<unsigned char *>(base);
+  return 0;
+}
 
 int cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes) {
   NEED_UPLOAD(g);
@@ -1548,15 +1719,18 @@ int cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes) {
   auto &I = g->ipc;
   I.land_bytes = (((size_t)(g->nall - g->nown) * 21 * sizeof(double)) + 255) & ~(size_t)255;
   const size_t bytes = GG_IPC_HDR_BYTES + 2 * I.land_bytes;
-  // CFDP_IPC_FINEGRAINED=1: a fine-grained block (coherent at system scope without cache maintenance);
-  // the default coarse-grained block relies on the system-scope loads / fences of the kernels
-  const char *fg = getenv("CFDP_IPC_FINEGRAINED");
-  if (fg && atoi(fg) != 0) HIP_TRY(hipExtMallocWithFlags((void **)&I.block, bytes, hipDeviceMallocFinegrained));
+  I.mode = ipc_mode_from_env();
+  if (I.mode == 1) HIP_TRY(hipExtMallocWithFlags((void **)&I.block, bytes, hipDeviceMallocFinegrained));
   else HIP_TRY(hipMalloc(&I.block, bytes));
   HIP_TRY(hipMemset(I.block, 0, bytes));
+  if (I.mode == 2) {  // the flag words alone in fine-grained memory (the header of `block` stays unused)
+    HIP_TRY(hipExtMallocWithFlags((void **)&I.flags, 64 * 1024, hipDeviceMallocFinegrained));
+    HIP_TRY(hipMemset(I.flags, 0, 64 * 1024));
+  }
   hipIpcMemHandle_t h;
   HIP_TRY(hipIpcGetMemHandle(&h, I.block));
   memcpy(handle64, &h, sizeof h);
+  memcpy(I.my_handle, &h, sizeof h);
   if (land_bytes) *land_bytes = I.land_bytes;
   const int nslots = (int)g->partner.size();
   I.dst[0].assign(nslots, nullptr); I.dst[1].assign(nslots, nullptr); I.rflag.assign(nslots, nullptr);
@@ -1569,21 +1743,48 @@ int cfdp_gpu_ipc_connect(cfdp_gpu *g, int slot, const void *partner_handle64, si
   auto &I = g->ipc;
   if (!I.block) return fail("cfdp_gpu_ipc_export() first");
   if (slot < 0 || slot >= (int)g->partner.size() || !partner_handle64) return fail("bad partner slot");
-  void *base = nullptr;
-  for (size_t i = 0; i < I.opened.size(); i++)
-    if (!memcmp(I.opened_handle[i].data(), partner_handle64, 64)) base = I.opened[i];
-  if (!base) {
-    hipIpcMemHandle_t h;
-    memcpy(&h, partner_handle64, sizeof h);
-    HIP_TRY(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
-    I.opened.push_back(base);
-    I.opened_handle.emplace_back((const unsigned char *)partner_handle64, (const unsigned char *)partner_handle64 + 64);
-  }
-  unsigned char *b = static_cast<unsigned char *>(base);
+  unsigned char *b = nullptr;
+  if (ipc_open(g, partner_handle64, &b)) return 1;
   I.dst[0][slot] = reinterpret_cast<double *>(b + land_off0);
   I.dst[1][slot] = reinterpret_cast<double *>(b + land_off1);
   I.rflag[slot] = reinterpret_cast<int *>(b + flag_off);
   return 0;
+}
+
+// the handle of the block that holds this rank's flag words: a block of its own in split mode, else the main block
+int cfdp_gpu_ipc_export_flags(cfdp_gpu *g, void *handle64) {
+  NEED_UPLOAD(g);
+  auto &I = g->ipc;
+  if (!I.block || !handle64) return fail("cfdp_gpu_ipc_export() first");
+  if (I.flags) {
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, I.flags));
+    memcpy(handle64, &h, sizeof h);
+  } else {
+    memcpy(handle64, I.my_handle, 64);
+  }
+  return 0;
+}
+
+// my arrival counter at partner `slot` lives at flag_off in the block of THAT handle (after cfdp_gpu_ipc_connect)
+int cfdp_gpu_ipc_connect_flags(cfdp_gpu *g, int slot, const void *partner_flags_handle64, size_t flag_off) {
+  NEED_UPLOAD(g);
+  auto &I = g->ipc;
+  if (!I.block) return fail("cfdp_gpu_ipc_export() first");
+  if (slot < 0 || slot >= (int)g->partner.size() || !partner_flags_handle64) return fail("bad partner slot");
+  unsigned char *b = nullptr;
+  if (ipc_open(g, partner_flags_handle64, &b)) return 1;
+  I.rflag[slot] = reinterpret_cast<int *>(b + flag_off);
+  return 0;
+}
+
+// what the exchange set up by cfdp_gpu_ipc_ready does: bit 0 the fused pass pushes and notifies itself, bit 1 its
+// boundary tiles wait themselves, bit 2 per-partner notification and wait masks, bits 4-5 the memory mode
+// (0 coarse, 1 fine, 2 split)
+int cfdp_gpu_ipc_mode(const cfdp_gpu *g) {
+  if (!g || !g->ipc.block) return -1;
+  const auto &I = g->ipc;
+  return (I.inkernel ? 1 : 0) | (I.inkernel && I.wait_inkernel ? 2 : 0) | (I.per_partner ? 4 : 0) | (I.mode << 4);
 }
 
 int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
@@ -1645,8 +1846,32 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       I.inkernel = g->nbtiles > 0 && !g->faceless_send && !(e && atoi(e) == 0);
       const char *w = getenv("CFDP_IPC_WAIT_INKERNEL");  // 0: always a separate wait kernel (A/B timing)
       I.wait_inkernel = !(w && atoi(w) == 0);
+      // per-partner notification needs: every boundary tile reads ghost rows only of partners it sends to (then the
+      // flags a tile waits for also cover the rows it is about to overwrite at those partners, see gg_kernels.hip)
+      std::vector<unsigned long long> smask((size_t)g->nbtiles, 0ull);
+      std::vector<int> need((size_t)(nslots ? nslots : 1), 0);
+      for (int t = 0; t < g->nbtiles; t++)
+        for (int e2 = tile_off[t]; e2 < tile_off[t + 1]; e2++) smask[(size_t)t] |= 1ull << (ent[e2] >> 16);
+      bool pp = nslots <= GG_IPC_MAXSLOTS && (int)g->tile_recv_mask.size() == g->nbtiles;
+      for (int t = 0; t < g->nbtiles && pp; t++) pp = (g->tile_recv_mask[(size_t)t] & ~smask[(size_t)t]) == 0;
+      for (int t = 0; t < g->nbtiles; t++)
+        for (int s2 = 0; s2 < nslots; s2++)
+          if ((smask[(size_t)t] >> s2) & 1ull) need[(size_t)s2]++;
+      for (int s2 = 0; s2 < nslots; s2++) pp = pp && need[(size_t)s2] > 0;
+      const char *ppe = getenv("CFDP_IPC_PER_PARTNER");  // 0: one counter, all flags raised by the last boundary tile (A/B)
+      I.per_partner = pp && !(ppe && atoi(ppe) == 0);
+      HIP_TRY(hipMalloc(&I.d_need, sizeof(int) * need.size()));
+      HIP_TRY(hipMemcpy(I.d_need, need.data(), sizeof(int) * need.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&I.d_tile_mask, sizeof(unsigned long long) * (smask.size() + 1)));
+      if (!smask.empty())
+        HIP_TRY(hipMemcpy(I.d_tile_mask, smask.data(), sizeof(unsigned long long) * smask.size(), hipMemcpyHostToDevice));
+      const char *f = getenv("CFDP_IPC_FAULT");
+      I.fault_skip_wait = f && !strcmp(f, "skip_wait");
+      if (I.fault_skip_wait) fprintf(stderr, "[cfdp] FAULT INJECTION: boundary tiles do not wait for the previous exchange (CFDP_IPC_FAULT)\n");
     }
   }
+  HIP_TRY(hipMalloc(&I.d_done, sizeof(int) * (GG_IPC_MAXSLOTS + 1)));
+  HIP_TRY(hipMemset(I.d_done, 0, sizeof(int) * (GG_IPC_MAXSLOTS + 1)));
   if (flush_flux(g)) return 1;
   HIP_TRY(hipDeviceSynchronize());
   // the ghost rows move into the landing arenas

@@ -13,9 +13,10 @@
  *                                 partner the owner-local ids of the ghosts it needs from it
  *                                                                           (src/comm_data.c:203-249)
  *   init_threads                  + the data path between the ranks' GPUs: xGMI write + notify through
- *                                 HIP IPC when all ranks share a node (VALIDATED before use: ghost rows
- *                                 against owner rows for var and 2*var with a short wait bound; retried
- *                                 with a fine-grained landing block; then RCCL), else RCCL send/recv
+ *                                 HIP IPC when all ranks share a node (VALIDATED before use: the flux of
+ *                                 64 iterations in a field scaled per iteration, so that a ghost row read
+ *                                 one exchange early cannot hide; ghost rows against owner rows; short
+ *                                 wait bound; retried with a fine-grained block; then RCCL), else RCCL
  *                                 -- in place of src/exchange_data_{mpi,mpidma,gaspi}.c
  *   test_solver                   MPI_Barrier around every sample, rank 0 prints  (src/solver.c:42-58)
  *   free_communication_ressources unmap / tear down collectively, MPI_Finalize (when this library did
@@ -88,11 +89,12 @@ static void hook_tables(comm_data *cd) {
 /* ---- the xGMI write + notify path: map the partners' landing arenas (handles travel in one allgather) */
 static int ipc_setup(cfdp_gpu *gpu, int r, int G) {
   enum { MAXP = 48 };
-  typedef struct { unsigned char handle[64]; long land; int np, partner[MAXP], recv_off[MAXP + 1]; } ipc_info;
+  typedef struct { unsigned char handle[64], fhandle[64]; long land; int np, partner[MAXP], recv_off[MAXP + 1]; } ipc_info;
   ipc_info mine, *all_info = cfdp_malloc((size_t)G * sizeof(ipc_info));
   memset(&mine, 0, sizeof mine);
   size_t land = 0;
-  int ok = cfdp_gpu_ipc_export(gpu, mine.handle, &land) == 0 && cfdp_gpu_npartners(gpu) <= MAXP;
+  int ok = cfdp_gpu_ipc_export(gpu, mine.handle, &land) == 0 && cfdp_gpu_ipc_export_flags(gpu, mine.fhandle) == 0 &&
+           cfdp_gpu_npartners(gpu) <= MAXP;
   mine.land = (long)land;
   mine.np = ok ? cfdp_gpu_npartners(gpu) : -1;
   for (int s = 0; s < mine.np; s++) {
@@ -110,7 +112,8 @@ static int ipc_setup(cfdp_gpu *gpu, int r, int G) {
     for (int i = 0; i < pi->np; i++)
       if (pi->partner[i] == r) t = i;
     const size_t base = 256 + (size_t)pi->recv_off[t < 0 ? 0 : t] * NGRAD * 3 * sizeof(double);
-    ok = t >= 0 && cfdp_gpu_ipc_connect(gpu, s, pi->handle, base, base + (size_t)pi->land, 4 * (size_t)t) == 0;
+    ok = t >= 0 && cfdp_gpu_ipc_connect(gpu, s, pi->handle, base, base + (size_t)pi->land, 4 * (size_t)t) == 0 &&
+         cfdp_gpu_ipc_connect_flags(gpu, s, pi->fhandle, 4 * (size_t)t) == 0; /* (a block of its own in "split" mode) */
   }
   ok = ok && cfdp_gpu_ipc_ready(gpu) == 0;
   int all_ok = 0;
@@ -126,11 +129,16 @@ static void ipc_teardown(cfdp_gpu *gpu) {
   MPI_Barrier(MPI_COMM_WORLD);
 }
 
-/* collective: Sigma |sent rows| (weighted by the position in the message) == Sigma |ghost rows| (same
- * weights on the receiving side) over all ranks and no wait gave up, after 4 iterations each with var,
- * 2*var, var -- a ghost row left over from an earlier round cannot satisfy the next.  Restores the
- * host and device fields.                                                                    */
-static int exchange_valid(comm_data *cd, solver_data *sd, cfdp_gpu *gpu) {
+/* collective, before a data path is used.  (1) No flux phase may READ a ghost row before the rows of its exchange
+ * have landed: the field is constant in time and the landing arenas alternate, so such a read returns the right value
+ * and no comparison of final states sees it.  The library's scaled-field mode (cfdp_gpu_scaled_check_begin:
+ * var x 2, 2, 1/4 after every iteration, the flux of EVERY step compared with reference x 2^e on the device) makes the
+ * values carry the iteration number -- the analogue of the reference's stage / flag lock-step asserts at every receive
+ * (src/exchange_data_mpi.c:189,439, src/exchange_data_gaspi.c:389-416).  (2) Afterwards Sigma |sent rows| (weighted by
+ * the position in the message) == Sigma |ghost rows| over all ranks.  (3) No device-side wait gave up.  *why names the
+ * check that failed.  Restores the host and device fields.                                                         */
+static int exchange_valid(comm_data *cd, solver_data *sd, cfdp_gpu *gpu, const char **why) {
+  enum { STEPS = 64 };
   const size_t nall = (size_t)sd->nallpoints;
   double *var0 = cfdp_malloc(nall * NGRAD * sizeof(double));
   double *grad0 = cfdp_malloc(nall * NGRAD * 3 * sizeof(double));
@@ -139,29 +147,48 @@ static int exchange_valid(comm_data *cd, solver_data *sd, cfdp_gpu *gpu) {
   memcpy(grad0, sd->grad, nall * NGRAD * 3 * sizeof(double));
   memcpy(flux0, sd->psd_flux, nall * NFLUX * sizeof(double));
   cfdp_ipc_set_wait_seconds(2.0); /* a broken mapping must not cost half a minute per iteration here */
-  int good = 1;
-  const double scales[3] = {1.0, 2.0, 1.0};
-  for (int round = 0; round < 3; round++) {
-    for (size_t i = 0; i < nall * NGRAD; i++) (&sd->var[0][0])[i] = var0[i] * scales[round];
-    cfdp_sync_fields_to_device(sd);
-    MPI_Barrier(MPI_COMM_WORLD);
-    for (int it = 0; it < 4; it++) {
-      compute_gradients_gg_gaspi_async(cd, sd, it == 3);
-      compute_psd_flux(sd);
-    }
-    cfdp_sync_fields_to_host(sd);
-    double s[3] = {0.0, 0.0, 0.0}, gs[3];
-    for (int i = 0; i < cd->ncommdomains; i++) {
-      const int p = cd->commpartner[i];
-      for (int j = 0; j < cd->sendcount[p]; j++)
-        for (int c = 0; c < NGRAD * 3; c++) s[0] += (j + 1.0) * fabs((&sd->grad[cd->sendindex[p][j]][0][0])[c]);
-      for (int j = 0; j < cd->recvcount[p]; j++)
-        for (int c = 0; c < NGRAD * 3; c++) s[1] += (j + 1.0) * fabs((&sd->grad[cd->recvindex[p][j]][0][0])[c]);
-    }
-    s[2] = g_use_ipc ? (double)(cfdp_gpu_ipc_error(gpu) != 0) : 0.0;
-    MPI_Allreduce(s, gs, 3, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
-    good = good && gs[2] == 0.0 && gs[0] > 0.0 && fabs(gs[0] - gs[1]) <= 1e-9 * gs[0];
+  /* the reference flux: two exchanging iterations (both grad buffers / arenas hold delivered rows), every device
+   * synced, a barrier -- every push has landed everywhere -- then one iteration that does not exchange */
+  for (int it = 0; it < 2; it++) {
+    compute_gradients_gg_gaspi_async(cd, sd, 0);
+    compute_psd_flux(sd);
   }
+  int ok = cfdp_gpu_sync(gpu) == 0;
+  MPI_Barrier(MPI_COMM_WORLD);
+  compute_gradients_gg_comm_free(cd, sd, 1);
+  compute_psd_flux(sd);
+  cfdp_scaled_check ev;
+  memset(&ev, 0, sizeof ev);
+  ok = ok && cfdp_gpu_scaled_check_begin(gpu) == 0;
+  MPI_Barrier(MPI_COMM_WORLD);
+  for (int it = 0; ok && it < STEPS; it++) {
+    compute_gradients_gg_gaspi_async(cd, sd, it == STEPS - 1);
+    compute_psd_flux(sd);
+  }
+  ok = ok && cfdp_gpu_scaled_check_end(gpu, &ev) == 0;
+  cfdp_sync_fields_to_host(sd);
+  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, gs[5];
+  for (int i = 0; i < cd->ncommdomains; i++) {
+    const int p = cd->commpartner[i];
+    for (int j = 0; j < cd->sendcount[p]; j++)
+      for (int c = 0; c < NGRAD * 3; c++) s[0] += (j + 1.0) * fabs((&sd->grad[cd->sendindex[p][j]][0][0])[c]);
+    for (int j = 0; j < cd->recvcount[p]; j++)
+      for (int c = 0; c < NGRAD * 3; c++) s[1] += (j + 1.0) * fabs((&sd->grad[cd->recvindex[p][j]][0][0])[c]);
+  }
+  s[2] = g_use_ipc ? (double)(cfdp_gpu_ipc_error(gpu) != 0) : 0.0;
+  s[3] = (double)ev.mismatches;
+  s[4] = ok && ev.flux_checks >= STEPS - 1 ? 0.0 : 1.0; /* the mode did not run as it should */
+  MPI_Allreduce(s, gs, 5, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
+  const char *failed = NULL;
+  if (gs[2] != 0.0) failed = "wait timeout (a partner's flag never arrived)";
+  else if (gs[4] != 0.0) failed = "the scaled-field run did not complete";
+  else if (!(gs[0] > 0.0)) failed = "nothing sent";
+  else if (gs[3] != 0.0) failed = "stale read (a flux phase read a ghost row of an earlier exchange)";
+  else if (!(fabs(gs[0] - gs[1]) <= 1e-9 * gs[0])) failed = "stale rows (rows did not arrive although every flag did)";
+  if (ev.mismatches && failed && !strncmp(failed, "stale read", 10))
+    fprintf(stderr, "[cfdp] rank %d: first stale read in iteration %d, point %d, component %d: saw %.17g, expected %.17g\n",
+            cd->iProc, ev.first_iteration, ev.first_point, ev.first_component, ev.seen, ev.expected);
+  if (why) *why = failed;
   const char *w = getenv("CFDP_IPC_WAIT_SECONDS");
   cfdp_ipc_set_wait_seconds(w && atof(w) > 0 ? atof(w) : 30.0);
   memcpy(sd->var, var0, nall * NGRAD * sizeof(double));
@@ -169,7 +196,7 @@ static int exchange_valid(comm_data *cd, solver_data *sd, cfdp_gpu *gpu) {
   memcpy(sd->psd_flux, flux0, nall * NFLUX * sizeof(double));
   cfdp_sync_fields_to_device(sd);
   free(var0); free(grad0); free(flux0);
-  return good;
+  return failed == NULL;
 }
 
 /* choose, set up and VALIDATE the data path between the ranks' GPUs (collective).  force_rccl: skip
@@ -192,14 +219,20 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
     MPI_Allreduce(&all_one_node, &agreed, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
     try_ipc = agreed;
   }
+  /* the memory modes of the landing block (cfdproxy_hip.h, CFDP_IPC_MODE), in the order they are tried; a mode the
+   * environment names is the only one tried */
+  static const char *const modes[3] = {"coarse", "split", "fine"};
+  static const char *const labels[3] = {"coarse-grained landing block", "fine-grained flags, coarse-grained arenas, explicit invalidate",
+                                        "fine-grained landing block"};
+  const char *preset = getenv("CFDP_IPC_MODE");
   const char *fg0 = getenv("CFDP_IPC_FINEGRAINED");
-  const int fg_preset = fg0 && atoi(fg0) != 0;
-  for (int attempt = 0; try_ipc && attempt < 2; attempt++) {
-    if (attempt == 1) {
-      if (fg_preset) break; /* the first attempt already used a fine-grained block */
-      setenv("CFDP_IPC_FINEGRAINED", "1", 1);
-    }
-    const char *what = attempt || fg_preset ? "fine-grained landing block" : "coarse-grained landing block";
+  if (!(preset && *preset) && fg0 && atoi(fg0) != 0) preset = "fine";
+  char preset_copy[16] = "";
+  if (preset && *preset) snprintf(preset_copy, sizeof preset_copy, "%s", preset); /* (setenv below may move the string) */
+  for (int attempt = 0; try_ipc && attempt < 3; attempt++) {
+    if (preset_copy[0] && strcmp(preset_copy, modes[attempt])) continue;
+    setenv("CFDP_IPC_MODE", modes[attempt], 1);
+    const char *what = labels[attempt];
     if (!ipc_setup(gpu, r, G)) {
       if (r == 0) printf("exchange: HIP IPC setup failed (%s): %s\n", what, cfdp_gpu_last_error());
       ipc_teardown(gpu);
@@ -207,12 +240,13 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
     }
     cfdp_attach_ipc(sd);
     g_use_ipc = 1;
-    if (exchange_valid(cd, sd, gpu)) {
+    const char *why = NULL;
+    if (exchange_valid(cd, sd, gpu, &why)) {
       snprintf(g_path, sizeof g_path, "xGMI write + notify (HIP IPC, %s), validated", what);
       if (r == 0) printf("exchange: %s\n", g_path);
       return 1;
     }
-    if (r == 0) printf("exchange: xGMI write + notify FAILED its validation (%s)\n", what);
+    if (r == 0) printf("exchange: xGMI write + notify FAILED its validation (%s): %s\n", what, why ? why : "?");
     g_use_ipc = 0;
     cfdp_detach_external(sd);
     ipc_teardown(gpu);
@@ -229,8 +263,9 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
   }
   MPI_Bcast(id, 128, MPI_BYTE, 0, MPI_COMM_WORLD);
   cfdp_attach_rccl(sd, id, G, r);
-  if (!exchange_valid(cd, sd, gpu)) {
-    if (r == 0) fprintf(stderr, "Error: the RCCL exchange failed its validation\n");
+  const char *why = NULL;
+  if (!exchange_valid(cd, sd, gpu, &why)) {
+    if (r == 0) fprintf(stderr, "Error: the RCCL exchange failed its validation: %s\n", why ? why : "?");
     MPI_Abort(MPI_COMM_WORLD, EXIT_FAILURE);
   }
   snprintf(g_path, sizeof g_path, "RCCL send/recv, validated");

@@ -107,6 +107,22 @@ def bench_config(name: str, n_ranks: int) -> dict:
                 workload=f"{name} {level} stand-in ({what}; {how})")
 
 
+IPC_MODE_LABEL = {"coarse": "coarse-grained block", "split": "fine-grained flags, coarse-grained arenas, explicit invalidate",
+                  "fine": "fine-grained block"}
+
+
+# what the environment asked for when the process started (RankSolver sets CFDP_IPC_MODE itself while it tries the modes)
+_IPC_MODE_PRESET = os.environ.get("CFDP_IPC_MODE", "") or ("fine" if os.environ.get("CFDP_IPC_FINEGRAINED", "0") not in ("", "0") else "")
+
+
+def ipc_mode_attempts() -> List[str]:
+    """memory modes of the xGMI landing block in the order the set-up tries them (cfdproxy_hip.h, CFDP_IPC_MODE): the
+    one the environment named (a comma-separated list is an order), else coarse -> split -> fine"""
+    if _IPC_MODE_PRESET:
+        return [x for x in _IPC_MODE_PRESET.split(",") if x in IPC_MODE_LABEL] or ["coarse"]
+    return ["coarse", "split", "fine"]
+
+
 def exchange_requests(part: Domain, rank: int, world: int, dist=None, all_requests=None) -> None:
     """Fill part's send lists from what the partners request (comm_data.c:203-249 analogue).
     `dist`: an initialised torch.distributed module, or None with `all_requests` given
@@ -209,21 +225,18 @@ class RankSolver:
         self.validation: Dict[str, dict] = {}
         if transport in ("ipc", "auto") and world > 1:
             import sys
-            # a second attempt with a fine-grained landing block (every rank fails or passes alike:
-            # _init_ipc raises from all-reduced evidence only)
-            for attempt in ("as configured", "fine-grained block"):
-                if attempt == "fine-grained block":
-                    if os.environ.get("CFDP_IPC_FINEGRAINED", "0") not in ("", "0"):
-                        break
-                    os.environ["CFDP_IPC_FINEGRAINED"] = "1"
-                self._validating = f"ipc / {attempt}"
+            # the memory modes of the landing block, in the order they are tried (every rank fails or passes alike:
+            # _init_ipc raises from all-reduced evidence only); a mode set in the environment is the only one tried
+            for mode in ipc_mode_attempts():
+                os.environ["CFDP_IPC_MODE"] = mode
+                self._validating = f"ipc / {IPC_MODE_LABEL[mode]}"
                 try:
                     self._init_ipc()
                     self.available.append("ipc")
                     break
                 except Exception as e:
                     self.validation.setdefault(self._validating, {"ok": False, "failed": f"setup: {e}"[:160]})
-                    print(f"[rank {rank}] xGMI write+notify setup failed ({attempt}: {e})", file=sys.stderr)
+                    print(f"[rank {rank}] xGMI write+notify setup failed ({IPC_MODE_LABEL[mode]}: {e})", file=sys.stderr)
             if "ipc" not in self.available and transport == "ipc":
                 transport = "rccl"
         elif transport in ("ipc", "auto"):
@@ -274,7 +287,7 @@ class RankSolver:
             roff = [0]
             for s in range(len(self.partners)):
                 roff.append(roff[-1] + self.gpu.recv_slice(s)[1] // (8 * ROWLEN))
-            info = dict(handle=handle, land=land, partners=list(self.partners), recv_off=roff)
+            info = dict(handle=handle, fhandle=self.gpu.ipc_export_flags(), land=land, partners=list(self.partners), recv_off=roff)
         except Exception as e:
             ok, self._ipc_why = False, str(e)
         gathered = [None] * self.world
@@ -287,6 +300,7 @@ class RankSolver:
                 t = pi["partners"].index(self.rank)
                 base = 256 + pi["recv_off"][t] * 8 * ROWLEN
                 self.gpu.ipc_connect(s, pi["handle"], base, base + pi["land"], 4 * t)
+                self.gpu.ipc_connect_flags(s, pi["fhandle"], 4 * t)  # (a block of its own in "split" mode)
             self.gpu.ipc_ready()
         except Exception as e:
             ok, self._ipc_why = False, str(e)
@@ -326,7 +340,7 @@ class RankSolver:
             self.probe[name] = float(dt.item()) / steps * 1e6
             # a transport whose rows did not all arrive in their slots (or, ipc: a wait that gave up) is
             # out, however fast it looked (all ranks see the same gathered evidence)
-            self.checks[name] = bool(self.exchange_check()["ok"])
+            self.checks[name] = bool(self.exchange_check(stale_read_steps=56)["ok"])
             if not self.checks[name]:
                 del self.probe[name]
                 self.available.remove(name)
@@ -338,12 +352,13 @@ class RankSolver:
             self.transport = "torch"  # nothing device-side is left: torch.distributed P2P ops
         return self.transport
 
-    def exchange_check(self) -> dict:
+    def exchange_check(self, stale_read_steps: int = 0) -> dict:
         """collective: every row that was sent must have arrived in ITS slot.  Per partner slice a
         position-weighted checksum of the rows this rank sent must equal the partner's checksum of the
         ghost rows it received from this rank (row j of a message weighs j+1, so permuted or mis-slotted
         rows do not cancel); something must have been sent at all; no device-side wait may have given up"""
         torch, dist, part = self.torch, self.dist, self.gpu.dom
+        stale = self.stale_read_check(batches=(stale_read_steps,)) if stale_read_steps > 0 else None
         g = self.grad_host()
         mine = {}
         for k in part.partners:
@@ -369,6 +384,9 @@ class RankSolver:
             dist.all_reduce(et)
             chk["wait_timeouts"] = int(et.item())
             chk["ok"] = chk["ok"] and int(et.item()) == 0
+        if stale is not None:  # did any flux phase of `stale_read_steps` more steps read a row of an earlier exchange?
+            chk["stale_read_check"] = stale
+            chk["ok"] = chk["ok"] and stale["ok"]
         return chk
 
     def fallback(self) -> bool:
@@ -403,42 +421,88 @@ class RankSolver:
             self.gpu.ipc_disconnect()
             self.dist.barrier()
 
+    def stale_read_check(self, batches=(1, 2, 3, 5, 8, 60, 107), overlap: bool = True, before_steps=None) -> dict:
+        """collective: can any flux phase have READ a ghost row before the rows of its exchange had landed?  The
+        field is constant in time and the landing arenas alternate, so a row read one exchange early has the value
+        of the right one and no comparison of final states can tell (the reference asserts stage / flag lock-step
+        at every receive instead, src/exchange_data_mpi.c:189,439, src/exchange_data_gaspi.c:389-416).  Here the
+        library scales var by 2, 2, 1/4, ... after every iteration (cfdp_gpu_scaled_check_begin): iteration k's
+        gradients, ghost rows and flux are the first iteration's times 2^((k-1) mod 3) exactly, and a device kernel
+        compares the flux EVERY step produced -- in the schedule that is timed: stream launches, hipGraph replays,
+        in-kernel wait and push -- with reference * 2^e bit for bit.  The reference flux comes from an iteration
+        whose exchange is complete beyond doubt: device sync on every rank, barrier, one step without exchange.
+        `before_steps` (tests): called on every rank between the set-up and the scaled steps."""
+        torch, dist = self.torch, self.dist
+        self.run_steps(2, with_exchange=True, overlap=overlap)  # both grad buffers / arenas hold delivered rows
+        self.synchronize()
+        dist.barrier()
+        self.run_steps(1, with_exchange=False, overlap=overlap)
+        self.synchronize()
+        self.gpu.scaled_check_begin()
+        dist.barrier()
+        if before_steps is not None:
+            before_steps()
+        try:
+            for k in batches:
+                self.run_steps(int(k), with_exchange=True, overlap=overlap)
+        finally:
+            ev = self.gpu.scaled_check_end()
+        err = float(self.gpu.ipc_error() != 0) if self.transport == "ipc" else 0.0
+        t = torch.tensor([float(ev["mismatches"]), float(ev["mismatches"] > 0), err], dtype=torch.float64,
+                         device=self._coll_device())
+        dist.all_reduce(t)
+        tmin = torch.tensor([float(ev["flux_checks"])], dtype=torch.float64, device=self._coll_device())
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        first = None
+        if ev["mismatches"]:
+            first = {"rank": self.rank, "iteration": ev["first_iteration"], "point": ev["first_point"],
+                     "component": ev["first_component"], "seen": ev["seen"], "expected": ev["expected"]}
+        firsts = [None] * self.world
+        dist.all_gather_object(firsts, first)
+        out = {"steps": int(sum(batches)), "flux_fields_compared_per_rank": int(tmin.item()),
+               "stale_reads": int(t[0].item()), "ranks_with_stale_reads": int(t[1].item()),
+               "wait_timeouts": int(t[2].item()), "first": next((f for f in firsts if f), None),
+               "check": "var scaled by 2, 2, 1/4, ... after every iteration; the flux of every step == reference x 2^e, "
+                        "bit for bit, compared on the device",
+               "ok": bool(t[0].item() == 0 and t[2].item() == 0 and tmin.item() >= sum(batches) - 1)}
+        dist.barrier()
+        return out
+
     def validate_exchange(self) -> bool:
-        """collective: after a few iterations every ghost row must equal its owner's row -- checked
-        through the sums of |rows| sent and received over all ranks, for var and for 2*var (a stale
-        copy of a ghost row from the first pass cannot satisfy the second)"""
+        """collective, before a transport is used: (1) no flux phase may read a ghost row early (stale_read_check over
+        stream-launched steps and hipGraph replays), (2) after it every ghost row must equal its owner's row
+        (position-weighted sums of |rows| sent and received over all ranks), (3) no device-side wait may give up.
+        WHICH of them failed is recorded: "stale read" (a flux saw a row of an earlier exchange), "stale rows" (rows
+        that never arrived although every flag did), "wait timeout" (a partner's flag never arrived)"""
         torch, dist, part = self.torch, self.dist, self.gpu.dom
-        sidx = [part.sendindex(k) for k in part.partners]
-        sidx = np.concatenate(sidx) if sidx else np.zeros(0, np.int32)
-        good = True
-        var0 = part.var.copy()
         lib = self.gpu.lib
         lib.cfdp_ipc_set_wait_seconds(2.0)  # a broken mapping must not cost half a minute per iteration here
-        timeouts, worst, nothing_sent = 0, 0.0, False
-        for scale in (1.0, 2.0, 1.0):
-            part.var[:] = var0 * scale
-            self.gpu._ck(self.gpu.lib.cfdp_gpu_set_var(self.gpu.h, part.sd.var))
-            dist.barrier()
-            self.run_steps(4, with_exchange=True, overlap=True)
+        try:
+            ev = self.stale_read_check()
             g = self.grad_host()
-            t = torch.tensor([float(np.abs(g[sidx]).sum()), float(np.abs(g[part.nown:]).sum()),
-                              float(self.gpu.ipc_error() != 0)], dtype=torch.float64, device=self._coll_device())
+            sent = got = 0.0
+            for k in part.partners:
+                sidx, ridx = part.sendindex(k), part.recvindex(k)
+                sent += float((np.abs(g[sidx]).sum(axis=(1, 2)) * np.arange(1, len(sidx) + 1.0)).sum())
+                got += float((np.abs(g[ridx]).sum(axis=(1, 2)) * np.arange(1, len(ridx) + 1.0)).sum())
+            t = torch.tensor([sent, got, float(self.gpu.ipc_error() != 0) if self.transport == "ipc" else 0.0],
+                             dtype=torch.float64, device=self._coll_device())
             dist.all_reduce(t)
             sent, got, err = (float(x) for x in t)
-            timeouts += int(err)
-            nothing_sent = nothing_sent or not sent > 0
-            if sent > 0:
-                worst = max(worst, abs(sent - got) / sent)
-            good = good and err == 0 and sent > 0 and abs(sent - got) <= 1e-9 * sent
-        lib.cfdp_ipc_set_wait_seconds(float(os.environ.get("CFDP_IPC_WAIT_SECONDS", "30")))
-        # WHICH check failed: a wait that gave up (the partner's flag never arrived: mapping / ordering), rows that
-        # arrived late or not at all although every flag did (stale rows: the L2 question of a coarse-grained block),
-        # or nothing to send
-        failed = None if good else ("wait timeout" if timeouts else "nothing sent" if nothing_sent else "stale rows")
+        finally:
+            lib.cfdp_ipc_set_wait_seconds(float(os.environ.get("CFDP_IPC_WAIT_SECONDS", "30")))
+        timeouts = int(err) + ev["wait_timeouts"]
+        worst = abs(sent - got) / sent if sent > 0 else float("inf")
+        rows_ok = sent > 0 and abs(sent - got) <= 1e-9 * sent
+        good = ev["ok"] and rows_ok and timeouts == 0
+        failed = None if good else ("wait timeout" if timeouts else "nothing sent" if not sent > 0 else
+                                    "stale read" if ev["stale_reads"] else "stale rows" if not rows_ok else "too few flux checks")
         self.validation[getattr(self, "_validating", self.transport)] = {
-            "ok": bool(good), "failed": failed, "wait_timeouts": timeouts, "worst_sum_mismatch": worst,
-            "check": "sum |sent rows| vs sum |ghost rows| over all ranks, 4 iterations each with var, 2 var, var"}
-        return good
+            "ok": bool(good), "failed": failed, "wait_timeouts": timeouts, "stale_reads": ev["stale_reads"],
+            "first_stale_read": ev["first"], "steps": ev["steps"], "worst_sum_mismatch": worst,
+            "check": "scaled field: flux of every one of %d steps (stream launches + hipGraph replays) == reference x 2^e "
+                     "on the device; then position-weighted sum |sent rows| vs |ghost rows| over all ranks" % ev["steps"]}
+        return bool(good)
 
     def _init_own_communicator(self) -> None:
         """collective over the process group; raises on every rank alike when a step fails"""

@@ -178,10 +178,27 @@ int  cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int over
  *   cfdp_gpu_ipc_connect  for my partner slot: the partner's handle and where, in ITS block, my
  *                         rows land (both parities) and my arrival counter lives
  *   cfdp_gpu_ipc_ready    switch the context over (the ghost block is then the landing arenas)
- *   cfdp_gpu_ipc_error    1 if a wait for a partner gave up (bounded polling)                 */
+ *   cfdp_gpu_ipc_error    1 if a wait for a partner gave up (bounded polling)
+ * Memory of the block, CFDP_IPC_MODE (the hosts try them in this order and keep the first that passes the scaled-field
+ * validation): "coarse" (default: hipMalloc; system-scope loads and fences in the kernels), "split" (the flag words in
+ * a small fine-grained block of their own, the arenas coarse-grained, an explicit cache invalidate once a tile has
+ * seen its partners' flags), "fine" (everything fine-grained; CFDP_IPC_FINEGRAINED=1 is the older spelling).
+ *   cfdp_gpu_ipc_export_flags   the handle of the block that holds this rank's flag words (the main block's handle
+ *                               again unless the mode is "split")
+ *   cfdp_gpu_ipc_connect_flags  after cfdp_gpu_ipc_connect, before _ready: my arrival counter at partner `slot` lives
+ *                               at flag_off in the block of THAT handle
+ * Notification (src/threads.c:268-311, src/exchange_data_gaspi.c:389-416): the boundary tile that completes partner k's
+ * rows raises k's flag at once, and a boundary tile waits only for the partners it exchanges with -- when every boundary
+ * tile reads ghost rows only of partners it holds send points for (checked at _ready; else, or with
+ * CFDP_IPC_PER_PARTNER=0, the last boundary tile raises all flags and every tile waits for all).
+ *   cfdp_gpu_ipc_mode     bit 0 the fused pass pushes / notifies, bit 1 its tiles wait themselves, bit 2 per-partner
+ *                         notification, bits 4-5 memory mode (0 coarse, 1 fine, 2 split); -1 without a block          */
 int  cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes);
 int  cfdp_gpu_ipc_connect(cfdp_gpu *g, int slot, const void *partner_handle64, size_t land_off0,
                           size_t land_off1, size_t flag_off);
+int  cfdp_gpu_ipc_export_flags(cfdp_gpu *g, void *handle64);
+int  cfdp_gpu_ipc_connect_flags(cfdp_gpu *g, int slot, const void *partner_flags_handle64, size_t flag_off);
+int  cfdp_gpu_ipc_mode(const cfdp_gpu *g);
 int  cfdp_gpu_ipc_ready(cfdp_gpu *g);
 int  cfdp_gpu_ipc_enable(cfdp_gpu *g, int on);   /* keep the mappings, use / do not use them */
 int  cfdp_gpu_ipc_disconnect(cfdp_gpu *g);
@@ -192,6 +209,31 @@ int  cfdp_gpu_step_ipc_post(cfdp_gpu *g, int with_flux, int flux_mode);    /* ..
 int  cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode);
 int  cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
                             int flux_mode, int use_graph);
+
+/* Scaled-field validation of an exchange -- the analogue of the reference's stage / flag lock-step asserts at every
+ * receive (src/exchange_data_mpi.c:189,439, src/exchange_data_gaspi.c:389-416).  The benchmark's field is constant in
+ * time, so a ghost row READ one exchange too early (double-buffered landing arenas: the row of two exchanges ago, same
+ * address, same value) is invisible to any comparison of final states.  Between _begin and _end every step entry point
+ * (cfdp_gpu_step_post, cfdp_gpu_step_ipc[_post], cfdp_gpu_run_steps_ipc / _rccl, cfdp_gpu_rank_flux, the drop-in
+ * compute_psd_flux) ends with one more kernel: it compares the flux the step produced with reference * 2^e bit for bit and
+ * then multiplies var by 2, 2, 1/4, 2, 2, 1/4, ... (exact), so iteration k's gradients, ghost rows and flux are those of
+ * the first iteration times 2^((k-1) mod 3) and a term taken from a row of two exchanges ago is off by 2x or 4x.  The
+ * state lives on the device: the steps replay from hipGraphs as usual.
+ *   _begin  the flux the context holds now becomes the reference: the caller has run one iteration whose exchange is
+ *           known to be complete (device sync on every rank, a barrier, one more step WITHOUT exchange)
+ *   _end    compares the last iteration's deferred flux too, restores var exactly, returns the evidence
+ * While the mode is on every step must exchange and compute the flux.                                                 */
+typedef struct cfdp_scaled_check {
+  int iterations;       /* steps run in the mode                                                        */
+  int flux_checks;      /* flux fields compared (one per step that produced one)                        */
+  int mismatches;       /* flux values that were not reference * 2^e (saturates)                        */
+  int first_iteration;  /* the iteration (1-based, in the mode) whose flux held the first mismatch found, or 0 */
+  int first_point;      /* ... its point, file numbering, or -1                                         */
+  int first_component;
+  double seen, expected;
+} cfdp_scaled_check;
+int  cfdp_gpu_scaled_check_begin(cfdp_gpu *g);
+int  cfdp_gpu_scaled_check_end(cfdp_gpu *g, cfdp_scaled_check *out);
 
 /* measurement: `iters` back-to-back launches bracketed by HIP events on the context's
  * main stream; average milliseconds per launch (gradient over all tiles; flux)           */

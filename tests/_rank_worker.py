@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--per-device", action="store_true",
                     help="one device per rank (LOCAL_RANK) and the nccl backend: the real multi-GPU set-up")
     ap.add_argument("--soak", type=int, default=0, help="extra iterations before the values are checked")
+    ap.add_argument("--inject-early-read", action="store_true",
+                    help="CFDP_IPC_FAULT=skip_wait is set: the comparison of final states must still pass, the scaled-field "
+                         "check must see the ghost rows that were read one exchange early")
     ap.add_argument("--fail-first-validation", action="store_true",
                     help="the first exchange validation reports failure: the set-up must be torn down and retried")
     args = ap.parse_args()
@@ -72,19 +75,45 @@ def main():
             real, calls = mg.RankSolver.validate_exchange, []
 
             def flaky(self):
-                calls.append(os.environ.get("CFDP_IPC_FINEGRAINED", "0"))
+                calls.append(os.environ.get("CFDP_IPC_MODE", "coarse"))
                 return real(self) and len(calls) > 1
             mg.RankSolver.validate_exchange = flaky
-            os.environ.pop("CFDP_IPC_FINEGRAINED", None)
             solver = mg.RankSolver(part, rank, world, 0, dist, transport="ipc", tile_points=32)
-            assert solver.transport == "ipc" and calls == ["0", "1"], (solver.transport, calls)
+            assert solver.transport == "ipc" and calls == ["coarse", "split"], (solver.transport, calls)
+            assert solver.gpu.ipc_mode()["memory"].startswith("split"), solver.gpu.ipc_mode()
             solver.run_steps(60, with_exchange=True, overlap=True)
             g = solver.grad_host()
             assert np.abs(g - truth[gid]).max() / np.abs(truth).max() <= 1e-12
             assert solver.gpu.ipc_error() == 0
             solver.close()
             mg.RankSolver.validate_exchange = real
-            os.environ.pop("CFDP_IPC_FINEGRAINED", None)
+            print(f"RANK_OK {rank}", flush=True)
+            dist.destroy_process_group()
+            return
+        if args.inject_early_read:
+            import time
+            assert os.environ.get("CFDP_IPC_FAULT") == "skip_wait"
+            real = mg.RankSolver.validate_exchange
+            mg.RankSolver.validate_exchange = lambda self: True  # the set-up validation would (rightly) reject the faulty path
+            solver = mg.RankSolver(part, rank, world, 0, dist, transport="ipc", tile_points=32)
+            mg.RankSolver.validate_exchange = real
+            assert solver.transport == "ipc"
+            # (1) what rounds 1-3 checked: states after the run.  Blind: the field is constant in time
+            solver.run_steps(60, with_exchange=True, overlap=True)
+            old = solver.exchange_check()
+            g = solver.grad_host()
+            assert old["ok"], old
+            assert np.abs(g - truth[gid]).max() / np.abs(truth).max() <= 1e-12
+            assert np.abs(part.psd_flux[: part.nown] - ftruth[gid[: part.nown]]).max() / np.abs(ftruth[: whole.nown]).max() <= 1e-12
+            # (2) the scaled field: rank 1 starts late, so every other rank's boundary tiles (which no longer wait)
+            # read rows of earlier exchanges -- each such read is off by 2x or 4x and the device check counts it
+            ev = solver.stale_read_check(batches=(40,), before_steps=(lambda: time.sleep(1.5)) if rank == 1 else None)
+            if rank == 0:
+                import json
+                print("STALE_READ_EVIDENCE " + json.dumps(ev), flush=True)
+            assert not ev["ok"] and ev["stale_reads"] > 0 and ev["first"] is not None, ev
+            assert ev["wait_timeouts"] == 0, ev
+            solver.close()
             print(f"RANK_OK {rank}", flush=True)
             dist.destroy_process_group()
             return
@@ -94,14 +123,18 @@ def main():
                 import json
                 print("VALIDATION " + json.dumps(solver.validation), flush=True)
             assert solver.transport == args.transport, solver.transport  # no silent fallback in the tests
-            if args.soak:
-                solver.run_steps(args.soak, with_exchange=True, overlap=True)
+            if args.soak:  # a long run in the scaled field: no flux phase of any step may have read a row of an earlier exchange
+                ev = solver.stale_read_check(batches=(args.soak,))
+                assert ev["ok"] and ev["stale_reads"] == 0, ev
             for overlap in (True, False):
                 part.grad[:] = 1.0
                 part.psd_flux[:] = 2.0
                 solver.gpu.push_fields()
                 for _ in range(3):  # repeated: buffer reuse hazards, both grad buffers of the fused mode
                     solver.step(with_exchange=True, overlap=overlap, with_flux=True)
+                # the scaled field through this schedule (stream launches, and for ipc hipGraph replays): every step's flux
+                ev = solver.stale_read_check(batches=(1, 2, 3, 5, 8, 57), overlap=overlap)
+                assert ev["ok"] and ev["stale_reads"] == 0 and ev["flux_fields_compared_per_rank"] >= 75, (rank, fusion, overlap, ev)
                 if args.transport == "ipc":  # batches: lead-in steps + hipGraph replays of 50 + remainder
                     solver.run_steps(107, with_exchange=True, overlap=overlap)
                     solver.run_steps(52, with_exchange=True, overlap=overlap)

@@ -87,6 +87,9 @@ def _bench_two_ranks(transport, extra_env=None, expect=None, weak=False):
     assert out["config"]["ghost_points_per_gpu"] > 0 and "overlap" in out
     assert out["overlap"]["efficiency_async"] > 0  # (its size means nothing between ranks time-slicing one GPU)
     assert out["exchange_check"]["ok"], out["exchange_check"]
+    # the post-run leg in the scaled field: no flux phase of 50 more steps read a ghost row of an earlier exchange
+    sr = out["exchange_check"]["stale_read_check"]
+    assert sr["ok"] and sr["stale_reads"] == 0 and sr["steps"] == 50 and sr["flux_fields_compared_per_rank"] >= 49, sr
     assert out["config"]["transport"] == (expect or ("ipc" if transport == "auto" else transport))
     assert out["config"]["fused_iterations"]
     assert "cpu_baseline" not in out  # (--no-cpu here; the self-launched run below carries it)
@@ -189,6 +192,8 @@ def test_bench_gpus2_started_plainly_launches_two_ranks(gpu):
     assert cb["value"] > 0 and "whole 64^3 mesh of this config as one domain" in cb["sample"]
     # what the set-up validation of every attempted transport saw, and which check a rejected one failed
     val = out["config"]["transport_probe_validation"]
-    assert any(k.startswith("ipc") and v["ok"] and v["failed"] is None for k, v in val.items()), val
+    assert any(k.startswith("ipc") and v["ok"] and v["failed"] is None and v["stale_reads"] == 0 and v["steps"] >= 186
+               for k, v in val.items()), val
+    assert out["exchange_check"]["stale_read_check"]["ok"], out["exchange_check"]
     if not shared:
         assert "rccl" in val, val

@@ -63,9 +63,33 @@ def test_multirank_xgmi_write_notify_between_processes_on_one_gpu(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"CFDP_IPC_MODE": "split"}, {"CFDP_IPC_MODE": "fine"}, {"CFDP_IPC_PER_PARTNER": "0"},
+                                 {"CFDP_IPC_WAIT_INKERNEL": "0"}, {"CFDP_IPC_INKERNEL": "0"}])
+def test_multirank_xgmi_write_notify_other_rungs(gpu, env):
+    """the same value checks (and the scaled-field check of every schedule) on the other rungs of the exchange: flags in a
+    fine-grained block of their own with the arenas coarse-grained and an explicit invalidate ("split"), everything
+    fine-grained, one completion counter for all partners instead of one per partner, the wait as a kernel of its own,
+    push / notify as kernels of their own"""
+    _launch(3, ["--gpu", "--transport", "ipc", "--files"], extra_env=env)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,mode", [(2, "coarse"), (2, "fine"), (2, "split"), (3, "coarse"), (4, "fine")])
+def test_scaled_field_check_sees_a_ghost_row_read_one_exchange_early(gpu, world, mode):
+    """fault injection: CFDP_IPC_FAULT=skip_wait makes the boundary tiles of the fused pass read their ghost rows without
+    waiting for the partners' rows of the previous exchange (the wait at the top of the pass is skipped).  The checks of
+    rounds 1-3 -- sums of sent vs received rows after the run, final gradients and flux against the oracle -- PASS on
+    that broken path, because the field is constant in time and the arena still holds the row of two exchanges ago.
+    The scaled-field check (var x 2, 2, 1/4 per iteration, the flux of every step compared on the device) must FAIL
+    it.  Reference analogue: the stage / flag lock-step asserts at every receive, src/exchange_data_mpi.c:189,439."""
+    extra = ["--gpu", "--inject-early-read"] + (["--dims", "16,16,12", "--ndomains", "8"] if world == 4 else [])
+    _launch(world, extra, extra_env={"CFDP_IPC_FAULT": "skip_wait", "CFDP_IPC_MODE": mode})
+
+
+@pytest.mark.gpu
 def test_write_notify_setup_is_retried_with_a_fine_grained_block(gpu):
-    """a failed exchange validation tears the IPC mappings down on every rank and the set-up is retried
-    once with a fine-grained landing block (CFDP_IPC_FINEGRAINED=1) before any other transport is tried"""
+    """a failed exchange validation tears the IPC mappings down on every rank and the set-up is retried with the
+    next memory mode of the landing block (coarse -> split -> fine, CFDP_IPC_MODE) before any other transport is tried"""
     _launch(2, ["--gpu", "--fail-first-validation"])
 
 
@@ -82,8 +106,8 @@ two_devices = pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs (a 
 
 @pytest.mark.gpu
 @two_devices
-@pytest.mark.parametrize("transport,env", [("ipc", {"CFDP_IPC_FINEGRAINED": "0"}), ("ipc", {"CFDP_IPC_FINEGRAINED": "1"}),
-                                           ("rccl", {})])
+@pytest.mark.parametrize("transport,env", [("ipc", {"CFDP_IPC_MODE": "coarse"}), ("ipc", {"CFDP_IPC_MODE": "split"}),
+                                           ("ipc", {"CFDP_IPC_MODE": "fine"}), ("rccl", {})])
 def test_transports_between_two_devices_against_the_oracle(gpu, transport, env):
     """the first thing to run on a multi-GPU node (also: tools/multigpu_selftest.py): one rank per DEVICE, the xGMI
     write + notify exchange with a coarse-grained and with a fine-grained landing block, and the C library's RCCL

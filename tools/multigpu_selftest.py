@@ -4,7 +4,8 @@ values of every rank (owned AND ghost gradient rows, flux) against the un-partit
     python tools/multigpu_selftest.py [NRANKS]
 
   ipc / coarse-grained   xGMI write + notify into a hipMalloc'd landing block (system-scope loads and fences)
-  ipc / fine-grained     the same into a fine-grained block (CFDP_IPC_FINEGRAINED=1)
+  ipc / split            flag words in a fine-grained block of their own, arenas coarse-grained, explicit invalidate
+  ipc / fine-grained     the same into a fine-grained block (CFDP_IPC_MODE=fine)
   rccl                   grouped ncclSend/ncclRecv issued by the C library (cfdp_gpu_step_rccl)
 """
 import os
@@ -14,7 +15,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-cases = [("ipc / coarse-grained", "ipc", {"CFDP_IPC_FINEGRAINED": "0"}), ("ipc / fine-grained", "ipc", {"CFDP_IPC_FINEGRAINED": "1"}),
+cases = [("ipc / coarse-grained", "ipc", {"CFDP_IPC_MODE": "coarse"}), ("ipc / split", "ipc", {"CFDP_IPC_MODE": "split"}),
+         ("ipc / fine-grained", "ipc", {"CFDP_IPC_MODE": "fine"}),
          ("rccl", "rccl", {})]
 results = {}
 for label, transport, env in cases:
