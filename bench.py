@@ -311,6 +311,7 @@ def main() -> None:
                 "transport_probe_us_per_iteration": solver.probe if world > 1 else {},
                 "transport_probe_rows_arrived": solver.checks if world > 1 else {},
                 "transport_probe_validation": solver.validation if world > 1 else {},
+                "exchange_protocol": solver.gpu.ipc_mode() if world > 1 and solver.transport == "ipc" else {},
                 "mesh_iterations_per_s": its, "via_dualgrid_files": not args.no_files,
                 "tiles": solver.gpu.stats["ntiles"], "tile_points": solver.gpu.stats["tile_points"],
                 "setup_s": round(t_setup, 2),
@@ -332,7 +333,10 @@ def main() -> None:
         part.free()
         return res, None, None
 
-    cfg = mg.bench_config(args.config or mg.default_bench_config(world), world)
+    # (CFDP_BENCH_AS_GPUS=N: this run stands in for the N-GPU line -- its config, ride-along and CPU baseline -- with
+    # fewer ranks: the 8-rank command cannot be rehearsed on a box that admits 6 GPU processes)
+    role = mg.bench_role(world)
+    cfg = mg.bench_config(args.config or mg.default_bench_config(role), world)
     res, solver, part = measure(cfg, keep_solver=True)
     nfaces_part, nown, nadd = part.nfaces, part.nown, part.nall - part.nown
 
@@ -345,6 +349,8 @@ def main() -> None:
         "data": "synthetic (F6-like dualgrid stand-in; the f6/dualgrid.N files are not distributed)",
         "config": res["config"],
     }
+    if role != world:
+        out["config"]["rehearsal"] = f"{world} ranks standing in for the {role}-GPU line (CFDP_BENCH_AS_GPUS)"
     for k in ("exchange_check", "overlap"):
         if k in res:
             out[k] = res[k]
@@ -392,7 +398,7 @@ def main() -> None:
 
     # ---- what rides along: --gpus 2 / 4 the weak-scaling point of the same run (262,144 owned points per GPU);
     # --gpus 8 BASELINE config 4 (dualgrid.192 lvl 2, ~33 k points per GPU: the strong-scaling point) ----
-    extra = mg.bench_extra(cfg["name"], world)
+    extra = mg.bench_extra(cfg["name"], role)
     if extra and not (args.no_weak if extra[0] == "weak_scaling" else args.no_strong):
         if solver is not None:
             solver.close()

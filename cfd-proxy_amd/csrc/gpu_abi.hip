@@ -251,7 +251,13 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
   cfdp_gpu *g = new cfdp_gpu();
   g->device = device;
   if (const char *e = getenv("CFDP_DEBUG_ABLATE")) gg_debug_flags = atoi(e);
-  if (const char *e = getenv("CFDP_RESIDENT")) g->resident = atoi(e);
+  if (const char *e = getenv("CFDP_RESIDENT")) {
+    g->resident = atoi(e);
+    if (g->resident < 0 || g->resident > 2) {
+      delete g;
+      return fail("CFDP_RESIDENT=%s: 0 (off), 1 (on where the partition qualifies) or 2 (staleness test)", e);
+    }
+  }
   if (const char *e = getenv("CFDP_FUSED_SPLIT")) gg_fused_split = atoi(e);
   HIP_TRY(hipStreamCreateWithFlags(&g->s_main, hipStreamNonBlocking));
   {
@@ -1124,6 +1130,7 @@ static bool resident_qualifies(const cfdp_gpu *g, const char **why) {
   const int mr = g->max_rows[0] > g->max_rows[1] ? g->max_rows[0] : g->max_rows[1];
   const int mb = g->max_blob[0] > g->max_blob[1] ? g->max_blob[0] : g->max_blob[1];
   if (!g->d_grad_alt) w = "fused iterations are off (no second grad buffer)";
+  else if (g->ipc.on) w = "xGMI landing arenas in use (the resident kernel reads the grad buffers' own ghost blocks)";
   else if (!g->d_rowlist) w = "no fixed-stride row lists (tiles of more than 64 points or 204 rows)";
   else if (tp > 64 || !gg_resident_fits(64, mr - 64 > 0 ? mr - 64 : 0, mb)) w = "a tile exceeds the 36-KiB LDS image";
   else if (g->max_nbr > 64) w = "a tile has more than 64 neighbour tiles";
@@ -1195,6 +1202,16 @@ int cfdp_gpu_time_fused_movement(cfdp_gpu *g, int iters, float *ms_pass) {
   if (iters < 1) return fail("iters must be >= 1");
   if (!g->fusion || !g->d_grad_alt) return fail("fusion is off");
   if (!g->d_rowlist) return fail("no fixed-stride row lists: the movement-only instantiation needs them");
+  {  // the movement-only kernel is an instantiation of the phase-split form: refuse where that form would not run (the
+     // launch would otherwise fall back to the two REAL kernels and their time be reported as the floor)
+    const tile_range r = range_of(g, CFDP_TILES_ALL);
+    const int block = ((r.tp * 4 + 63) / 64) * 64;
+    const int cb = (r.max_blob + block - 1) / block, kv = ((r.tp + r.row_halo()) * 4 + block - 1) / block,
+              kg = ((r.tp + r.row_halo()) * 5 + block - 1) / block;
+    if (!gg_fused_split || g->beside_rccl || block > 1024 || cb > 5 || kv > 4 || kg > 4)
+      return fail("the phase-split fused pass would not run on this partition (CFDP_FUSED_SPLIT=0, or tiles beyond its capacity): "
+                  "no movement-only form to time");
+  }
   if (flush_flux(g)) return 1;
   hipStream_t st = g->s_main;
   const int dbg0 = gg_debug_flags;
@@ -1254,7 +1271,13 @@ static int run_or_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int 
     return fail("bad flux mode %d", flux_mode);
   if (g->resident && g->fusion && resident_qualifies(g, nullptr)) {
     if (!run) return 0;  // nothing to capture: the run is one launch
-    return run_resident(g, iters, with_flux, flux_mode, ms_total);
+    if (run_resident(g, iters, with_flux, flux_mode, ms_total) == 0) return 0;
+    // a neighbour wait gave up: the grid was not co-resident after all (other work on the device: ranks sharing it,
+    // another stream, a profiler).  Say so, switch tile residency off for this context and run the K iterations the
+    // usual way -- every gradient is recomputed from var, so nothing of the failed launch survives
+    fprintf(stderr, "[cfdp] %s -- tile-resident iterations are off for this context from here on; re-running from hipGraphs\n", g_err);
+    g->resident = 0;
+    HIP_TRY(hipDeviceSynchronize());
   }
   if (flush_flux(g)) return 1;
   hipStream_t st = g->s_main;

@@ -16,7 +16,11 @@
  *     thread executes -- cannot be told from a late team mate when the call arrives; it is detected from the
  *     attendance of earlier calls: when call k is performed, every call up to k - CFDP_ELECT_GRACE must have
  *     been attended by its whole team (the reference's per-iteration barrier guarantees that after two calls).
- *     (A team in which ONE thread makes all calls -- omp master -- loses nothing and is left alone.  A team whose
+ *     (A team in which ONE thread makes all calls -- omp master -- loses nothing and is left alone: a call that only
+ *     its performer attended counts against the team only if ANOTHER thread performed it.  That is judged per call, not
+ *     once per solver: a host may run the reference's every-thread regions first and master sections later (going BACK
+ *     to every-thread regions after master sections is not supported in AUTO mode: the threads that sat out cannot be
+ *     told from late team mates of the last master calls, and the run stops with the message below).  A team whose
  *     calls rotate evenly over all its T threads produces exactly the arrivals of T late team mates and cannot be
  *     told apart by anything the library sees: such a host has to select CFDP_CALLS_EVERY itself.)
  *     The run then stops with a message naming the fix (cfdp_set_call_mode(CFDP_CALLS_EVERY) or
@@ -35,20 +39,22 @@
 
 static int g_mode = -1; /* -1: read CFDP_CALL_MODE on first use */
 
-void cfdp_set_call_mode(int mode) { g_mode = mode; }
+void cfdp_set_call_mode(int mode) { __atomic_store_n(&g_mode, mode, __ATOMIC_RELAXED); }
 
-int cfdp_get_call_mode(void) {
-  if (g_mode < 0) {
+int cfdp_get_call_mode(void) { /* (every thread of a team gets here at once: the lazy read is an atomic, -fsanitize=thread found it) */
+  int m = __atomic_load_n(&g_mode, __ATOMIC_RELAXED);
+  if (m < 0) {
     const char *e = getenv("CFDP_CALL_MODE");
-    g_mode = CFDP_CALLS_AUTO;
-    if (e && !strcmp(e, "every")) g_mode = CFDP_CALLS_EVERY;
-    else if (e && !strcmp(e, "team")) g_mode = CFDP_CALLS_TEAM;
+    m = CFDP_CALLS_AUTO;
+    if (e && !strcmp(e, "every")) m = CFDP_CALLS_EVERY;
+    else if (e && !strcmp(e, "team")) m = CFDP_CALLS_TEAM;
     else if (e && *e && strcmp(e, "auto")) {
       fprintf(stderr, "Error: CFDP_CALL_MODE=%s (one of auto, team, every)\n", e);
       exit(EXIT_FAILURE);
     }
+    __atomic_store_n(&g_mode, m, __ATOMIC_RELAXED);
   }
-  return g_mode;
+  return m;
 }
 
 /* ---- "is the caller inside a parallel team, and how large is it?"
@@ -65,10 +71,11 @@ typedef int (*omp_int_fn)(void);
 static omp_int_fn g_in_parallel = NULL, g_num_threads = NULL;
 static int g_team_override = 0;
 
-void cfdp_set_call_team(int nthreads) { g_team_override = nthreads > 0 ? nthreads : 0; }
+void cfdp_set_call_team(int nthreads) { __atomic_store_n(&g_team_override, nthreads > 0 ? nthreads : 0, __ATOMIC_RELAXED); }
 
 static int caller_team_size(void) {
-  if (g_team_override) return g_team_override;
+  const int ov = __atomic_load_n(&g_team_override, __ATOMIC_RELAXED);
+  if (ov) return ov;
   omp_int_fn a = __atomic_load_n(&g_in_parallel, __ATOMIC_ACQUIRE), b = __atomic_load_n(&g_num_threads, __ATOMIC_ACQUIRE);
   if (!a || !b) { /* (looked up again while absent: a host may load its runtime later) */
     a = (omp_int_fn)dlsym(RTLD_DEFAULT, "omp_in_parallel");
@@ -108,14 +115,16 @@ static void violation(const cfdp_election *el, unsigned long k, unsigned long la
 
 static int trace_on(void) { /* CFDP_CALL_TRACE=1: one line per entry-point call on stderr (diagnostics) */
   static int on = -1;
-  if (on < 0) { const char *e = getenv("CFDP_CALL_TRACE"); on = e && *e && *e != '0'; }
-  return on;
+  int v = __atomic_load_n(&on, __ATOMIC_RELAXED);
+  if (v < 0) { const char *e = getenv("CFDP_CALL_TRACE"); v = e && *e && *e != '0'; __atomic_store_n(&on, v, __ATOMIC_RELAXED); }
+  return v;
 }
 
 int cfdp_elect_begin(cfdp_election *el, int kind) {
   /* a team the host has declared itself (cfdp_set_call_team) is taken at its word: no attendance check, which
    * presumes the reference's barrier per iteration */
-  const int mode = g_team_override && cfdp_get_call_mode() == CFDP_CALLS_AUTO ? CFDP_CALLS_TEAM : cfdp_get_call_mode();
+  const int mode = __atomic_load_n(&g_team_override, __ATOMIC_RELAXED) && cfdp_get_call_mode() == CFDP_CALLS_AUTO ? CFDP_CALLS_TEAM
+                                                                                                   : cfdp_get_call_mode();
   const int resync = mode == CFDP_CALLS_AUTO;
   const int team = mode != CFDP_CALLS_EVERY ? caller_team_size() : 1;
   if (team <= 1) { /* serial caller: it performs what it calls */
@@ -136,12 +145,6 @@ int cfdp_elect_begin(cfdp_election *el, int kind) {
     tls_calls[slot].n = 0;
   }
   pthread_mutex_lock(&el->mtx);
-  if (!el->have_first) {
-    el->first = pthread_self();
-    el->have_first = 1;
-  } else if (!pthread_equal(el->first, pthread_self())) {
-    el->several = 1;
-  }
   /* Whether this thread performs is decided by its ordinal alone: call k is new iff k > team_calls.  The ring of
    * recent calls (an entry is trusted only while it still carries its call's ordinal) serves two things: a thread
    * whose ordinal points at a call its whole team has attended was not part of that team and moves forward to the
@@ -174,9 +177,14 @@ int cfdp_elect_begin(cfdp_election *el, int kind) {
   ENTRY(k).attended = 1;
   ENTRY(k).team = team;
   ENTRY(k).kind = kind;
-  if (mode == CFDP_CALLS_AUTO && el->several) /* (one thread making all calls -- omp master -- loses none) */
+  ENTRY(k).performer = pthread_self();
+  /* attendance: an earlier call that its team has not fully attended by now is a violation -- unless this very thread
+   * performed it and nobody else came: one thread making all calls (omp master) loses none */
+  if (mode == CFDP_CALLS_AUTO)
     for (unsigned long j = k > CFDP_ELECT_RING - 1 ? k - (CFDP_ELECT_RING - 1) : 1; j + CFDP_ELECT_GRACE <= k; j++)
-      if (ENTRY(j).ordinal == j && ENTRY(j).attended < ENTRY(j).team) violation(el, k, j);
+      if (ENTRY(j).ordinal == j && ENTRY(j).attended < ENTRY(j).team &&
+          (ENTRY(j).attended > 1 || !pthread_equal(ENTRY(j).performer, pthread_self())))
+        violation(el, k, j);
 #undef ENTRY
   return 1;
 }

@@ -15,9 +15,7 @@ typedef struct cfdp_election {
   unsigned long id;           /* keys the callers' thread-local ordinals */
   unsigned long team_calls;   /* calls performed in team mode */
   unsigned long serial_calls; /* calls performed by serial callers */
-  pthread_t first;            /* the first thread that made a team call ... */
-  int have_first, several;    /* ... and whether any other thread has made one since */
-  struct { unsigned long ordinal; int attended, team, kind; } ring[CFDP_ELECT_RING];
+  struct { unsigned long ordinal; int attended, team, kind; pthread_t performer; } ring[CFDP_ELECT_RING];
 } cfdp_election;
 
 void cfdp_elect_init(cfdp_election *el);

@@ -573,17 +573,22 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
   PLAN_STAGE("point->face CSR");
   /* ---- 2. which owned points are sent (reference htype 2, src/rangelist.c:129-141) ---- */
   unsigned char *is_send = cfdp_calloc((size_t)nown, 1);
+  int *first_partner = NULL; /* per sent point: the first partner (position in commpartner) it is sent to */
   int any_send = 0;
-  if (has_comm && cd->sendindex)
+  if (has_comm && cd->sendindex) {
+    first_partner = cfdp_malloc((size_t)(nown ? nown : 1) * sizeof(int));
+    for (int p = 0; p < nown; p++) first_partner[p] = cd->ncommdomains;
     for (int i = 0; i < cd->ncommdomains; i++) {
       int k = cd->commpartner[i];
       for (int j = 0; j < cd->sendcount[k]; j++) {
         int pnt = cd->sendindex[k][j];
         CFDP_ASSERT(pnt >= 0 && pnt < nown);
         is_send[pnt] = 1;
+        if (i < first_partner[pnt]) first_partner[pnt] = i;
         any_send = 1;
       }
     }
+  }
 
   /* ---- 3. grow tiles ---- */
   tiler T;
@@ -731,6 +736,39 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
     free(txadj); free(tstamp);
   }
 
+  /* ---- 3c. boundary tiles of one partner next to each other at the front of the grid.  The boundary tile that
+   * completes a partner's rows raises that partner's flag at once (per-partner notification, csrc/gg_kernels.hip
+   * push_tile_done; the reference fires partner k's send when k's buffer is complete, src/threads.c:268-311): with the
+   * tiles sorted by their first partner the flags go up partner by partner instead of all near the end of the sheet.
+   * Stable: inside a partner's run the growth order (spatial neighbours) stays. */
+  if (first_partner && P->nbtiles > 1 && !(getenv("CFDP_BTILE_ORDER") && atoi(getenv("CFDP_BTILE_ORDER")) == 0)) {
+    const int nb = P->nbtiles, nk = cd->ncommdomains + 1;
+    int *key = cfdp_malloc((size_t)nb * sizeof(int)), *start = cfdp_calloc((size_t)nk + 1, sizeof(int));
+    for (int t = 0; t < nb; t++) {
+      int k = cd->ncommdomains;
+      for (int i = T.tile_first[t]; i < T.tile_first[t + 1]; i++)
+        if (first_partner[T.order[i]] < k) k = first_partner[T.order[i]];
+      key[t] = k;
+      start[k + 1]++;
+    }
+    for (int k = 0; k < nk; k++) start[k + 1] += start[k];
+    int *seq = cfdp_malloc((size_t)nb * sizeof(int));
+    for (int t = 0; t < nb; t++) seq[start[key[t]]++] = t;
+    const int nbp = T.tile_first[nb]; /* points of the boundary tiles: a prefix of the order */
+    int *norder = cfdp_malloc((size_t)(nbp ? nbp : 1) * sizeof(int)), *nfirst = cfdp_malloc((size_t)(nb + 1) * sizeof(int));
+    int n = 0;
+    for (int k = 0; k < nb; k++) {
+      const int t = seq[k];
+      nfirst[k] = n;
+      for (int i = T.tile_first[t]; i < T.tile_first[t + 1]; i++) norder[n++] = T.order[i];
+    }
+    CFDP_ASSERT(n == nbp);
+    memcpy(T.order, norder, (size_t)nbp * sizeof(int));
+    memcpy(T.tile_first, nfirst, (size_t)nb * sizeof(int));
+    for (int k = 0; k < nb; k++)
+      for (int i = T.tile_first[k]; i < T.tile_first[k + 1]; i++) T.tile_of[T.order[i]] = k;
+    free(key); free(start); free(seq); free(norder); free(nfirst);
+  }
   PLAN_STAGE("supertile order");
   /* ---- 4. renumber: owned points tile-major; ghosts grouped by partner, message order ---- */
   P->new2old = cfdp_malloc((size_t)nall * sizeof(int));
@@ -801,7 +839,7 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
   free(T.hseen);
   free(T.tile_of); free(T.stamp); free(T.seeded); free(T.seedq); free(T.lq);
   free(T.order); free(T.tile_first);
-  free(xadj); free(adj_face); free(adj_other); free(is_send);
+  free(xadj); free(adj_face); free(adj_other); free(is_send); free(first_partner);
   return P;
 }
 

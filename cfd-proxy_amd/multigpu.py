@@ -72,6 +72,18 @@ _BENCH = {
 }
 
 
+def bench_role(n_ranks: int) -> int:
+    """the GPU count whose BASELINE workload a run takes: n_ranks itself, or CFDP_BENCH_AS_GPUS -- a rehearsal of the
+    N-GPU line (its config, its ride-along, its CPU baseline) by fewer ranks on a box that cannot hold N processes"""
+    return int(os.environ.get("CFDP_BENCH_AS_GPUS", "0") or 0) or n_ranks
+
+
+def mesh_divisor() -> int:
+    """CFDP_BENCH_MESH_DIVISOR=d: every bench lattice is d times smaller per axis (contract tests of the multi-rank code
+    paths on a tiny mesh; the line says so)"""
+    return max(1, int(os.environ.get("CFDP_BENCH_MESH_DIVISOR", "1") or 1))
+
+
 def default_bench_config(n_ranks: int) -> str:
     """BASELINE.json: config 2 on 1 GPU, config 3 on 4, config 5 on 8; 2 GPUs continue the strong series"""
     return {1: "dualgrid.12", 2: "dualgrid.24", 4: "dualgrid.48", 8: "dualgrid.384"}.get(n_ranks, "weak")
@@ -91,8 +103,10 @@ def bench_extra(name: str, n_ranks: int):
 def bench_config(name: str, n_ranks: int) -> dict:
     """one bench workload: lattice, number of domains (whole domains per GPU), the text of
     config.workload and the scaling label of the series the run belongs to"""
+    dv = mesh_divisor()
     if name == "weak":
         dims, ndom = bench_mesh(n_ranks)
+        dims = tuple(max(4, x // dv) for x in dims)
         return dict(name="weak", dims=dims, ndomains=ndom, scaling="weak",
                     workload=f"weak-scaling stand-in ({dims[0]}x{dims[1]}x{dims[2]}, {ndom} domains, {ndom // n_ranks} per GPU, "
                              f"262144 owned points per GPU" + (", halo exchange over xGMI)" if n_ranks > 1 else ")"))
@@ -101,7 +115,8 @@ def bench_config(name: str, n_ranks: int) -> dict:
     dims, ndom, level, scaling = _BENCH[name]
     if ndom % n_ranks:
         raise ValueError(f"{name}: {ndom} domains do not divide over {n_ranks} GPUs")
-    what = f"{dims[0]}^3, {ndom} domains, {ndom // n_ranks} per GPU"
+    dims = tuple(max(4, x // dv) for x in dims)
+    what = f"{dims[0]}^3, {ndom} domains, {ndom // n_ranks} per GPU" + (f"; TINY MESH: lattice / {dv} per axis" if dv > 1 else "")
     how = "merged on 1 GPU, no halo exchange" if n_ranks == 1 else "halo exchange over xGMI with compute overlap"
     return dict(name=name, dims=dims, ndomains=ndom, scaling=scaling,
                 workload=f"{name} {level} stand-in ({what}; {how})")

@@ -152,12 +152,14 @@ def _build_call_election_host(tmp_path, lib_name="cfdproxy_host"):
 
 
 @pytest.mark.parametrize("lib_name", ["cfdproxy_host", "cfdproxy_hip"])
-@pytest.mark.parametrize("scenario", ["team", "serial_threads", "mixed", "master", "pthread_team"])
+@pytest.mark.parametrize("scenario", ["team", "serial_threads", "mixed", "master", "pthread_team", "team_then_master"])
 def test_entry_point_calls_are_performed_exactly_once(pkg, tmp_path, scenario, lib_name):
     """host/call_election.c: which caller of compute_gradients_gg_* / compute_psd_flux enqueues the work.  The
     reference's harness (every thread of a team of 4 makes every call, team mates running ahead, src/solver.c:45-55),
     serial callers on ever new threads, serial calls mixed with teams of 4 and 2, one thread of a team making all
-    calls, and a team of pthreads: every call is performed exactly once, in the order it was issued.  Against
+    calls, a team of pthreads, and every-thread regions followed by master sections (the master pattern is judged
+    per call, not once per solver): every call is performed exactly once, in the order
+    it was issued.  Against
     libcfdproxy_hip.so the process holds TWO OpenMP runtimes (the gcc host's libgomp and the libomp hipcc links): the
     team is the one the HOST's runtime knows, and the other runtime is never called (never initialised)"""
     exe = _build_call_election_host(tmp_path, lib_name)

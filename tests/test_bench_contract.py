@@ -197,3 +197,61 @@ def test_bench_gpus2_started_plainly_launches_two_ranks(gpu):
     assert out["exchange_check"]["stale_read_check"]["ok"], out["exchange_check"]
     if not shared:
         assert "rccl" in val, val
+
+
+def test_eight_gpu_line_is_config_5_with_config_4_riding_along(pkg):
+    """what `bench.py --gpus 8` measures (BASELINE.json configs 5 and 4), decided by pure functions of the rank count --
+    and what a rehearsal by fewer ranks (CFDP_BENCH_AS_GPUS=8) takes over"""
+    from cfd_proxy_amd import multigpu as mg
+    assert mg.default_bench_config(8) == "dualgrid.384" and mg.bench_extra("dualgrid.384", 8) == ("strong_scaling", "dualgrid.192")
+    c = mg.bench_config("dualgrid.384", 8)
+    assert c["dims"] == (128, 128, 128) and c["ndomains"] == 384 and c["scaling"] == "weak" and "48 per GPU" in c["workload"]
+    c = mg.bench_config("dualgrid.192", 8)
+    assert c["dims"] == (64, 64, 64) and c["ndomains"] == 192 and "24 per GPU" in c["workload"]
+    os.environ["CFDP_BENCH_AS_GPUS"] = "8"
+    try:
+        assert mg.bench_role(4) == 8 and mg.bench_role(6) == 8
+    finally:
+        del os.environ["CFDP_BENCH_AS_GPUS"]
+    assert mg.bench_role(4) == 4
+    for n in (4, 6, 8):  # the rank counts a rehearsal can use: whole domains per rank
+        assert 384 % n == 0 and 192 % n == 0
+
+
+def test_launcher_starts_eight_ranks(capfd):
+    import bench
+    cmd = [sys.executable, "-c", _FAKE_RANK]
+    assert bench.launch_ranks(8, ["ok", "--gpus", "8"], ndev=8, child_cmd=cmd, timeout=60) == 0
+    out = json.loads([l for l in capfd.readouterr().out.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["argv"] == ["ok", "--gpus", "8"]
+
+
+@pytest.mark.gpu
+def test_bench_eight_gpu_code_path_rehearsed_by_four_ranks_on_a_tiny_mesh(gpu):
+    """the code path of the driver's `bench.py --gpus 8 --steps 20 --warmup 5` -- dualgrid.384 as the workload,
+    dualgrid.192 riding along as `strong_scaling`, the CPU baseline on the config's whole mesh, exchange_check with its
+    scaled-field leg, overlap -- by FOUR self-launched ranks standing in for eight (a GPU box admits 6 GPU processes
+    and this one already is one), on lattices halved per axis so that it takes about a minute"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CFDP_SHARED_GPU="1", CFDP_BENCH_AS_GPUS="8", CFDP_BENCH_MESH_DIVISOR="2")
+    import time
+    t = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "20", "--warmup", "5",
+                        "--cpu-samples", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    wall = time.time() - t
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["steps"] == 20 and out["warmup"] == 5 and "standing in for the 8-GPU line" in out["config"]["rehearsal"]
+    assert out["config"]["baseline_config"] == "dualgrid.384" and out["scaling"] == "weak" and out["config"]["domains"] == 384
+    assert out["config"]["domains_per_gpu"] == 96 and "TINY MESH" in out["config"]["workload"]
+    assert out["exchange_check"]["ok"] and out["exchange_check"]["stale_read_check"]["stale_reads"] == 0
+    assert out["overlap"]["efficiency_async"] > 0 and out["roofline"]["frac"] > 0
+    st = out["strong_scaling"]
+    assert st["config"]["baseline_config"] == "dualgrid.192" and st["scaling"] == "strong" and st["exchange_check"]["ok"], st
+    assert st["exchange_check"]["stale_read_check"]["ok"] and st["overlap"]["efficiency_async"] > 0
+    cb = out["cpu_baseline"]
+    assert cb["value"] > 0 and "whole 64^3 mesh of this config as one domain" in cb["sample"]
+    val = out["config"]["transport_probe_validation"]
+    assert any(k.startswith("ipc") and v["ok"] for k, v in val.items()), val
+    assert out["config"]["exchange_protocol"]["notify"] == "per partner", out["config"]["exchange_protocol"]
+    assert wall < 240, wall

@@ -1,6 +1,8 @@
 """Generator, domain merger and tiler (host C side, CPU only).  The tiler tests restate the
 run-time invariants of the reference's eval.c / thread_comm.c asserts for GPU tiles
 (reference src/eval.c:88-235, src/thread_comm.c:159-205,329-428)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -184,6 +186,25 @@ def test_plan_with_partners_tiles_send_points_first(pkg, orc):
             assert np.array_equal(np.array(plan.send_idx[plan.send_off[s]: plan.send_off[s + 1]]), o2n[si])
             pos += len(ri)
         assert pos == dom.nall
+        # boundary tiles of one partner sit next to each other: sorted by the first partner slot they send to (the tile
+        # that completes a partner's rows raises its flag: per-partner notification), each tile sends to somebody, and
+        # a tile reads ghost rows only of partners it sends to (what the per-partner wait masks rely on)
+        slot_of_send = np.full(dom.nown, plan.npartners, np.int64)  # new numbering -> first slot
+        sends_to = [set() for _ in range(dom.nown)]
+        for s in range(plan.npartners):
+            for p_new in plan.send_idx[plan.send_off[s]: plan.send_off[s + 1]]:
+                slot_of_send[p_new] = min(slot_of_send[p_new], s)
+                sends_to[p_new].add(s)
+        keys = []
+        for t in range(plan.nbtiles):
+            td = plan.tile(t)
+            keys.append(int(slot_of_send[td.pstart: td.pstart + td.npts].min()))
+            s_t = set().union(*[sends_to[i] for i in range(td.pstart, td.pstart + td.npts)])
+            halo = plan.tile_arrays(t)[3]
+            ghost = halo[halo >= dom.nown] - dom.nown
+            r_t = {int(np.searchsorted(np.array(plan.recv_off[1: plan.npartners + 1]), gi, side="right")) for gi in ghost}
+            assert r_t <= s_t, (d, t, r_t, s_t)
+        assert keys == sorted(keys) and keys[-1] < plan.npartners, keys
         g = interpret_plan(plan, dom.var[n2o], dom.pvolume[n2o])
         back = np.empty_like(g)
         back[n2o] = g
@@ -293,3 +314,43 @@ def test_merge_under_an_explicit_domain_map(pkg, orc):
         p.free()
     for d in doms:
         d.free()
+
+
+_PLAN_HASH = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from __graft_entry__ import load_package
+pkg = load_package()
+gp = pkg.gen_params(24, 20, 18, ndomains=6)
+doms = [pkg.gen_domain(gp, d) for d in range(6)]
+part = pkg.merge_domains(doms[:3], [0, 1, 2], 6, 2, 0)
+other = pkg.merge_domains(doms[3:], [3, 4, 5], 6, 2, 1)
+pkg.merge_link_group([part, other])
+plan = pkg.Plan(part, tile_points=32)
+h = hashlib.sha256()
+h.update(np.ascontiguousarray(plan.new2old).tobytes())
+h.update(np.ctypeslib.as_array(plan.p.blob, shape=(plan.p.blob_bytes,)).tobytes())
+h.update(np.ctypeslib.as_array(plan.p.halo_idx, shape=(max(plan.p.nhalo_total, 1),)).tobytes())
+for t in range(plan.ntiles):
+    td = plan.tile(t)
+    h.update(np.array([td.pstart, td.npts, td.nhalo, td.nfaces, td.ninc, td.blob_qw, td.halo_off], np.int64).tobytes())
+h.update(np.ascontiguousarray(part.fpoint).tobytes())
+print("PLAN", plan.ntiles, plan.nbtiles, h.hexdigest())
+"""
+
+
+def test_host_stages_do_not_depend_on_the_thread_count(pkg):
+    """the library's own OpenMP regions (generator, merger, point->face CSR, tile graph, tile blobs) produce the same
+    merged partition and the same plan, bit for bit, on 1, 3 and 8 threads -- the check that stands in for a thread
+    sanitizer on these regions (neither OpenMP runtime of this image is instrumented: cfd-proxy_amd/Makefile, tsan)"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    seen = set()
+    for nthreads in ("1", "3", "8"):
+        r = subprocess.run([sys.executable, "-c", _PLAN_HASH, ROOT], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, CFDP_HOST_THREADS=nthreads, OMP_NUM_THREADS=nthreads))
+        assert r.returncode == 0, r.stdout + r.stderr
+        seen.add([l for l in r.stdout.splitlines() if l.startswith("PLAN")][-1])
+    assert len(seen) == 1, seen
