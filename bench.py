@@ -228,19 +228,31 @@ def main() -> None:
                                 device_id=torch.device("cuda", device) if backend == "nccl" else None)
     coll_device = torch.device("cuda", device) if dist is not None and dist.get_backend() == "nccl" else "cpu"
 
+    walls = {}  # seconds of wall time per phase of this process (rank 0's view), reported as "wall_s"
+    t_start = time.time()
+
+    def lap(key: str, since: float) -> float:
+        now = time.time()
+        walls[key] = round(walls.get(key, 0.0) + now - since, 2)
+        return now
+
     def measure(cfg: dict, keep_solver: bool = False):
         """set-up, W untimed + exactly K timed steps (max over ranks), exchange check, overlap report"""
         dims, ndom = cfg["dims"], cfg["ndomains"]
         gp = pkg.gen_params(*dims, ndomains=ndom)
+        tag = cfg["name"]
         t0 = time.time()
         part, _ = mg.build_rank_partition(gp, ndom, world, rank, via_files=not args.no_files)
         mg.exchange_requests(part, rank, world, dist)
         nfaces_part, nown, nadd = part.nfaces, part.nown, part.nall - part.nown
+        tl = lap(f"{tag}: mesh files, loader, merge", t0)
         solver = mg.RankSolver(part, rank, world, device, dist, transport=args.transport,
                                tile_points=args.tile_points, grad_lanes=args.grad_lanes, flux_lanes=args.flux_lanes,
                                fusion=not args.no_fusion)
+        tl = lap(f"{tag}: plan, upload, transport set-up + validation", tl)
         if world > 1 and args.transport == "auto":
             solver.choose_transport()
+            tl = lap(f"{tag}: transport probe", tl)
         t_setup = time.time() - t0
 
         def barrier():
@@ -297,6 +309,7 @@ def main() -> None:
             rejected.append(solver.transport)
             if not solver.fallback():
                 break
+        tl = lap(f"{tag}: warm-up, timed steps, exchange check", tl)
         its = args.steps / dt  # iterations/s of the whole mesh
         mesh_points = dims[0] * dims[1] * dims[2]
         res = {
@@ -327,6 +340,7 @@ def main() -> None:
             res["overlap"] = {"t_comm_free_ms": dt_free / args.steps * 1e3, "t_async_ms": res["ms_per_step"],
                               "t_bulk_sync_ms": dt_bulk / args.steps * 1e3,
                               "efficiency_async": dt_free / dt, "efficiency_bulk_sync": dt_free / dt_bulk}
+            tl = lap(f"{tag}: overlap report (comm_free, bulk)", tl)
         if keep_solver:
             return res, solver, part
         solver.close()
@@ -362,6 +376,7 @@ def main() -> None:
     #   frac_unique     the bytes one launch must move at least (the fused pass streams the face data ONCE:
     #                   B_grad + B_flux - 32 F) / launch time
     #   frac_traffic    HBM-side bytes from the PMC counters / launch time
+    t_phase = time.time()
     bg = pkg.algo_bytes_grad(nfaces_part, nown, nadd)
     bf = pkg.algo_bytes_flux(nfaces_part, nown, nadd)
     ms_g, ms_f = solver.gpu.time_kernels(500)
@@ -395,6 +410,7 @@ def main() -> None:
             out["roofline"]["movement_only_us"] = None
             out["roofline"]["movement_only_note"] = str(e)[:160]
     out["roofline"]["traffic_source"] = traffic_src
+    t_phase = lap("roofline block", t_phase)
 
     # ---- what rides along: --gpus 2 / 4 the weak-scaling point of the same run (262,144 owned points per GPU);
     # --gpus 8 BASELINE config 4 (dualgrid.192 lvl 2, ~33 k points per GPU: the strong-scaling point) ----
@@ -410,6 +426,7 @@ def main() -> None:
                              if k in xres}
         except Exception as e:  # the extra must never cost the line
             out[extra[0]] = {"error": repr(e)[:300]}
+    t_phase = time.time()
 
     if world > 1:
         # the other ranks are done: the CPU baseline below runs on rank 0's host cores alone
@@ -525,6 +542,9 @@ def main() -> None:
             cpu_dom.free()
             part = None
     if rank == 0:
+        lap("finest level + cpu baseline", t_phase)
+        walls["total (this process, after imports)"] = round(time.time() - t_start, 2)
+        out["wall_s"] = walls
         print(json.dumps(out))
     if solver is not None:
         solver.close()

@@ -1579,12 +1579,12 @@ int cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int overl
 // arenas.  A step needs no communication library and no host involvement beyond kernel launches,
 // so a run of steps is replayed from one hipGraph.
 namespace {
-// polls (~1 us each) before a device-side wait for a partner gives up: about 30 s by default
+// polls (~1 us each) before a device-side wait for a partner gives up: about 10 s by default
 double g_ipc_wait_seconds = 0.0;
 long ipc_max_polls() {
   if (g_ipc_wait_seconds <= 0.0) {
     const char *e = getenv("CFDP_IPC_WAIT_SECONDS");
-    g_ipc_wait_seconds = e && atof(e) > 0 ? atof(e) : 30.0;
+    g_ipc_wait_seconds = e && atof(e) > 0 ? atof(e) : 10.0;
   }
   return (long)(g_ipc_wait_seconds * 1e6);
 }

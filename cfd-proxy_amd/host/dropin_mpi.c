@@ -190,7 +190,7 @@ static int exchange_valid(comm_data *cd, solver_data *sd, cfdp_gpu *gpu, const c
             cd->iProc, ev.first_iteration, ev.first_point, ev.first_component, ev.seen, ev.expected);
   if (why) *why = failed;
   const char *w = getenv("CFDP_IPC_WAIT_SECONDS");
-  cfdp_ipc_set_wait_seconds(w && atof(w) > 0 ? atof(w) : 30.0);
+  cfdp_ipc_set_wait_seconds(w && atof(w) > 0 ? atof(w) : 10.0);
   memcpy(sd->var, var0, nall * NGRAD * sizeof(double));
   memcpy(sd->grad, grad0, nall * NGRAD * 3 * sizeof(double));
   memcpy(sd->psd_flux, flux0, nall * NFLUX * sizeof(double));
@@ -218,6 +218,11 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
     int all_one_node = nsize == G, agreed = 0;
     MPI_Allreduce(&all_one_node, &agreed, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
     try_ipc = agreed;
+    /* ranks that SHARE a device must not wait inside the fused pass: the boundary tiles of every rank would sit in the
+     * device's workgroup slots, spinning, while the pass whose flags they wait for cannot get a slot (measured: 4 ranks
+     * at 128^3 on one MI355X starve each other until the bounded waits give up).  One waiting workgroup per rank (the
+     * wait kernel) cannot exhaust the device. */
+    if (nsize > cfdp_gpu_device_count()) setenv("CFDP_IPC_WAIT_INKERNEL", "0", 0);
   }
   /* the memory modes of the landing block (cfdproxy_hip.h, CFDP_IPC_MODE), in the order they are tried; a mode the
    * environment names is the only one tried */

@@ -240,6 +240,12 @@ class RankSolver:
         self.validation: Dict[str, dict] = {}
         if transport in ("ipc", "auto") and world > 1:
             import sys
+            if os.environ.get("CFDP_SHARED_GPU") == "1" or world > max(torch.cuda.device_count(), 1):
+                # ranks that SHARE a device must not wait inside the fused pass: the boundary tiles of every rank would
+                # sit in the device's workgroup slots, spinning, while the pass whose flags they wait for cannot get a
+                # slot (measured: 4 ranks at 128^3 on one MI355X starve each other until the bounded waits give up).
+                # One waiting workgroup per rank (the wait kernel) cannot exhaust the device
+                os.environ.setdefault("CFDP_IPC_WAIT_INKERNEL", "0")
             # the memory modes of the landing block, in the order they are tried (every rank fails or passes alike:
             # _init_ipc raises from all-reduced evidence only); a mode set in the environment is the only one tried
             for mode in ipc_mode_attempts():
@@ -491,7 +497,10 @@ class RankSolver:
         that never arrived although every flag did), "wait timeout" (a partner's flag never arrived)"""
         torch, dist, part = self.torch, self.dist, self.gpu.dom
         lib = self.gpu.lib
-        lib.cfdp_ipc_set_wait_seconds(2.0)  # a broken mapping must not cost half a minute per iteration here
+        # a broken mapping must not cost half a minute per iteration here; ranks that time-slice ONE device (rehearsals)
+        # wait for each other's turn on it, which takes seconds with 6 of them
+        lib.cfdp_ipc_set_wait_seconds(float(os.environ.get("CFDP_IPC_VALIDATE_WAIT_SECONDS") or
+                                            (20.0 if os.environ.get("CFDP_SHARED_GPU") == "1" else 2.0)))
         try:
             ev = self.stale_read_check()
             g = self.grad_host()
@@ -505,7 +514,7 @@ class RankSolver:
             dist.all_reduce(t)
             sent, got, err = (float(x) for x in t)
         finally:
-            lib.cfdp_ipc_set_wait_seconds(float(os.environ.get("CFDP_IPC_WAIT_SECONDS", "30")))
+            lib.cfdp_ipc_set_wait_seconds(float(os.environ.get("CFDP_IPC_WAIT_SECONDS", "10")))
         timeouts = int(err) + ev["wait_timeouts"]
         worst = abs(sent - got) / sent if sent > 0 else float("inf")
         rows_ok = sent > 0 and abs(sent - got) <= 1e-9 * sent

@@ -203,7 +203,7 @@ int  cfdp_gpu_ipc_ready(cfdp_gpu *g);
 int  cfdp_gpu_ipc_enable(cfdp_gpu *g, int on);   /* keep the mappings, use / do not use them */
 int  cfdp_gpu_ipc_disconnect(cfdp_gpu *g);
 int  cfdp_gpu_ipc_error(cfdp_gpu *g);
-int  cfdp_ipc_set_wait_seconds(double seconds);   /* bound of the device-side waits (default 30 s) */
+int  cfdp_ipc_set_wait_seconds(double seconds);   /* bound of the device-side waits (default 10 s) */
 int  cfdp_gpu_step_ipc_pre(cfdp_gpu *g, int with_exchange, int overlap);  /* gradients + exchange ... */
 int  cfdp_gpu_step_ipc_post(cfdp_gpu *g, int with_flux, int flux_mode);    /* ... then the flux         */
 int  cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode);

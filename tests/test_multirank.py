@@ -57,9 +57,12 @@ def test_multirank_xgmi_write_notify_between_processes_on_one_gpu(gpu):
     arenas through HIP IPC handles, push rows and flags into them from kernels, poll flags on the
     device, replay steps from hipGraphs; owned AND ghost gradient rows and the flux are checked
     against the un-partitioned mesh"""
-    _launch(2, ["--gpu", "--transport", "ipc"])
-    _launch(3, ["--gpu", "--transport", "ipc", "--files"])
-    _launch(4, ["--gpu", "--transport", "ipc", "--dims", "16,16,12", "--ndomains", "8"])
+    # (ranks that share a device use the wait kernel by default -- waiting boundary tiles of several ranks can fill the
+    # device; these meshes are small, and the wait INSIDE the fused pass is the path a rank with its own GPU takes)
+    inkernel = {"CFDP_IPC_WAIT_INKERNEL": "1"}
+    _launch(2, ["--gpu", "--transport", "ipc"], extra_env=inkernel)
+    _launch(3, ["--gpu", "--transport", "ipc", "--files"], extra_env=inkernel)
+    _launch(4, ["--gpu", "--transport", "ipc", "--dims", "16,16,12", "--ndomains", "8"], extra_env=inkernel)
 
 
 @pytest.mark.gpu
@@ -70,7 +73,7 @@ def test_multirank_xgmi_write_notify_other_rungs(gpu, env):
     fine-grained block of their own with the arenas coarse-grained and an explicit invalidate ("split"), everything
     fine-grained, one completion counter for all partners instead of one per partner, the wait as a kernel of its own,
     push / notify as kernels of their own"""
-    _launch(3, ["--gpu", "--transport", "ipc", "--files"], extra_env=env)
+    _launch(3, ["--gpu", "--transport", "ipc", "--files"], extra_env=dict({"CFDP_IPC_WAIT_INKERNEL": "1"}, **env))
 
 
 @pytest.mark.gpu
@@ -83,7 +86,7 @@ def test_scaled_field_check_sees_a_ghost_row_read_one_exchange_early(gpu, world,
     The scaled-field check (var x 2, 2, 1/4 per iteration, the flux of every step compared on the device) must FAIL
     it.  Reference analogue: the stage / flag lock-step asserts at every receive, src/exchange_data_mpi.c:189,439."""
     extra = ["--gpu", "--inject-early-read"] + (["--dims", "16,16,12", "--ndomains", "8"] if world == 4 else [])
-    _launch(world, extra, extra_env={"CFDP_IPC_FAULT": "skip_wait", "CFDP_IPC_MODE": mode})
+    _launch(world, extra, extra_env={"CFDP_IPC_FAULT": "skip_wait", "CFDP_IPC_MODE": mode, "CFDP_IPC_WAIT_INKERNEL": "1"})
 
 
 @pytest.mark.gpu
