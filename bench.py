@@ -386,9 +386,13 @@ def main() -> None:
 
     def fracs(alg, uniq, tr, ms):
         gbs = lambda b: b / (ms * 1e-3) / 1e9
+        # traffic / traffic_committed: HBM bytes per launch from the PMC counters, read from the newest COMMITTED
+        # profiles/rNN_traffic.json (PMC passes cannot run inside this process), never measured in this run --
+        # traffic_source names the file and says whether the kernel sources have changed since
         return {"achieved": gbs(alg), "frac": gbs(alg) / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg,
                 "unique_bytes_per_launch": uniq, "frac_unique": gbs(uniq) / HBM_PEAK_GBS,
-                "traffic": tr, "frac_traffic": gbs(tr) / HBM_PEAK_GBS if tr else None, "us_per_launch": ms * 1e3}
+                "traffic": tr, "traffic_committed": tr, "frac_traffic": gbs(tr) / HBM_PEAK_GBS if tr else None,
+                "us_per_launch": ms * 1e3}
     grad_k = {"kernel": "gg_gradient_dma_kernel", **fracs(bg, bg, traffic.get("gg_gradient"), ms_g)}
     flux_k = {"kernel": "gg_flux_dma_kernel", **fracs(bf, bf, traffic.get("gg_flux"), ms_f)}
     if args.no_fusion:

@@ -243,6 +243,9 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_rank_gradients.argtypes = [P(vp), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_rank_flux.argtypes = [P(vp), C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_sync_group.argtypes = [P(vp), C.c_int]
+    lib.cfdp_gpu_rank_gradients_launch.argtypes = [P(vp), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.cfdp_gpu_rank_gradients_send.argtypes = [P(vp), C.c_int, C.c_int]
+    lib.cfdp_gpu_enable_peer_access.argtypes = [P(vp), C.c_int, P(C.c_int)]
     lib.cfdp_gpu_step_pre.argtypes = [vp, C.c_int, C.c_int]
     lib.cfdp_gpu_step_post.argtypes = [vp, C.c_int, C.c_int]
     lib.cfdp_gpu_time_kernels.argtypes = [vp, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]
@@ -880,6 +883,55 @@ def group_iteration(parts: Sequence[GpuPartition], with_exchange=True, overlap=T
     rc = lib.cfdp_gpu_iteration_group(arr, len(parts), int(with_exchange), int(overlap), int(with_flux), flux_mode)
     if rc:
         raise GpuError(lib.cfdp_gpu_last_error().decode())
+
+
+def group_iterations_threaded(parts: Sequence[GpuPartition], iters: int, with_exchange=True, overlap=True, with_flux=True,
+                              flux_mode=FLUX_CONSISTENT) -> None:
+    """`iters` iterations of G in-process ranks driven by G host threads, thread r enqueuing rank r's work ("thread t
+    drives device t"): phase 1 in its two parts with a barrier behind each (cfdp_gpu_rank_gradients_launch /
+    _send), then the flux -- what the drop-in layer's test_solver does with pthreads"""
+    import threading
+    lib = hip_lib()
+    G = len(parts)
+    arr = (C.c_void_p * G)(*[p.h for p in parts])
+    bar = threading.Barrier(G)
+    errors: List[str] = []
+
+    def body(r: int) -> None:
+        try:
+            for _ in range(iters):
+                rc = lib.cfdp_gpu_rank_gradients_launch(arr, G, r, int(with_exchange), int(overlap))
+                if rc:
+                    errors.append(lib.cfdp_gpu_last_error().decode())
+                bar.wait()
+                if lib.cfdp_gpu_rank_gradients_send(arr, G, r):
+                    errors.append(lib.cfdp_gpu_last_error().decode())
+                bar.wait()
+                if lib.cfdp_gpu_rank_flux(arr, G, r, int(with_flux), flux_mode):
+                    errors.append(lib.cfdp_gpu_last_error().decode())
+        except threading.BrokenBarrierError:
+            pass
+        except Exception as e:  # never leave the other threads at the barrier
+            errors.append(repr(e))
+            bar.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise GpuError("; ".join(errors[:3]))
+
+
+def enable_peer_access(parts: Sequence[GpuPartition]) -> int:
+    """hipDeviceEnablePeerAccess between the devices of the ranks; returns the ordered device pairs enabled"""
+    lib = hip_lib()
+    arr = (C.c_void_p * len(parts))(*[p.h for p in parts])
+    n = C.c_int()
+    if lib.cfdp_gpu_enable_peer_access(arr, len(parts), C.byref(n)):
+        raise GpuError(lib.cfdp_gpu_last_error().decode())
+    return n.value
 
 
 def vcycle(levels: Sequence[GpuPartition], sweeps: int = 3, cycles: int = 1, flux_mode: int = FLUX_CONSISTENT,

@@ -860,8 +860,12 @@ int cfdp_gpu_step_post(cfdp_gpu *g, int with_flux, int flux_mode) {
 }
 
 // ----------------------------------------------------------------- in-process rank group
-// Phase 1 of rank a's iteration: gradients (+ pack + peer copies into the partners' ghost rows).
-int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, int overlap) {
+// Phase 1 of rank a's iteration: gradients (+ pack + peer copies into the partners' ghost rows).  Two parts, so that G
+// host threads can drive G devices: _launch enqueues rank a's own kernels (and swaps its grad buffers in fused mode),
+// _send the copies into the partners -- once EVERY rank of the group has done its _launch (the caller's barrier), so
+// that "the partner's ghost block of this iteration" is simply its current one.  cfdp_gpu_rank_gradients does both for a
+// single caller that walks the ranks one after the other (a partner may then not have swapped yet: handled in place).
+static int rank_launch(cfdp_gpu **ranks, int G, int a, int with_exchange, int overlap) {
   if (!ranks || G < 1 || a < 0 || a >= G) return fail("bad rank group");
   cfdp_gpu *ga = ranks[a];
   NEED_UPLOAD(ga);
@@ -892,6 +896,14 @@ int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, i
     HIP_TRY(hipStreamWaitEvent(ga->s_comm, ga->ev_pack, 0));
   }
   if (fused) fused_done(ga);
+  return 0;
+}
+
+static int rank_send(cfdp_gpu **ranks, int G, int a) {
+  if (!ranks || G < 1 || a < 0 || a >= G) return fail("bad rank group");
+  cfdp_gpu *ga = ranks[a];
+  NEED_UPLOAD(ga);
+  if (!ga->pending_exchange) return 0;
   for (size_t s = 0; s < ga->partner.size(); s++) {
     const int b = ga->partner[s];
     if (b < 0 || b >= G) return fail("partner rank %d outside the in-process group", b);
@@ -903,9 +915,8 @@ int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, i
     size_t sbytes = 0, rbytes = 0;
     void *from = cfdp_gpu_send_ptr(ga, (int)s, &sbytes);
     void *dst = cfdp_gpu_recv_ptr(gb, slot, &rbytes);
-    // b's ghost block of THIS iteration: ranks of a group run their phases in lockstep, so b
-    // has either done its phase 1 already (iter equal: its buffers are swapped) or will fuse
-    // -- and swap -- when it gets there
+    // b's ghost block of THIS iteration: b has either done its launch part already (iter equal: its buffers are
+    // swapped) or -- single caller walking the ranks in order -- will fuse, and swap, when it gets there
     if (gb->iter != ga->iter && gb->will_fuse())
       dst = gb->alt_view().ghost + (size_t)gb->recv_off[slot] * 21;
     if (sbytes != rbytes) return fail("halo size mismatch %d->%d: %zu vs %zu bytes", a, b, sbytes, rbytes);
@@ -915,6 +926,42 @@ int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, i
     HIP_TRY(hipMemcpyPeerAsync(dst, gb->device, from, ga->device, sbytes, ga->s_comm));
   }
   HIP_TRY(hipEventRecord(ga->ev_senddone, ga->s_comm));
+  return 0;
+}
+
+int cfdp_gpu_rank_gradients_launch(cfdp_gpu **ranks, int G, int a, int with_exchange, int overlap) {
+  return rank_launch(ranks, G, a, with_exchange, overlap);
+}
+int cfdp_gpu_rank_gradients_send(cfdp_gpu **ranks, int G, int a) { return rank_send(ranks, G, a); }
+
+int cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, int overlap) {
+  if (rank_launch(ranks, G, a, with_exchange, overlap)) return 1;
+  return rank_send(ranks, G, a);
+}
+
+// direct loads / stores and copies between the devices of a group: hipDeviceEnablePeerAccess for every pair of ranks
+// that live on different devices (already enabled is fine).  *npairs (optional) = pairs enabled or found enabled;
+// a pair the runtime refuses is not an error (copies then travel through the host): the count says so.
+int cfdp_gpu_enable_peer_access(cfdp_gpu **ranks, int G, int *npairs) {
+  if (!ranks || G < 1) return fail("bad rank group");
+  int n = 0;
+  for (int a = 0; a < G; a++)
+    for (int b = 0; b < G; b++) {
+      if (!ranks[a] || !ranks[b] || ranks[a]->device == ranks[b]->device) continue;
+      bool seen = false;  // one call per ordered device pair
+      for (int c = 0; c < a && !seen; c++)
+        for (int d = 0; d < G && !seen; d++)
+          seen = ranks[c] && ranks[d] && ranks[c]->device == ranks[a]->device && ranks[d]->device == ranks[b]->device;
+      if (seen) continue;
+      int can = 0;
+      HIP_TRY(hipDeviceCanAccessPeer(&can, ranks[a]->device, ranks[b]->device));
+      if (!can) continue;
+      HIP_TRY(hipSetDevice(ranks[a]->device));
+      const hipError_t e = hipDeviceEnablePeerAccess(ranks[b]->device, 0);
+      if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) n++;
+      (void)hipGetLastError();
+    }
+  if (npairs) *npairs = n;
   return 0;
 }
 

@@ -31,6 +31,11 @@ typedef struct cfdp_group {
   solver_data **sds;     /* [G] */
   comm_data **cds;       /* [G] */
   int flux_mode;
+  /* G host threads, thread r driving rank r's device (group_run_threaded): the entry points then run phase 1 in two
+   * parts with a barrier between the threads after each (cfdp_gpu_rank_gradients_launch / _send) */
+  int threaded;
+  pthread_barrier_t bar;
+  int peers_enabled;
 } cfdp_group;
 
 typedef struct cfdp_solver { /* what solver_data.gpu points to */
@@ -162,6 +167,16 @@ void init_threads(comm_data *cd, solver_data *sd, int NTHREADS) {
   cfdp_elect_init(&sv->calls);
   sd->gpu = sv;
   cfdp_sync_fields_to_device(sd);
+  { /* the last rank of an in-process group: copies between its devices go over xGMI directly */
+    int complete = grp->G > 1 && !grp->peers_enabled;
+    for (int r = 0; r < grp->G && complete; r++) complete = grp->gpus[r] != NULL;
+    if (complete) {
+      int pairs = 0;
+      GPU_OK(cfdp_gpu_enable_peer_access(grp->gpus, grp->G, &pairs));
+      grp->peers_enabled = 1;
+      if (getenv("CFDP_PLAN_TRACE")) fprintf(stderr, "[cfdp] peer access enabled for %d device pair(s)\n", pairs);
+    }
+  }
   /* one rank per process: set up (and validate) the data path to the partner ranks' GPUs */
   const cfdp_mpi_hooks *h = cfdp_get_mpi_hooks();
   if (h && h->attach && grp->G == 1 && cd->nProc > 1 && cd->ndomains > 1) h->attach(cd, sd);
@@ -226,10 +241,50 @@ static void gradients(solver_data *sd, int with_exchange, int overlap, int final
   } else if (sv->external) { /* step bracket + this iteration's RCCL group; compute_psd_flux closes the step */
     GPU_OK(cfdp_gpu_step_pre(sv->gpu, with_exchange, overlap));
     if (with_exchange) GPU_OK(cfdp_gpu_exchange_rccl(sv->gpu));
+  } else if (sv->group->threaded) { /* every rank's thread is in this call right now (group_run_threaded) */
+    GPU_OK(cfdp_gpu_rank_gradients_launch(sv->group->gpus, sv->group->G, sv->rank, with_exchange, overlap));
+    pthread_barrier_wait(&sv->group->bar); /* every rank has launched (and swapped its grad buffers) */
+    GPU_OK(cfdp_gpu_rank_gradients_send(sv->group->gpus, sv->group->G, sv->rank));
+    pthread_barrier_wait(&sv->group->bar); /* every copy is enqueued and its completion event recorded */
   } else {
     GPU_OK(cfdp_gpu_rank_gradients(sv->group->gpus, sv->group->G, sv->rank, with_exchange, overlap));
   }
   call_end(sv);
+}
+
+/* ---- G host threads for G in-process ranks: thread r drives rank r ("thread t drives device t").  One
+ * caller enqueuing rank after rank is host-bound at 8 GPUs x 10-us iterations (3-5 launches per rank and iteration).
+ * The threads are pthreads, not an OpenMP team: to the call election every one of them is a serial caller that
+ * performs what it calls.  CFDP_GROUP_THREADS=0: the single caller walks the ranks as before.                       */
+typedef void (*rank_body)(cfdp_group *grp, int r, void *ctx);
+typedef struct { cfdp_group *grp; int r; rank_body body; void *ctx; } rank_thread;
+
+static void *rank_thread_main(void *p) {
+  rank_thread *t = (rank_thread *)p;
+  t->body(t->grp, t->r, t->ctx);
+  return NULL;
+}
+
+static int group_threads_wanted(const cfdp_group *grp) {
+  const char *e = getenv("CFDP_GROUP_THREADS");
+  return grp->G > 1 && !(e && atoi(e) == 0);
+}
+
+static void group_run_threaded(cfdp_group *grp, rank_body body, void *ctx) {
+  const int G = grp->G;
+  pthread_t *th = cfdp_malloc((size_t)G * sizeof(pthread_t));
+  rank_thread *arg = cfdp_malloc((size_t)G * sizeof(rank_thread));
+  CFDP_ASSERT(pthread_barrier_init(&grp->bar, NULL, (unsigned)G) == 0);
+  grp->threaded = 1;
+  for (int r = 0; r < G; r++) {
+    arg[r].grp = grp; arg[r].r = r; arg[r].body = body; arg[r].ctx = ctx;
+    if (r > 0) CFDP_ASSERT(pthread_create(&th[r], NULL, rank_thread_main, &arg[r]) == 0);
+  }
+  rank_thread_main(&arg[0]);
+  for (int r = 1; r < G; r++) pthread_join(th[r], NULL);
+  grp->threaded = 0;
+  pthread_barrier_destroy(&grp->bar);
+  free(th); free(arg);
 }
 
 void compute_gradients_gg_comm_free(comm_data *cd, solver_data *sd, int final) {
@@ -308,10 +363,37 @@ void sort_median(double *begin, double *end) { /* [begin, end): `end` is exclusi
  * rank groups.  One rank per level: the whole cycle is one hipGraph (cfdp_gpu_vcycle); several
  * ranks: stream launches with the overlapped ("async") exchange.  Prints the median seconds
  * per cycle over N_MEDIAN samples of NCYCLES cycles, in the style of the TIMINGS block.      */
+/* one rank's share of `ncycles` V cycles on its own host thread (group_run_threaded on the finest level's group: its
+ * barrier serves every level, all groups have the same G) */
+typedef struct { int nlevels; cfdp_group **levels; int sweeps, ncycles; double seconds; } vcycle_ctx;
+static void vcycle_rank_body(cfdp_group *g0, int r, void *p) {
+  vcycle_ctx *c = (vcycle_ctx *)p;
+  for (int l = 0; l < c->nlevels; l++) GPU_OK(cfdp_gpu_sync(c->levels[l]->gpus[r]));
+  pthread_barrier_wait(&g0->bar);
+  double t = -cfdp_now();
+  for (int cy = 0; cy < c->ncycles; cy++)
+    for (int v = 0; v < 2 * c->nlevels - 1; v++) {
+      cfdp_group *g = c->levels[v < c->nlevels ? v : 2 * c->nlevels - 2 - v];
+      for (int i = 0; i < c->sweeps; i++) {
+        GPU_OK(cfdp_gpu_rank_gradients_launch(g->gpus, g->G, r, 1, 1));
+        pthread_barrier_wait(&g0->bar);
+        GPU_OK(cfdp_gpu_rank_gradients_send(g->gpus, g->G, r));
+        pthread_barrier_wait(&g0->bar);
+        GPU_OK(cfdp_gpu_rank_flux(g->gpus, g->G, r, 1, g->flux_mode));
+      }
+    }
+  for (int l = 0; l < c->nlevels; l++) GPU_OK(cfdp_gpu_sync(c->levels[l]->gpus[r]));
+  pthread_barrier_wait(&g0->bar);
+  if (r == 0) c->seconds = t + cfdp_now();
+}
+
 void cfdp_test_vcycle(int nlevels, cfdp_group **levels, int sweeps, int ncycles) {
   CFDP_ASSERT(nlevels >= 1 && levels != NULL && sweeps >= 1 && ncycles >= 1);
-  int single = 1;
-  for (int l = 0; l < nlevels; l++) single = single && levels[l]->G == 1;
+  int single = 1, threads = group_threads_wanted(levels[0]);
+  for (int l = 0; l < nlevels; l++) {
+    single = single && levels[l]->G == 1;
+    threads = threads && levels[l]->G == levels[0]->G; /* one thread per rank walks all levels */
+  }
   double median[N_MEDIAN];
   cfdp_gpu **lv = cfdp_calloc((size_t)nlevels, sizeof(*lv));
   for (int l = 0; l < nlevels; l++) lv[l] = levels[l]->gpus[0];
@@ -320,6 +402,10 @@ void cfdp_test_vcycle(int nlevels, cfdp_group **levels, int sweeps, int ncycles)
       float ms = 0.f;
       GPU_OK(cfdp_gpu_vcycle(lv, nlevels, sweeps, ncycles, levels[0]->flux_mode, 1, &ms));
       median[k] = (double)ms * 1e-3;
+    } else if (threads) {
+      vcycle_ctx ctx = {nlevels, levels, sweeps, ncycles, 0.0};
+      group_run_threaded(levels[0], vcycle_rank_body, &ctx);
+      median[k] = ctx.seconds / ncycles;
     } else {
       for (int l = 0; l < nlevels; l++) GPU_OK(cfdp_gpu_sync_group(levels[l]->gpus, levels[l]->G));
       double t = -cfdp_now();
@@ -359,6 +445,31 @@ static int cmp_double(const void *a, const void *b) {
 
 typedef void (*grad_fn)(comm_data *, solver_data *, int);
 
+/* one rank's share of the harness loop (src/solver.c:42-58), on its own host thread: the barrier between the threads
+ * plays MPI_Barrier's part, thread 0 reads the clock */
+typedef struct { int nvar, niter; grad_fn *fns; double *median; } solver_ctx;
+static void solver_rank_body(cfdp_group *grp, int r, void *p) {
+  solver_ctx *c = (solver_ctx *)p;
+  for (int k = 0; k < N_MEDIAN; k++) {
+    for (int v = 0; v < c->nvar; v++) {
+      GPU_OK(cfdp_gpu_sync(grp->gpus[r]));
+      pthread_barrier_wait(&grp->bar);
+      double t = -cfdp_now();
+      for (int i = 0; i < c->niter; i++) {
+        c->fns[v](grp->cds[r], grp->sds[r], i == c->niter - 1);
+        compute_psd_flux(grp->sds[r]);
+      }
+      GPU_OK(cfdp_gpu_sync(grp->gpus[r]));
+      pthread_barrier_wait(&grp->bar);
+      if (r == 0) c->median[v * N_MEDIAN + k] = t + cfdp_now();
+    }
+    if (r == 0) {
+      printf(".");
+      fflush(stdout);
+    }
+  }
+}
+
 /* Times every in-process rank of the group `cd` belongs to (the reference times one MPI
  * rank between barriers, src/solver.c:42-58; here the barrier is a device sync of the
  * whole group).  Prints the reference's TIMINGS block (src/solver.c:288-311): the same ten
@@ -388,24 +499,29 @@ void test_solver(comm_data *cd, solver_data *sd, int NTHREADS) {
   int nvar = single ? 1 : N_SOLVER;
   const cfdp_mpi_hooks *hooks = sv->external ? cfdp_get_mpi_hooks() : NULL; /* ranks in other processes */
   const int talk = !hooks || cd->iProc == 0;
-  for (int k = 0; k < N_MEDIAN; k++) {
-    for (int v = 0; v < nvar; v++) {
-      GPU_OK(cfdp_gpu_sync_group(grp->gpus, G));
-      if (hooks && hooks->barrier) hooks->barrier(); /* MPI_Barrier, src/solver.c:44 */
-      double t = -cfdp_now();
-      for (int i = 0; i < sd->niter; i++) {
-        int final = (i == sd->niter - 1);
-        for (int r = 0; r < G; r++) fns[v](grp->cds[r], grp->sds[r], final);
-        for (int r = 0; r < G; r++) compute_psd_flux(grp->sds[r]);
+  if (!hooks && group_threads_wanted(grp)) {
+    solver_ctx ctx = {nvar, sd->niter, fns, &median[0][0]};
+    group_run_threaded(grp, solver_rank_body, &ctx);
+  } else {
+    for (int k = 0; k < N_MEDIAN; k++) {
+      for (int v = 0; v < nvar; v++) {
+        GPU_OK(cfdp_gpu_sync_group(grp->gpus, G));
+        if (hooks && hooks->barrier) hooks->barrier(); /* MPI_Barrier, src/solver.c:44 */
+        double t = -cfdp_now();
+        for (int i = 0; i < sd->niter; i++) {
+          int final = (i == sd->niter - 1);
+          for (int r = 0; r < G; r++) fns[v](grp->cds[r], grp->sds[r], final);
+          for (int r = 0; r < G; r++) compute_psd_flux(grp->sds[r]);
+        }
+        GPU_OK(cfdp_gpu_sync_group(grp->gpus, G));
+        if (hooks && hooks->barrier) hooks->barrier(); /* src/solver.c:56 */
+        t += cfdp_now();
+        median[v][k] = t;
       }
-      GPU_OK(cfdp_gpu_sync_group(grp->gpus, G));
-      if (hooks && hooks->barrier) hooks->barrier(); /* src/solver.c:56 */
-      t += cfdp_now();
-      median[v][k] = t;
-    }
-    if (talk) {
-      printf(".");
-      fflush(stdout);
+      if (talk) {
+        printf(".");
+        fflush(stdout);
+      }
     }
   }
   if (!talk) return; /* rank 0 prints (src/solver.c:66) */

@@ -122,6 +122,14 @@ int  cfdp_gpu_iteration_group(cfdp_gpu **ranks, int G, int with_exchange, int ov
  * compute_psd_flux enqueue): gradients [+ pack + peer copies], then wait-for-halo + flux */
 int  cfdp_gpu_rank_gradients(cfdp_gpu **ranks, int G, int a, int with_exchange, int overlap);
 int  cfdp_gpu_rank_flux(cfdp_gpu **ranks, int G, int b, int with_flux, int flux_mode);
+/* the same phase 1 in two parts, for G host threads driving G devices ("thread t drives device t"): _launch enqueues rank
+ * a's own kernels, _send its copies into the partners -- called after EVERY rank's _launch (a barrier between the
+ * threads), and every rank's _send precedes any rank's cfdp_gpu_rank_flux (a second barrier)                          */
+int  cfdp_gpu_rank_gradients_launch(cfdp_gpu **ranks, int G, int a, int with_exchange, int overlap);
+int  cfdp_gpu_rank_gradients_send(cfdp_gpu **ranks, int G, int a);
+/* hipDeviceEnablePeerAccess between the devices of the group's ranks (copies and stores then go over xGMI directly);
+ * *npairs (optional) = ordered device pairs enabled                                                                  */
+int  cfdp_gpu_enable_peer_access(cfdp_gpu **ranks, int G, int *npairs);
 int  cfdp_gpu_sync_group(cfdp_gpu **ranks, int G);
 
 /* one rank per process: the two brackets of an iteration around the caller's transport.
