@@ -404,6 +404,11 @@ static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P
   long *hoff = cfdp_calloc((size_t)P->ntiles + 1, sizeof(long)); /* halo offsets, entries */
   long dup_total = 0, inc_total = 0;
   int bad = 0;
+  /* EXPERIMENT (CFDP_EXP_OWNED_NORMALS=1, timing only -- the values are WRONG): the normals of a face cut by two tiles
+   * are stored with ONE of them (the lower tile id); the other tile's planes simply do not hold them (its incidence
+   * words point past its planes).  What the fused pass and its movement floor take then is an UPPER BOUND on what
+   * "cut-face normals owned by one tile, fetched by the other through L2" can gain: the fetch itself is free here. */
+  const int exp_owned = getenv("CFDP_EXP_OWNED_NORMALS") && atoi(getenv("CFDP_EXP_OWNED_NORMALS")) != 0;
   for (int pass = 0; pass < 2; pass++) {
     if (pass == 1) {
       for (int t = 0; t < P->ntiles; t++) {
@@ -430,6 +435,7 @@ static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P
         lmap_reset(&hmap);
         int E = 0, H = 0, I = 0;
         if (pass == 0) {
+          int E_foreign = 0; /* (experiment) cut faces whose normals live with the other tile */
           for (int li = 0; li < np; li++) {
             int p = tl->order[ts + li];
             for (int e = tl->xadj[p]; e < tl->xadj[p + 1]; e++) {
@@ -438,11 +444,16 @@ static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P
               int in_tile = q < nown && tl->tile_of[q] == t;
               I++;
               /* an internal face is listed by both ends and numbered at its p0 end */
-              if (!in_tile || sgn == 0) lmap_index(&fmap, f, &E);
+              if (!in_tile || sgn == 0) {
+                const int before = E;
+                lmap_index(&fmap, f, &E);
+                if (exp_owned && E > before && !in_tile && q < nown && tl->tile_of[q] < t) E_foreign++;
+              }
               if (!in_tile) lmap_index(&hmap, q, &H);
             }
           }
           if (np + H > 65535 || E > 32767) bad = 1;
+          E -= E_foreign; /* (experiment: the planes hold the owned faces only) */
           td->pstart = ts; td->npts = np;
           td->nhalo = H; td->nfaces = E; td->ninc = I;
           const long b_fn = cfdp_blob_fn_bytes(E), b_inc = cfdp_blob_inc_bytes(I), b_off = cfdp_blob_off_bytes(np);
@@ -476,10 +487,20 @@ static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P
               int q = tl->adj_other[e];
               int f = tl->adj_face[e] & 0x7FFFFFFF, sgn = (unsigned)tl->adj_face[e] >> 31;
               int in_tile = q < nown && tl->tile_of[q] == t;
-              if (!in_tile || sgn == 0) lmap_index(&fmap, f, &En);
+              const int foreign = exp_owned && !in_tile && q < nown && tl->tile_of[q] < t;
+              if ((!in_tile || sgn == 0) && !foreign) lmap_index(&fmap, f, &En);
               if (!in_tile) lmap_index(&hmap, q, &Hn);
             }
           }
+          int Eall = En; /* (experiment) the foreign faces are numbered behind the owned ones */
+          if (exp_owned)
+            for (int li = 0; li < np; li++) {
+              int p = tl->order[ts + li];
+              for (int e = tl->xadj[p]; e < tl->xadj[p + 1]; e++) {
+                int q = tl->adj_other[e];
+                if (q < nown && tl->tile_of[q] != t && tl->tile_of[q] < t) lmap_index(&fmap, tl->adj_face[e] & 0x7FFFFFFF, &Eall);
+              }
+            }
           int Ic = 0;
           for (int li = 0; li < np; li++) {
             int p = tl->order[ts + li];
@@ -492,9 +513,11 @@ static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P
               int dummy = 0;
               int lf = lmap_index(&fmap, f, &dummy);
               /* an internal face is listed by both ends; the normal is stored once */
-              fn[lf] = sd->fnormal[f][0];
-              fn[plane + lf] = sd->fnormal[f][1];
-              fn[2 * plane + lf] = sd->fnormal[f][2];
+              if (lf < E) {
+                fn[lf] = sd->fnormal[f][0];
+                fn[plane + lf] = sd->fnormal[f][1];
+                fn[2 * plane + lf] = sd->fnormal[f][2];
+              }
               unsigned nbr;
               if (in_tile) nbr = (unsigned)(P->old2new[q] - ts);
               else {
