@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--per-device", action="store_true",
                     help="one device per rank (LOCAL_RANK) and the nccl backend: the real multi-GPU set-up")
     ap.add_argument("--soak", type=int, default=0, help="extra iterations before the values are checked")
+    ap.add_argument("--mode-may-be-rejected", action="store_true",
+                    help="the memory mode named by CFDP_IPC_MODE may be REJECTED by the set-up validation (a question only "
+                         "hardware answers): then print the evidence and exit with code 77 instead of failing")
     ap.add_argument("--inject-early-read", action="store_true",
                     help="CFDP_IPC_FAULT=skip_wait is set: the comparison of final states must still pass, the scaled-field "
                          "check must see the ghost rows that were read one exchange early")
@@ -122,6 +125,13 @@ def main():
             if rank == 0:  # what the set-up validation saw, and which check a rejected transport failed
                 import json
                 print("VALIDATION " + json.dumps(solver.validation), flush=True)
+            if args.mode_may_be_rejected and solver.transport != args.transport:
+                bad = {k: v for k, v in solver.validation.items() if not v.get("ok")}
+                assert bad and all(v.get("failed") for v in bad.values()), solver.validation  # rejected BY the validation, with a reason
+                print("MODE_REJECTED " + __import__("json").dumps(bad), flush=True)
+                solver.close()
+                dist.destroy_process_group()
+                sys.exit(77)
             assert solver.transport == args.transport, solver.transport  # no silent fallback in the tests
             if args.soak:  # a long run in the scaled field: no flux phase of any step may have read a row of an earlier exchange
                 ev = solver.stale_read_check(batches=(args.soak,))

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _launch(world, extra, extra_env=None):
+def _launch(world, extra, extra_env=None, rejected_ok=False):
     port = _free_port()
     procs = []
     for r in range(world):
@@ -36,8 +36,12 @@ def _launch(world, extra, extra_env=None):
                 q.kill()
             raise
         outs.append(out)
+    if rejected_ok and all(p.returncode == 77 for p in procs):  # every rank alike: the validation rejected the mode
+        ev = [l for l in outs[0].splitlines() if l.startswith("MODE_REJECTED ")]
+        return ev[-1] if ev else "MODE_REJECTED"
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in out, out[-3000:]
+    return None
 
 
 @pytest.mark.parametrize("world,extra", [(2, []), (3, ["--files"]), (2, ["--dims", "12,12,12", "--ndomains", "8"])])
@@ -109,14 +113,29 @@ two_devices = pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs (a 
 
 @pytest.mark.gpu
 @two_devices
-@pytest.mark.parametrize("transport,env", [("ipc", {"CFDP_IPC_MODE": "coarse"}), ("ipc", {"CFDP_IPC_MODE": "split"}),
-                                           ("ipc", {"CFDP_IPC_MODE": "fine"}), ("rccl", {})])
-def test_transports_between_two_devices_against_the_oracle(gpu, transport, env):
-    """the first thing to run on a multi-GPU node (also: tools/multigpu_selftest.py): one rank per DEVICE, the xGMI
-    write + notify exchange with a coarse-grained and with a fine-grained landing block, and the C library's RCCL
-    send/recv group (cfdp_gpu_step_rccl), 1000 iterations each, then owned AND ghost rows and the flux of every rank
-    against the un-partitioned mesh -- stale ghost rows across xGMI cannot pass"""
-    _launch(2, ["--gpu", "--per-device", "--transport", transport, "--soak", "1000"], extra_env=env)
+@pytest.mark.parametrize("transport", ["ipc", "rccl"])
+def test_transports_between_two_devices_against_the_oracle(gpu, transport):
+    """the first thing to run on a multi-GPU node (also: tools/multigpu_selftest.py): one rank per DEVICE.  "ipc": the
+    xGMI write + notify exchange in the first memory mode of its landing block (coarse -> split -> fine) that passes the
+    scaled-field validation -- one MUST; "rccl": the C library's RCCL send/recv group (cfdp_gpu_step_rccl).  1000 steps
+    in the scaled field (no flux phase may read a ghost row of an earlier exchange), then owned AND ghost rows and the
+    flux of every rank against the un-partitioned mesh"""
+    env = {k: v for k, v in os.environ.items() if k not in ("CFDP_IPC_MODE", "CFDP_IPC_FINEGRAINED")}
+    _launch(2, ["--gpu", "--per-device", "--transport", transport, "--soak", "1000"],
+            extra_env={"CFDP_IPC_MODE": ""} if "CFDP_IPC_MODE" in env else None)
+
+
+@pytest.mark.gpu
+@two_devices
+@pytest.mark.parametrize("mode", ["coarse", "split", "fine"])
+def test_each_memory_mode_of_the_landing_block_between_two_devices(gpu, mode):
+    """each memory mode on its own between two devices: either it carries the 1000 scaled steps and the value checks, or
+    the set-up validation REJECTS it with a reason (skip, with the evidence: whether a coarse-grained arena behind
+    another device's stores is coherent inside a kernel is a question only hardware answers) -- never a wrong flux"""
+    ev = _launch(2, ["--gpu", "--per-device", "--transport", "ipc", "--soak", "1000", "--mode-may-be-rejected"],
+                 extra_env={"CFDP_IPC_MODE": mode}, rejected_ok=True)
+    if ev:
+        pytest.skip(f"memory mode {mode} rejected by the scaled-field validation on this node: {ev[:400]}")
 
 
 MPIEXEC = "/opt/conda/bin/mpiexec"
