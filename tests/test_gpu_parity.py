@@ -549,6 +549,63 @@ def test_in_process_ranks_driven_by_one_host_thread_each(gpu, orc, fusion):
         assert np.array_equal(g_a, g_b) and np.array_equal(f_a, f_b) and np.abs(g_a).max() > 0
 
 
+@pytest.mark.parametrize("fusion", [False, True])
+@pytest.mark.parametrize("flux_mode", [0, 1])
+def test_scaled_field_mode_counts_exactly_what_is_wrong(gpu, fusion, flux_mode):
+    """cfdp_gpu_scaled_check_begin / _end on one partition (no exchange needed to test the mechanism): var is scaled by
+    2, 2, 1/4 per step and every step's flux must be reference x 2^e bit for bit -- in both flux modes, fused and not,
+    with a point without faces in the mesh (its flux row is never written and must be skipped); var comes back exactly.
+    Then the negative: var replaced by 1.5 x var behind the mode's back -> every flux value of every later step is
+    reported, with the first offender's iteration, point and values"""
+    pkg = gpu
+    gp = pkg.gen_params(14, 12, 10, ndomains=1)
+    dom0 = pkg.gen_domain(gp, 0)
+    pkg.fill_var(dom0, None, pkg.VAR_HASH)
+    # the same mesh plus one isolated owned point (no faces)
+    nown = dom0.nown
+    vol = np.concatenate([dom0.pvolume, [1.0]])
+    var = np.concatenate([dom0.var, np.full((1, 7), 3.0)])
+    dom = pkg.domain_from_arrays(dom0.fpoint.copy(), dom0.fnormal.copy(), vol, nown + 1, var=var)
+    dom0.free()
+    g = pkg.GpuPartition(dom, tile_points=32)
+    g.set_fusion(fusion)
+    for _ in range(2):
+        g.step_pre(False, False)
+        g.step_post(True, flux_mode)
+    g.sync()
+    var0 = dom.var.copy()
+    g.scaled_check_begin()
+    for _ in range(13):
+        g.step_pre(False, False)
+        g.step_post(True, flux_mode)
+    ev = g.scaled_check_end()
+    assert ev["iterations"] == 13 and ev["mismatches"] == 0 and ev["flux_checks"] >= 13 and ev["first_iteration"] == 0, ev
+    # var is back, bit for bit: one more iteration reproduces the gradients of the start
+    g.pull_fields()
+    g_scaled = dom.grad.copy()
+    g.step_pre(False, False)
+    g.step_post(True, flux_mode)
+    g.pull_fields()
+    g_plain = dom.grad.copy()
+    assert np.array_equal(g_scaled[:nown], g_plain[:nown] * 2.0 ** ((13 - 1) % 3))  # iteration 13 carried exponent 0 -> x1
+    # negative: something changes the field behind the mode's back
+    g.scaled_check_begin()
+    for _ in range(2):
+        g.step_pre(False, False)
+        g.step_post(True, flux_mode)
+    dom.var[:] = var0 * 1.5
+    g._ck(g.lib.cfdp_gpu_set_var(g.h, dom.sd.var))  # (device var now 1.5 x var0, whatever exponent the mode was at)
+    for _ in range(3):
+        g.step_pre(False, False)
+        g.step_post(True, flux_mode)
+    ev = g.scaled_check_end()
+    assert ev["mismatches"] > 0 and ev["first_iteration"] >= 3 and ev["first_point"] >= 0 and ev["seen"] != ev["expected"], ev
+    with pytest.raises(pkg.GpuError):
+        g.scaled_check_end()  # not on
+    g.close()
+    dom.free()
+
+
 # ------------------------------------------------------------------ multigrid V cycle
 @pytest.mark.parametrize("fusion", [False, True])
 def test_vcycle_over_three_levels_matches_single_level_runs(gpu, orc, fusion):
