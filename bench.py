@@ -7,7 +7,7 @@ N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE 
 one rank per GPU), or -- started plainly, without a rank environment -- this process only LAUNCHES: before it
 touches the GPU it starts N fresh rank processes of itself (the reference is started the same way, `mpirun -np N`
 around init_communication, reference src/comm_data.c:257-307, README.txt:92-93), forwards rank 0's JSON line, and
-exits non-zero if any rank fails or the job times out (CFDP_BENCH_TIMEOUT seconds, default 1500).
+exits non-zero if any rank fails or the job times out (CFDP_BENCH_TIMEOUT seconds, default 570).
 
 One "step" = one iteration of the hot path as the reference harness times it
 (reference src/solver.c:48-54): Green-Gauss gradients over all faces (+ halo exchange of the
@@ -121,7 +121,7 @@ def launch_ranks(n: int, argv: list, ndev: int, child_cmd=None, timeout: float =
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    timeout = timeout if timeout is not None else float(os.environ.get("CFDP_BENCH_TIMEOUT", "1500"))
+    timeout = timeout if timeout is not None else float(os.environ.get("CFDP_BENCH_TIMEOUT", "570"))
     cmd = list(child_cmd) if child_cmd else [sys.executable, os.path.abspath(__file__)]
     procs = []
     for r in range(n):

@@ -265,6 +265,7 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_ipc_export_flags.argtypes = [vp, vp]
     lib.cfdp_gpu_ipc_connect_flags.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.cfdp_gpu_ipc_mode.argtypes = [vp]
+    lib.cfdp_gpu_ipc_connect_loopback.argtypes = [vp, C.c_int]
     lib.cfdp_gpu_ipc_enable.argtypes = [vp, C.c_int]
     lib.cfdp_gpu_ipc_disconnect.argtypes = [vp]
     lib.cfdp_gpu_ipc_error.argtypes = [vp]

@@ -191,8 +191,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
                                                   int tid, double *__restrict__ gradA,
                                                   double *__restrict__ gradB,
                                                   double *__restrict__ stage, int dbg = 0,
-                                                  int var_off = -1, const gg_push_args *pa = nullptr,
-                                                  int tile = 0, double scale = 1.0) {
+                                                  int var_off = -1, double scale = 1.0) {
   constexpr int NE = grad_cfg<LPP>::NE;
   constexpr int PPW = 64 / LPP;  // points per wave
   const int li = tid / LPP, sub = tid % LPP;
@@ -231,25 +230,6 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     if (k < ke) grad_batch<1, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
     tmp = 1.0 / var_l[li * 8 + 7];  // 1/pvolume, src/gradients.c:138
     if constexpr (ST == 1) tmp *= scale;
-  }
-  // xGMI write + notify, pushed from the tile itself: every send point of this tile goes straight
-  // from the registers into the partners' landing arenas (whole 168-byte rows, written by the LPP
-  // lanes of the point); the entries of a tile are few (its send points x ~1.2 partners)
-  if (pa && pa->tile_off) {
-    const int e0 = pa->tile_off[tile], e1 = pa->tile_off[tile + 1];  // uniform: scalar loads
-    for (int e = e0; e < e1; e++) {
-      const int w = pa->ent[e];
-      if (active && (w & 0xFFFF) == li && ke0 > ks) {
-        double *row = pa->dst[w >> 16] + (size_t)pa->ent_row[e] * 21 + eq0 * 3;
-#pragma unroll
-        for (int j = 0; j < NE; j++)
-          if (eq0 + j < 7) {
-            row[3 * j + 0] = acc[j][0] * tmp;
-            row[3 * j + 1] = acc[j][1] * tmp;
-            row[3 * j + 2] = acc[j][2] * tmp;
-          }
-      }
-    }
   }
   // SYNC: `stage` aliases a region of the tile image other waves may still be reading
   if constexpr (SYNC) __syncthreads();
@@ -318,6 +298,51 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   }
 }
 
+// xGMI write + notify, pushed by the tile itself: once the tile's rows are stored, ALL its threads copy the rows of its send
+// points into the partners' landing arenas -- value i of the tile's (entries x 21) doubles goes to thread i mod nthr, so a
+// 168-byte row leaves as one contiguous run of stores and every load (entry word, slice pointer, row number, the value
+// itself out of L2) is independent of every other.  (Round 4, tools/loopback_probe.py: the first form walked the entries
+// one after the other, every thread testing every entry, with three dependent loads each and the 4 lanes of the point
+// storing 8 bytes at a 24-byte stride from their registers: 40-80 entries x ~1 us on the critical path of EVERY boundary
+// tile -- a pass with exchange took 99 us where the same pass without took 39.)
+__device__ __forceinline__ void st16_sys(void *p, gg_u32x4 v) {  // global_store_dwordx4 ... sc0 sc1: write-through, system scope
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void push_tile_rows(const gg_push_args &pa, int tile, int tid, int nthr, const cfdp_tile_desc &td,
+                                               const double *gradA, const double *gradB) {
+  if (!pa.tile_off || tile >= pa.nbtiles) return;  // uniform per workgroup
+  // a 168-byte row leaves as ELEVEN stores: ten of 16 bytes and one of 8 (rows start at 0 or 8 mod 16 in the arena; narrow
+  // write-through stores are one fabric write each and cost 2.7x a 16-byte store per byte, MI355X_MICROARCH.md)
+  const int e0 = pa.tile_off[tile], n = (pa.tile_off[tile + 1] - e0) * 11;
+  __syncthreads();  // s_waitcnt vmcnt(0) + barrier: every wave's row stores have been acknowledged by L2
+  for (int i = tid; i < n; i += nthr) {
+    const int e = e0 + i / 11, q = i % 11;
+    const int w = pa.ent[e];
+    const size_t p = (size_t)td.pstart + (size_t)(w & 0xFFFF);
+    double *row = pa.dst[w >> 16] + (size_t)pa.ent_row[e] * 21;
+    const bool odd = ((uintptr_t)row & 15) != 0;        // the row starts 8 mod 16: one double first, then ten pairs
+    const int c0 = odd ? (q == 0 ? 0 : 2 * q - 1) : 2 * q;  // first double of this piece
+    const bool pair = odd ? q != 0 : q != 10;
+    // past this CU's L1: the values were written a moment ago by other waves of this workgroup
+    auto ld = [&](int c) {
+      const double *src = c < 10 ? gradA + p * 10 + c : gradB + p * 11 + (c - 10);
+      return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // write-through at system scope: the bytes leave this device's caches with the store itself, so NO cache write-back
+    // is needed before the flag (push_tile_done) -- a system-scope release fence there would be a buffer_wbl2 of an L2
+    // full of the interior tiles' freshly written rows, once per boundary tile
+    if (pair) {
+      const double v0 = ld(c0), v1 = ld(c0 + 1);
+      gg_u32x4 v;
+      v.x = (unsigned)__double2loint(v0); v.y = (unsigned)__double2hiint(v0);
+      v.z = (unsigned)__double2loint(v1); v.w = (unsigned)__double2hiint(v1);
+      st16_sys(row + c0, v);
+    } else {
+      __hip_atomic_store(row + c0, ld(c0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // The wait for the previous exchange, at the top of a boundary tile of the next pass (see gg_push_args::
 // wait_polls; the protocol is gg_wait_kernel's).  iter0 = hdr[GG_IPC_ITER] = exchanges this rank has announced so
 // far, read once at the top of the pass: it only changes when the LAST boundary tile of a launch has finished, i.e.
@@ -334,58 +359,71 @@ __device__ __forceinline__ void wait_previous_exchange(const gg_push_args &pa, i
   if (mine && !pa.hdr[GG_IPC_ERR]) {
     const int need = iter0;
     bool ok = false;
+    // RELAXED system-scope polls (global_load_dword ... sc0 sc1, past every cache): an acquire per poll is a cache
+    // invalidate per poll (MI355X_MICROARCH.md: polling with acquire loads is 2-3x slower per hop and many pollers cut
+    // the chip's bandwidth).  No invalidate is needed behind the flag either: EVERY load of the rows the flag stands
+    // for is itself a system-scope load (glds16_sys / the generic flux kernel's atomic loads), issued after this poll
+    // has returned (the loop exit depends on its value) and, for the other waves, behind the barrier below.
     for (long k = 0; k < pa.wait_polls && !ok; k++) {
-      ok = __hip_atomic_load(&pa.hdr[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
+      ok = __hip_atomic_load(&pa.hdr[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
       if (!ok) __builtin_amdgcn_s_sleep(32);
     }
     if (!ok) {  // bounded: a lost partner must not hang the device.  Leave what was seen for the post-mortem.
       pa.hdr[GG_IPC_ERR] = 1;
       pa.hdr[GG_IPC_ERR + 1] = tid;
       pa.hdr[GG_IPC_ERR + 2] = need;
-      pa.hdr[GG_IPC_ERR + 3] = __hip_atomic_load(&pa.hdr[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      pa.hdr[GG_IPC_ERR + 3] = __hip_atomic_load(&pa.hdr[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       atomicAdd(&pa.hdr[GG_IPC_ERR + 4], 1);
     }
   }
-  // rows in a coarse-grained arena behind flags another device raised: drop whatever this CU's L1 / this XCD's L2
-  // still hold of them before the first row is requested (the acquire loads above imply it; said once more, by name)
-  if (pa.inv_after_flag && tid < 64) asm volatile("buffer_inv sc0 sc1" ::: "memory");
+  // "split" memory mode: rows in a coarse-grained arena behind flags in fine-grained memory -- drop whatever this CU's
+  // L1 / this XCD's L2 still hold, by name, once per tile (one wave), before the first row is requested
+  if (pa.inv_after_flag && tid < 64) asm volatile("buffer_inv sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
 
-// After the pushes of a boundary tile: count it.  Every thread has made its remote stores visible (system-scope
-// fence) before the tile is counted.
+// After the pushes of a boundary tile: count it.  Every wave has waited for the acknowledgement of its (write-through)
+// remote stores before the tile is counted.
 // Coarse protocol (pa.need == nullptr): ONE counter; the last boundary tile of the launch raises this rank's iteration
 // counter in every partner's flag word (gg_notify_kernel's job, done in place).
 // Per-partner protocol: one counter per partner slot, need[s] = the boundary tiles that hold send rows for partner s;
 // the tile that completes partner s's rows raises s's flag AT ONCE -- the reference's thread that completes partner
 // k's buffer fires k's send (src/threads.c:268-311) -- while other boundary tiles are still computing.
-__device__ __forceinline__ void push_tile_done(const gg_push_args &pa, int tile, int tid, int iter0) {
+__device__ __forceinline__ void push_tile_done(const gg_push_args &pa, int tile, int tid, int iter0, int dbg = 0) {
   if (!pa.tile_off || tile >= pa.nbtiles) return;  // uniform per workgroup
-  __threadfence_system();
-  __syncthreads();
+  // drained-flag publish (MI355X_MICROARCH.md, inter-workgroup visibility, the write-through form): the pushes were
+  // write-through system-scope stores; every storing wave waits until they are acknowledged, the workgroup meets, and only
+  // then ONE lane counts the tile / raises a flag with a relaxed system-scope store.  No fence: nothing sits in a cache.
+  if (!(dbg & 0x1000)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   const int it = iter0 + 1;
   if (pa.need) {  // lane s of wave 0 looks after partner slot s (at most GG_IPC_MAXSLOTS = 48 of them)
-    if (tid < pa.nslots && ((pa.tile_mask[tile] >> tid) & 1ull)) {
-      if (atomicAdd(&pa.done[1 + tid], 1) == pa.need[tid] - 1) {
-        pa.done[1 + tid] = 0;  // nobody counts this slot again before the next launch
-        __threadfence();
-        __hip_atomic_store(pa.rflag[tid], it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!(dbg & 0x800) && tid < pa.nslots && ((pa.tile_mask[tile] >> tid) & 1ull)) {
+      // (the flag store depends on the value the add returns: it is issued after every earlier tile's count -- and so
+      // after their acknowledged pushes -- has been observed)
+      if (atomicAdd(&pa.done[(1 + tid) * GG_DONE_STRIDE], 1) == pa.need[tid] - 1) {
+        pa.done[(1 + tid) * GG_DONE_STRIDE] = 0;  // nobody counts this slot again before the next launch
+        __hip_atomic_store(pa.rflag[tid], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // second level: the slots that are complete.  Every boundary tile counts on at least one slot (it holds send
+        // points), so "every slot complete" = "every boundary tile has counted": the rank's iteration counter moves.
+        // nslots adds on this word per pass instead of one per boundary tile (hundreds of adds on ONE address cost the
+        // pass 1 us; the slot counters sit on cache lines of their own for the same reason: 2 us, tools/loopback_ablate.py)
+        if (atomicAdd(&pa.done[0], 1) == pa.nslots - 1) {
+          pa.done[0] = 0;
+          pa.hdr[GG_IPC_ITER] = it;
+        }
       }
-    }
-    // (same wave, program order: the slot counters above are taken before the tile counts itself finished)
-    if (tid == 0 && atomicAdd(&pa.done[0], 1) == pa.nbtiles - 1) {
-      pa.done[0] = 0;
-      pa.hdr[GG_IPC_ITER] = it;
     }
     return;
   }
   if (tid == 0) {
     const int old = atomicAdd(&pa.done[0], 1);
     if (old == pa.nbtiles - 1) {
-      __threadfence();
       pa.done[0] = 0;  // nobody counts again before the next launch
       for (int s = 0; s < pa.nslots; s++)
-        __hip_atomic_store(pa.rflag[s], it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(pa.rflag[s], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       pa.hdr[GG_IPC_ITER] = it;
     }
   }
@@ -801,7 +839,8 @@ void gg_fused_dma_kernel(
   __syncthreads();
   flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(gbuf), dbg,
-                                   CB * nthr * 16, &pa, t);
+                                   CB * nthr * 16);
+  push_tile_rows(pa, t, tid, nthr, td, gradA_new, gradB_new);
   push_tile_done(pa, t, tid, iter0);
 }
 
@@ -869,7 +908,7 @@ void gg_fused_split_kernel(
   int iter0 = 0;
   if constexpr (PUSH) {
     if (pa.tile_off && t < pa.nbtiles) iter0 = pa.hdr[GG_IPC_ITER];  // uniform: a scalar load
-    wait_previous_exchange(pa, t, tid, iter0);  // before any ghost row is requested
+    if (!(dbg & 0x100)) wait_previous_exchange(pa, t, tid, iter0);  // before any ghost row is requested
   }
   int hv[KV], hg[KG], part[KG], rloc[KG];
   // with a fixed-stride row list the row numbers are requested before the descriptor is even here:
@@ -967,14 +1006,17 @@ void gg_fused_split_kernel(
   __syncthreads();  // vmcnt(0) + barrier
   if constexpr (STAMP) gg_stamp(dbg, t, 4);  // var rows in place
   grad_tile_compute<LPP, NT, true, 0, DIAG == 2>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
-                                                 CB * nthr * 16, PUSH ? &pa : nullptr, t);
+                                                 CB * nthr * 16);
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 2);  // this wave is through its gradient phase (stores issued)
   if constexpr (STAMP) gg_stamp(dbg, t, 5);  // gradient arithmetic done, row stores issued (wave 0)
   if constexpr (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     gg_stamp(dbg, t, 6);  // wave 0's stores acknowledged
   }
-  if constexpr (PUSH) push_tile_done(pa, t, tid, iter0);
+  if constexpr (PUSH) {
+    if (!(dbg & 0x200)) push_tile_rows(pa, t, tid, nthr, td, gradA_new, gradB_new);
+    if (!(dbg & 0x400)) push_tile_done(pa, t, tid, iter0, dbg);
+  }
 }
 
 // ------------------------------------------------------------------ tile-resident iterations
@@ -1076,8 +1118,7 @@ void gg_resident_kernel(
     __syncthreads();
     double scale = 1.0;
     if constexpr (SCALE) scale = __hiloint2double((1023 + k - 1) << 20, 0);  // 2^(k-1)
-    grad_tile_compute<LPP, false, true, 1>(smem, td, tid, gA, gB, reinterpret_cast<double *>(xbuf), 0, CB * nthr * 16,
-                                           nullptr, t, scale);
+    grad_tile_compute<LPP, false, true, 1>(smem, td, tid, gA, gB, reinterpret_cast<double *>(xbuf), 0, CB * nthr * 16, scale);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains ...
     __syncthreads();                                   // ... before ONE lane signals for all of them
     if (tid == 0) __hip_atomic_store(ra.flags + t, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

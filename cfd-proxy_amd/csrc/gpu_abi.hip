@@ -1848,6 +1848,23 @@ int cfdp_gpu_ipc_connect_flags(cfdp_gpu *g, int slot, const void *partner_flags_
   return 0;
 }
 
+// MEASUREMENT ONLY (tools/loopback_probe.py): partner slot `slot` is this rank ITSELF -- its rows land in its own arenas
+// at the slot's receive offset, its flag is its own flag word.  The ghost rows then hold this rank's own send rows (wrong
+// values, right traffic): what one iteration of the write + notify protocol costs when the partner is never late.
+int cfdp_gpu_ipc_connect_loopback(cfdp_gpu *g, int slot) {
+  NEED_UPLOAD(g);
+  auto &I = g->ipc;
+  if (!I.block) return fail("cfdp_gpu_ipc_export() first");
+  if (slot < 0 || slot >= (int)g->partner.size()) return fail("bad partner slot");
+  if (g->send_off[slot + 1] - g->send_off[slot] > g->recv_off[slot + 1] - g->recv_off[slot])
+    return fail("loopback needs a receive slice at least as long as the send slice (slot %d)", slot);
+  const size_t base = GG_IPC_HDR_BYTES + (size_t)g->recv_off[slot] * 21 * sizeof(double);
+  I.dst[0][slot] = reinterpret_cast<double *>(I.block + base);
+  I.dst[1][slot] = reinterpret_cast<double *>(I.block + base + I.land_bytes);
+  I.rflag[slot] = g->ipc_hdr() + slot;
+  return 0;
+}
+
 // what the exchange set up by cfdp_gpu_ipc_ready does: bit 0 the fused pass pushes and notifies itself, bit 1 its
 // boundary tiles wait themselves, bit 2 per-partner notification and wait masks, bits 4-5 the memory mode
 // (0 coarse, 1 fine, 2 split)
@@ -1940,8 +1957,8 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       if (I.fault_skip_wait) fprintf(stderr, "[cfdp] FAULT INJECTION: boundary tiles do not wait for the previous exchange (CFDP_IPC_FAULT)\n");
     }
   }
-  HIP_TRY(hipMalloc(&I.d_done, sizeof(int) * (GG_IPC_MAXSLOTS + 1)));
-  HIP_TRY(hipMemset(I.d_done, 0, sizeof(int) * (GG_IPC_MAXSLOTS + 1)));
+  HIP_TRY(hipMalloc(&I.d_done, sizeof(int) * (GG_IPC_MAXSLOTS + 1) * GG_DONE_STRIDE));
+  HIP_TRY(hipMemset(I.d_done, 0, sizeof(int) * (GG_IPC_MAXSLOTS + 1) * GG_DONE_STRIDE));
   if (flush_flux(g)) return 1;
   HIP_TRY(hipDeviceSynchronize());
   // the ghost rows move into the landing arenas

@@ -207,6 +207,9 @@ int  cfdp_gpu_ipc_connect(cfdp_gpu *g, int slot, const void *partner_handle64, s
 int  cfdp_gpu_ipc_export_flags(cfdp_gpu *g, void *handle64);
 int  cfdp_gpu_ipc_connect_flags(cfdp_gpu *g, int slot, const void *partner_flags_handle64, size_t flag_off);
 int  cfdp_gpu_ipc_mode(const cfdp_gpu *g);
+/* measurement only: partner slot `slot` is this rank itself (its own arenas, its own flag word): the cost of the protocol
+ * with a partner that is never late; the ghost rows then hold this rank's own send rows                              */
+int  cfdp_gpu_ipc_connect_loopback(cfdp_gpu *g, int slot);
 int  cfdp_gpu_ipc_ready(cfdp_gpu *g);
 int  cfdp_gpu_ipc_enable(cfdp_gpu *g, int on);   /* keep the mappings, use / do not use them */
 int  cfdp_gpu_ipc_disconnect(cfdp_gpu *g);
