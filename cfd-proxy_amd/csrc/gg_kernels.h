@@ -38,6 +38,11 @@ struct gg_push_args {
   int *done;
   const int *need;
   const unsigned long long *tile_mask;
+  // register push: pt_first[t * pt_stride + li] = {partner slot or -1, row in that partner's slice} of point li's FIRST
+  // destination; the entries [tile_xoff[t], tile_off[t + 1]) are the further destinations of points sent to several partners
+  const int2 *pt_first;
+  const int *tile_xoff;
+  int pt_stride;
   int nbtiles, nslots;
   int inv_after_flag;  // explicit buffer_inv sc0 sc1 once a tile has seen its partners' flags
   // > 0: the boundary tiles (the only ones that read ghost rows) first wait -- bounded -- until every partner's

@@ -179,6 +179,47 @@ __device__ __forceinline__ void st16_sc1(void *p, gg_u32x4 v) {
 __device__ __forceinline__ void st8_sc1(double *p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dwordx2 ... sc1
 }
+__device__ __forceinline__ void st16_sys(void *p, gg_u32x4 v) {  // global_store_dwordx4 ... sc0 sc1: write-through, system scope
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+// xGMI write + notify, a point's first destination, pushed from the REGISTERS of its lanes the moment the row is finished:
+// the lane holds the doubles [eq0 * 3, eq0 * 3 + n) of the 168-byte row (n = 6, or 3 for the lane group with the last
+// equation) and `row` is where the row lands in the partner's arena -- known long before (the table entry is requested at
+// the top of the kernel, the slice pointer behind the staging wait), so nothing but the stores themselves sits on the
+// boundary tile's critical path.  Write-through system-scope stores, 16 bytes wherever the arena's alignment allows
+// (rows start at 0 or 8 mod 16).  The caller drains them (s_waitcnt vmcnt(0), push_tile_done) before it counts the tile.
+template <int NE>
+__device__ __forceinline__ void push_from_registers(double *row, int eq0, const double (&acc)[NE][3], double tmp) {
+  double *p = row + eq0 * 3;
+  auto st8 = [](double *q, double x) { __hip_atomic_store(q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+  auto st16 = [](double *q, double a, double b) {
+    gg_u32x4 u;
+    u.x = (unsigned)__double2loint(a); u.y = (unsigned)__double2hiint(a);
+    u.z = (unsigned)__double2loint(b); u.w = (unsigned)__double2hiint(b);
+    st16_sys(q, u);
+  };
+  if constexpr (NE == 2) {  // 4 lanes per point (every kernel that pushes): 6 doubles, the last lane group 3
+    const double v0 = acc[0][0] * tmp, v1 = acc[0][1] * tmp, v2 = acc[0][2] * tmp;
+    const double v3 = acc[1][0] * tmp, v4 = acc[1][1] * tmp, v5 = acc[1][2] * tmp;
+    const bool six = eq0 + 2 <= 7;
+    if (((uintptr_t)p & 15) == 0) {
+      st16(p, v0, v1);
+      if (six) { st16(p + 2, v2, v3); st16(p + 4, v4, v5); }
+      else st8(p + 2, v2);
+    } else {
+      st8(p, v0);
+      st16(p + 1, v1, v2);
+      if (six) { st16(p + 3, v3, v4); st8(p + 5, v5); }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NE; j++)
+      if (eq0 + j < 7) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) st8(p + 3 * j + c, acc[j][c] * tmp);
+      }
+  }
+}
 
 // ST: how the finished rows are stored.  0: 8 bytes per lane, contiguous runs (NT: non-temporal) -- the form of the
 // one-launch-per-pass kernels.  1: part A (the rows neighbouring tiles re-read) write-through, 16 bytes per lane;
@@ -191,7 +232,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
                                                   int tid, double *__restrict__ gradA,
                                                   double *__restrict__ gradB,
                                                   double *__restrict__ stage, int dbg = 0,
-                                                  int var_off = -1, double scale = 1.0) {
+                                                  int var_off = -1, double scale = 1.0, double *push_row = nullptr) {
   constexpr int NE = grad_cfg<LPP>::NE;
   constexpr int PPW = 64 / LPP;  // points per wave
   const int li = tid / LPP, sub = tid % LPP;
@@ -231,6 +272,9 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     tmp = 1.0 / var_l[li * 8 + 7];  // 1/pvolume, src/gradients.c:138
     if constexpr (ST == 1) tmp *= scale;
   }
+  // this point's row goes to a partner: out of the registers, now (before the tile's own stores: the acknowledgement of a
+  // remote store takes longest).  A point without faces is pushed by nobody (such partitions keep the push kernel)
+  if (push_row && active && ke0 > ks) push_from_registers<NE>(push_row, eq0, acc, tmp);
   // SYNC: `stage` aliases a region of the tile image other waves may still be reading
   if constexpr (SYNC) __syncthreads();
   // ---- write the finished rows.  A lane holds NE*3 doubles of a 168-byte row; storing them
@@ -305,15 +349,15 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
 // one after the other, every thread testing every entry, with three dependent loads each and the 4 lanes of the point
 // storing 8 bytes at a 24-byte stride from their registers: 40-80 entries x ~1 us on the critical path of EVERY boundary
 // tile -- a pass with exchange took 99 us where the same pass without took 39.)
-__device__ __forceinline__ void st16_sys(void *p, gg_u32x4 v) {  // global_store_dwordx4 ... sc0 sc1: write-through, system scope
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-}
 __device__ __forceinline__ void push_tile_rows(const gg_push_args &pa, int tile, int tid, int nthr, const cfdp_tile_desc &td,
                                                const double *gradA, const double *gradB) {
   if (!pa.tile_off || tile >= pa.nbtiles) return;  // uniform per workgroup
   // a 168-byte row leaves as ELEVEN stores: ten of 16 bytes and one of 8 (rows start at 0 or 8 mod 16 in the arena; narrow
   // write-through stores are one fabric write each and cost 2.7x a 16-byte store per byte, MI355X_MICROARCH.md)
-  const int e0 = pa.tile_off[tile], n = (pa.tile_off[tile + 1] - e0) * 11;
+  // (only the FURTHER destinations of points sent to several partners take this road -- a point's first destination is
+  // pushed from the registers of its lanes, push_from_registers; most boundary tiles have none)
+  const int e0 = pa.tile_xoff[tile], n = (pa.tile_off[tile + 1] - e0) * 11;
+  if (n <= 0) return;  // uniform per workgroup
   __syncthreads();  // s_waitcnt vmcnt(0) + barrier: every wave's row stores have been acknowledged by L2
   for (int i = tid; i < n; i += nthr) {
     const int e = e0 + i / 11, q = i % 11;
@@ -473,6 +517,11 @@ __global__ __launch_bounds__(1024) void gg_gradient_kernel(
 __device__ __forceinline__ int ld_i32_nowait(const int *p) {
   int v;  // the compiler does not track this load: the caller waits for it (counted vmcnt)
   asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ unsigned long long ld_u64_nowait(const void *p) {
+  unsigned long long v;  // not tracked by the compiler either: issued ahead of the counted wait, used behind it
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
 __device__ __forceinline__ void glds16(const uint4 *src, unsigned char *lds_wave_base);
@@ -780,6 +829,8 @@ void gg_fused_dma_kernel(
   const int lane = tid & 63, w0 = tid & ~63;
   const int iter0 = pa.tile_off && t < pa.nbtiles ? pa.hdr[GG_IPC_ITER] : 0;  // uniform: a scalar load
   wait_previous_exchange(pa, t, tid, iter0);  // before any ghost row is requested
+  unsigned long long pfirst = ~0ull;  // see gg_fused_split_kernel
+  if (pa.tile_off && t < pa.nbtiles) pfirst = ld_u64_nowait(pa.pt_first + (size_t)t * pa.pt_stride + (tid >> 2));
   const int *hid = halo_idx + td.halo_off;
   const int hmax = td.nhalo > 0 ? td.nhalo - 1 : 0;
   // (1) halo row numbers of this thread's var pieces (4 per row) and gradient pieces (5 per row)
@@ -837,9 +888,15 @@ void gg_fused_dma_kernel(
                  gbuf + (size_t)(w0 + k * nthr) * 16);
   }
   __syncthreads();
+  double *push_row = nullptr;
+  {
+    asm volatile("" : "+v"(pfirst));
+    const int pslot = (int)(unsigned)pfirst, prow = (int)(pfirst >> 32);
+    if (pslot >= 0) push_row = pa.dst[pslot] + (size_t)prow * 21;
+  }
   flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(gbuf), dbg,
-                                   CB * nthr * 16);
+                                   CB * nthr * 16, 1.0, push_row);
   push_tile_rows(pa, t, tid, nthr, td, gradA_new, gradB_new);
   push_tile_done(pa, t, tid, iter0);
 }
@@ -906,9 +963,11 @@ void gg_fused_split_kernel(
     gg_stamp_buf[(size_t)t * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                                      (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
   int iter0 = 0;
+  unsigned long long pfirst = ~0ull;  // {partner slot or -1, row}: where this lane's point goes first (boundary tiles)
   if constexpr (PUSH) {
     if (pa.tile_off && t < pa.nbtiles) iter0 = pa.hdr[GG_IPC_ITER];  // uniform: a scalar load
     if (!(dbg & 0x100)) wait_previous_exchange(pa, t, tid, iter0);  // before any ghost row is requested
+    if (pa.tile_off && t < pa.nbtiles) pfirst = ld_u64_nowait(pa.pt_first + (size_t)t * pa.pt_stride + (tid >> 2));
   }
   int hv[KV], hg[KG], part[KG], rloc[KG];
   // with a fixed-stride row list the row numbers are requested before the descriptor is even here:
@@ -964,6 +1023,12 @@ void gg_fused_split_kernel(
   for (int k = 0; k < KV; k++) asm volatile("" : "+v"(hv[k]));
 #pragma unroll
   for (int k = 0; k < KG; k++) asm volatile("" : "+v"(hg[k]));
+  double *push_row = nullptr;  // this lane's point, in its first partner's arena (the slice pointer travels with the rows)
+  if constexpr (PUSH) {
+    asm volatile("" : "+v"(pfirst));
+    const int pslot = (int)(unsigned)pfirst, prow = (int)(pfirst >> 32);
+    if (pslot >= 0 && !(dbg & 0x200)) push_row = pa.dst[pslot] + (size_t)prow * 21;
+  }
   unsigned char *xbuf = smem + (size_t)CB * nthr * 16;  // the shared row region
   const unsigned char *abytes = reinterpret_cast<const unsigned char *>(gradA_old);
   const unsigned char *hbytes = reinterpret_cast<const unsigned char *>(ghost_old);
@@ -1006,7 +1071,7 @@ void gg_fused_split_kernel(
   __syncthreads();  // vmcnt(0) + barrier
   if constexpr (STAMP) gg_stamp(dbg, t, 4);  // var rows in place
   grad_tile_compute<LPP, NT, true, 0, DIAG == 2>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
-                                                 CB * nthr * 16);
+                                                 CB * nthr * 16, 1.0, push_row);
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 2);  // this wave is through its gradient phase (stores issued)
   if constexpr (STAMP) gg_stamp(dbg, t, 5);  // gradient arithmetic done, row stores issued (wave 0)
   if constexpr (STAMP) {

@@ -108,6 +108,12 @@ struct cfdp_gpu {
     int **d_rflag = nullptr;
     int *d_slot_of_row = nullptr, *d_send_off = nullptr;
     int *d_tile_off = nullptr, *d_ent = nullptr, *d_ent_row = nullptr;  // send rows per boundary tile
+    // ... point-major: the FIRST destination of every point of every boundary tile, {slot or -1, row}, pt_stride entries
+    // per tile (pushed from the lanes' registers); tile_xoff[t] = where, in tile t's entries, the further destinations
+    // of points sent to several partners start (pushed by the parallel re-read form)
+    int2 *d_pt_first = nullptr;
+    int *d_tile_xoff = nullptr;
+    int pt_stride = 64;
     bool inkernel = false;   // the fused pass pushes and notifies by itself
     // the latest exchange has been started but nothing on the main stream waits for its arrival yet: the
     // boundary tiles of the next pushing pass wait themselves (gg_push_args::wait_polls); anything else that
@@ -1652,6 +1658,8 @@ void ipc_release(cfdp_gpu *g) {
   (void)hipFree(I.d_rflag); I.d_rflag = nullptr; I.rflag.clear();
   (void)hipFree(I.d_slot_of_row); (void)hipFree(I.d_send_off);
   (void)hipFree(I.d_tile_off); (void)hipFree(I.d_ent); (void)hipFree(I.d_ent_row);
+  (void)hipFree(I.d_pt_first); (void)hipFree(I.d_tile_xoff);
+  I.d_pt_first = nullptr; I.d_tile_xoff = nullptr;
   I.d_slot_of_row = I.d_send_off = I.d_tile_off = I.d_ent = I.d_ent_row = nullptr;
   I.inkernel = false;
   (void)hipFree(I.d_done); (void)hipFree(I.d_need); (void)hipFree(I.d_tile_mask);
@@ -1688,6 +1696,7 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
       pa.tile_off = I.d_tile_off; pa.ent = I.d_ent; pa.ent_row = I.d_ent_row; pa.dst = I.d_dst[par];
       pa.hdr = g->ipc_hdr(); pa.rflag = I.d_rflag; pa.done = I.d_done;
       pa.need = I.per_partner ? I.d_need : nullptr; pa.tile_mask = I.per_partner ? I.d_tile_mask : nullptr;
+      pa.pt_first = I.d_pt_first; pa.pt_stride = I.pt_stride; pa.tile_xoff = I.d_tile_xoff;
       pa.nbtiles = g->nbtiles; pa.nslots = nslots;
       pa.inv_after_flag = I.mode == 2 ? 1 : 0;
       pa.wait_polls = I.wait_pending && I.wait_inkernel && !I.fault_skip_wait ? (long)ipc_max_polls() : 0;
@@ -1914,12 +1923,31 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
     I.inkernel = false;
     if (ok && nsend) {
       for (int t = 0; t < g->ntiles; t++) tile_off[t + 1] += tile_off[t];
-      std::vector<int> fill(tile_off.begin(), tile_off.end() - 1);
+      // a point's FIRST destination (message order) goes into the point-major table and to the front of its tile's
+      // entries; further destinations (points on an edge or corner between partners) behind them, from tile_xoff on
+      int tpmax = 1;
+      for (int t = 0; t < g->nbtiles; t++) tpmax = g->h_tiles[t].npts > tpmax ? g->h_tiles[t].npts : tpmax;
+      I.pt_stride = (tpmax + 63) & ~63;
+      std::vector<int2> pt_first((size_t)(g->nbtiles ? g->nbtiles : 1) * I.pt_stride, make_int2(-1, 0));
+      std::vector<int> tile_xoff((size_t)g->ntiles + 1, 0), nfirst((size_t)g->ntiles, 0);
+      std::vector<char> is_first(nsend, 0);
       for (size_t j = 0; j < nsend; j++) {
-        const int t = tile_of[j], s = slot_of_row[j], at = fill[t]++;
+        const int t = tile_of[j], li = g->send_idx_host[j] - g->h_tiles[t].pstart;
+        int2 &f = pt_first[(size_t)t * I.pt_stride + li];
+        if (f.x < 0) { f = make_int2(slot_of_row[j], (int)j - g->send_off[slot_of_row[j]]); is_first[j] = 1; nfirst[t]++; }
+      }
+      std::vector<int> fill(tile_off.begin(), tile_off.end() - 1), fillx((size_t)g->ntiles, 0);
+      for (int t = 0; t < g->ntiles; t++) { tile_xoff[t] = tile_off[t] + nfirst[t]; fillx[t] = tile_xoff[t]; }
+      tile_xoff[g->ntiles] = tile_off[g->ntiles];
+      for (size_t j = 0; j < nsend; j++) {
+        const int t = tile_of[j], s = slot_of_row[j], at = is_first[j] ? fill[t]++ : fillx[t]++;
         ent[at] = (g->send_idx_host[j] - g->h_tiles[t].pstart) | (s << 16);
         ent_row[at] = (int)j - g->send_off[s];
       }
+      HIP_TRY(hipMalloc(&I.d_pt_first, sizeof(int2) * pt_first.size()));
+      HIP_TRY(hipMemcpy(I.d_pt_first, pt_first.data(), sizeof(int2) * pt_first.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&I.d_tile_xoff, sizeof(int) * tile_xoff.size()));
+      HIP_TRY(hipMemcpy(I.d_tile_xoff, tile_xoff.data(), sizeof(int) * tile_xoff.size(), hipMemcpyHostToDevice));
       HIP_TRY(hipMalloc(&I.d_tile_off, sizeof(int) * tile_off.size()));
       HIP_TRY(hipMemcpy(I.d_tile_off, tile_off.data(), sizeof(int) * tile_off.size(), hipMemcpyHostToDevice));
       HIP_TRY(hipMalloc(&I.d_ent, sizeof(int) * ent.size()));
