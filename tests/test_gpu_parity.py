@@ -606,6 +606,51 @@ def test_scaled_field_mode_counts_exactly_what_is_wrong(gpu, fusion, flux_mode):
     dom.free()
 
 
+def test_exchange_protocol_overhead_in_loopback(gpu):
+    """what the write + notify protocol itself costs per iteration when no partner is ever late: rank 0 of the 4-rank
+    decomposition of the level-2 mesh (dualgrid.48: 65 k points, 3 partners, one round of tiles -- the latency-bound
+    strong-scaling regime), every partner slot looped back to the rank's own arenas and flag words
+    (cfdp_gpu_ipc_connect_loopback: wrong ghost values, right traffic, right protocol).  A regression guard: round 4 found
+    this ratio at 0.52 (a serial push loop, a system-scope fence per boundary tile, completion counters of hundreds of
+    tiles on one cache line) and brought it to 0.97; tools/loopback_probe.py prints it for every bench config"""
+    import time
+    pkg = gpu
+    from cfd_proxy_amd import multigpu as mg
+    cfg = mg.bench_config("dualgrid.48", 4)
+    gp = pkg.gen_params(*cfg["dims"], ndomains=cfg["ndomains"])
+    parts = [mg.build_rank_partition(gp, cfg["ndomains"], 4, r, via_files=False)[0] for r in range(4)]
+    reqs = [{int(k): (v[0], v[1]) for k, v in pkg.merge_requests(p).items()} for p in parts]
+    mg.exchange_requests(parts[0], 0, 4, None, all_requests=reqs)
+    g = pkg.GpuPartition(parts[0])
+    g.set_fusion(True)
+    g.ipc_export()
+    for s in range(len(g.partners())):
+        g._ck(g.lib.cfdp_gpu_ipc_connect_loopback(g.h, s))
+    g.ipc_ready()
+    mode = g.ipc_mode()
+    assert mode["push"] == "in the fused pass" and mode["wait"] == "in the fused pass" and mode["notify"] == "per partner", mode
+
+    def timed(**kw):
+        g.run_steps_ipc(200, **kw)
+        g.sync()
+        best = 1e9
+        for _ in range(3):
+            t = time.perf_counter()
+            g.run_steps_ipc(1000, **kw)
+            g.sync()
+            best = min(best, (time.perf_counter() - t) / 1000)
+        return best * 1e6
+    free = timed(with_exchange=False, overlap=True)
+    exch = timed(with_exchange=True, overlap=True)
+    assert g.ipc_error() == 0
+    print(f"loopback, dualgrid.48 rank 0 of 4: {free:.2f} us without, {exch:.2f} us with the exchange")
+    assert exch <= 1.25 * free, (free, exch)
+    g.ipc_disconnect()
+    g.close()
+    for p in parts:
+        p.free()
+
+
 # ------------------------------------------------------------------ multigrid V cycle
 @pytest.mark.parametrize("fusion", [False, True])
 def test_vcycle_over_three_levels_matches_single_level_runs(gpu, orc, fusion):
