@@ -64,7 +64,7 @@ def test_multirank_xgmi_write_notify_between_processes_on_one_gpu(gpu):
     # (ranks that share a device use the wait kernel by default -- waiting boundary tiles of several ranks can fill the
     # device; these meshes are small, and the wait INSIDE the fused pass is the path a rank with its own GPU takes)
     inkernel = {"CFDP_IPC_WAIT_INKERNEL": "1"}
-    _launch(2, ["--gpu", "--transport", "ipc"], extra_env=inkernel)
+    _launch(2, ["--gpu", "--transport", "ipc", "--soak", "600"], extra_env=inkernel)  # + 600 steps in the scaled field
     _launch(3, ["--gpu", "--transport", "ipc", "--files"], extra_env=inkernel)
     _launch(4, ["--gpu", "--transport", "ipc", "--dims", "16,16,12", "--ndomains", "8"], extra_env=inkernel)
 
