@@ -1925,8 +1925,10 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       for (int t = 0; t < g->ntiles; t++) tile_off[t + 1] += tile_off[t];
       // a point's FIRST destination (message order) goes into the point-major table and to the front of its tile's
       // entries; further destinations (points on an edge or corner between partners) behind them, from tile_xoff on
+      // (stride = the lanes-per-point groups of the LARGEST workgroup a launch over all tiles can have: every thread of
+      // a boundary tile's workgroup reads its group's entry, also the groups beyond the tile's points)
       int tpmax = 1;
-      for (int t = 0; t < g->nbtiles; t++) tpmax = g->h_tiles[t].npts > tpmax ? g->h_tiles[t].npts : tpmax;
+      for (int t = 0; t < g->ntiles; t++) tpmax = g->h_tiles[t].npts > tpmax ? g->h_tiles[t].npts : tpmax;
       I.pt_stride = (tpmax + 63) & ~63;
       std::vector<int2> pt_first((size_t)(g->nbtiles ? g->nbtiles : 1) * I.pt_stride, make_int2(-1, 0));
       std::vector<int> tile_xoff((size_t)g->ntiles + 1, 0), nfirst((size_t)g->ntiles, 0);
