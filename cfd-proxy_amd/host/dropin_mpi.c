@@ -226,9 +226,9 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
   }
   /* the memory modes of the landing block (cfdproxy_hip.h, CFDP_IPC_MODE), in the order they are tried; a mode the
    * environment names is the only one tried */
-  static const char *const modes[3] = {"coarse", "split", "fine"};
-  static const char *const labels[3] = {"coarse-grained landing block", "fine-grained flags, coarse-grained arenas, explicit invalidate",
-                                        "fine-grained landing block"};
+  static const char *const modes[3] = {"fine", "coarse", "split"}; /* fine first: coherent by definition, and no slower in loopback */
+  static const char *const labels[3] = {"fine-grained landing block", "coarse-grained landing block",
+                                        "fine-grained flags, coarse-grained arenas, explicit invalidate"};
   const char *preset = getenv("CFDP_IPC_MODE");
   const char *fg0 = getenv("CFDP_IPC_FINEGRAINED");
   if (!(preset && *preset) && fg0 && atoi(fg0) != 0) preset = "fine";

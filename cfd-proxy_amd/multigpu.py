@@ -132,10 +132,13 @@ _IPC_MODE_PRESET = os.environ.get("CFDP_IPC_MODE", "") or ("fine" if os.environ.
 
 def ipc_mode_attempts() -> List[str]:
     """memory modes of the xGMI landing block in the order the set-up tries them (cfdproxy_hip.h, CFDP_IPC_MODE): the
-    one the environment named (a comma-separated list is an order), else coarse -> split -> fine"""
+    one the environment named (a comma-separated list is an order), else fine -> coarse -> split.  Fine-grained first: it
+    is coherent between devices by definition, and in loopback it costs nothing (an iteration with exchange 41.8 us
+    against 41.3 with a coarse-grained block and 43.4 with the split form, dualgrid.384 rank; DESIGN appendix C.4) --
+    every ghost-row load bypasses the caches in every mode anyway"""
     if _IPC_MODE_PRESET:
-        return [x for x in _IPC_MODE_PRESET.split(",") if x in IPC_MODE_LABEL] or ["coarse"]
-    return ["coarse", "split", "fine"]
+        return [x for x in _IPC_MODE_PRESET.split(",") if x in IPC_MODE_LABEL] or ["fine"]
+    return ["fine", "coarse", "split"]
 
 
 def exchange_requests(part: Domain, rank: int, world: int, dist=None, all_requests=None) -> None:

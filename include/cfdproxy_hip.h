@@ -187,10 +187,11 @@ int  cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int over
  *                         rows land (both parities) and my arrival counter lives
  *   cfdp_gpu_ipc_ready    switch the context over (the ghost block is then the landing arenas)
  *   cfdp_gpu_ipc_error    1 if a wait for a partner gave up (bounded polling)
- * Memory of the block, CFDP_IPC_MODE (the hosts try them in this order and keep the first that passes the scaled-field
- * validation): "coarse" (default: hipMalloc; system-scope loads and fences in the kernels), "split" (the flag words in
- * a small fine-grained block of their own, the arenas coarse-grained, an explicit cache invalidate once a tile has
- * seen its partners' flags), "fine" (everything fine-grained; CFDP_IPC_FINEGRAINED=1 is the older spelling).
+ * Memory of the block, CFDP_IPC_MODE (the hosts try fine, coarse, split in this order and keep the first that passes the
+ * scaled-field validation; without the variable a context allocates coarse): "fine" (everything fine-grained: coherent
+ * between devices by definition; CFDP_IPC_FINEGRAINED=1 is the older spelling), "coarse" (hipMalloc; system-scope loads
+ * and write-through stores in the kernels), "split" (the flag words in a small fine-grained block of their own, the
+ * arenas coarse-grained, an explicit cache invalidate once a tile has seen its partners' flags).
  *   cfdp_gpu_ipc_export_flags   the handle of the block that holds this rank's flag words (the main block's handle
  *                               again unless the mode is "split")
  *   cfdp_gpu_ipc_connect_flags  after cfdp_gpu_ipc_connect, before _ready: my arrival counter at partner `slot` lives

@@ -78,12 +78,12 @@ def main():
             real, calls = mg.RankSolver.validate_exchange, []
 
             def flaky(self):
-                calls.append(os.environ.get("CFDP_IPC_MODE", "coarse"))
+                calls.append(os.environ.get("CFDP_IPC_MODE", "?"))
                 return real(self) and len(calls) > 1
             mg.RankSolver.validate_exchange = flaky
             solver = mg.RankSolver(part, rank, world, 0, dist, transport="ipc", tile_points=32)
-            assert solver.transport == "ipc" and calls == ["coarse", "split"], (solver.transport, calls)
-            assert solver.gpu.ipc_mode()["memory"].startswith("split"), solver.gpu.ipc_mode()
+            assert solver.transport == "ipc" and calls == ["fine", "coarse"], (solver.transport, calls)
+            assert solver.gpu.ipc_mode()["memory"].startswith("coarse"), solver.gpu.ipc_mode()
             solver.run_steps(60, with_exchange=True, overlap=True)
             g = solver.grad_host()
             assert np.abs(g - truth[gid]).max() / np.abs(truth).max() <= 1e-12

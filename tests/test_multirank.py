@@ -96,7 +96,7 @@ def test_scaled_field_check_sees_a_ghost_row_read_one_exchange_early(gpu, world,
 @pytest.mark.gpu
 def test_write_notify_setup_is_retried_with_a_fine_grained_block(gpu):
     """a failed exchange validation tears the IPC mappings down on every rank and the set-up is retried with the
-    next memory mode of the landing block (coarse -> split -> fine, CFDP_IPC_MODE) before any other transport is tried"""
+    next memory mode of the landing block (fine -> coarse -> split, CFDP_IPC_MODE) before any other transport is tried"""
     _launch(2, ["--gpu", "--fail-first-validation"])
 
 
@@ -116,7 +116,7 @@ two_devices = pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs (a 
 @pytest.mark.parametrize("transport", ["ipc", "rccl"])
 def test_transports_between_two_devices_against_the_oracle(gpu, transport):
     """the first thing to run on a multi-GPU node (also: tools/multigpu_selftest.py): one rank per DEVICE.  "ipc": the
-    xGMI write + notify exchange in the first memory mode of its landing block (coarse -> split -> fine) that passes the
+    xGMI write + notify exchange in the first memory mode of its landing block (fine -> coarse -> split) that passes the
     scaled-field validation -- one MUST; "rccl": the C library's RCCL send/recv group (cfdp_gpu_step_rccl).  1000 steps
     in the scaled field (no flux phase may read a ghost row of an earlier exchange), then owned AND ghost rows and the
     flux of every rank against the un-partitioned mesh"""
