@@ -1,0 +1,749 @@
+// gpu_exchange.hip -- the exchanges between ranks behind the C ABI of include/cfdproxy_hip.h: grouped RCCL send/recv
+// issued by the library itself, the xGMI write + notify exchange through HIP IPC (set-up, step schedules, hipGraph
+// replays), and the scaled-field validation of either.  Context and launch helpers: gpu_ctx.h / gpu_abi.hip.
+#include "gpu_ctx.h"
+
+#include <dlfcn.h>
+
+extern "C" {
+
+// ----------------------------------------------------- scaled-field validation of the exchange
+// See gg_validate_kernel.  begin: the flux the context holds NOW (from an iteration whose exchange the caller knows to be
+// complete: device syncs and a barrier between the ranks, then one step without exchange) becomes the reference; from
+// then on every step entry point (cfdp_gpu_step_post, _step_ipc*, _run_steps_*, _rank_flux; the drop-in layer's
+// compute_psd_flux) ends with the validation kernel: compare the flux the step produced with reference * 2^e, then
+// var *= 2, 2, 1/4, ...  Every step must exchange and compute the flux while the mode is on.  end: the deferred flux of
+// the last iteration is compared too, var is restored exactly, the evidence is returned.
+extern "C++" void cfdp_detail::drop_ipc_graphs(cfdp_gpu *g) {
+  auto &I = g->ipc;
+  if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
+  if (I.graph_rem) { (void)hipGraphExecDestroy(I.graph_rem); I.graph_rem = nullptr; }
+  I.graph_n = I.graph_rem_n = 0;
+}
+
+int cfdp_gpu_scaled_check_begin(cfdp_gpu *g) {
+  NEED_UPLOAD(g);
+  if (g->sc.on) return fail("the scaled-field validation is already on");
+  if (flush_flux(g)) return 1;
+  HIP_TRY(hipDeviceSynchronize());
+  const size_t nf = (size_t)g->nown * 3;
+  if (!g->sc.d_state) HIP_TRY(hipMalloc(&g->sc.d_state, GG_V_WORDS * sizeof(int)));
+  if (!g->sc.d_fref) HIP_TRY(hipMalloc(&g->sc.d_fref, (nf + 1) * sizeof(double)));
+  if (!g->sc.d_skip && !g->faceless.empty()) {
+    std::vector<unsigned char> skip((size_t)g->nown, 0);
+    for (int i : g->faceless) skip[(size_t)i] = 1;
+    HIP_TRY(hipMalloc(&g->sc.d_skip, skip.size()));
+    HIP_TRY(hipMemcpy(g->sc.d_skip, skip.data(), skip.size(), hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMemset(g->sc.d_state, 0, GG_V_WORDS * sizeof(int)));
+  // bit for bit: the reference must come from the kernel form the steps will use.  The flux phase of the fused pass
+  // sums a point's faces on 4 lanes, the separate flux kernel by default on 8 (another association): with fused
+  // iterations on, the separate kernel -- reference now, last iteration's deferred flux later -- runs on 4 as well
+  g->sc.saved_flux_lanes = g->flux_lanes;
+  if (g->fusion && g->d_grad_alt) g->flux_lanes = 4;
+  if (launch_flux(g, g->last_flux_mode, g->s_main)) return 1;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(g->sc.d_fref, g->d_flux, nf * sizeof(double), hipMemcpyDeviceToDevice));
+  g->sc.on = true;
+  g->drop_graphs();  // graphs captured without the validation kernel
+  drop_ipc_graphs(g);
+  return 0;
+}
+
+int cfdp_gpu_scaled_check_end(cfdp_gpu *g, cfdp_scaled_check *out) {
+  NEED_UPLOAD(g);
+  if (!g->sc.on) return fail("the scaled-field validation is not on");
+  const int rc = flush_flux(g);  // compares the last iteration's flux as well
+  g->sc.on = false;
+  g->flux_lanes = g->sc.saved_flux_lanes;
+  g->drop_graphs();
+  drop_ipc_graphs(g);
+  if (rc) return 1;
+  HIP_TRY(hipDeviceSynchronize());
+  int st[GG_V_WORDS];
+  HIP_TRY(hipMemcpy(st, g->sc.d_state, sizeof st, hipMemcpyDeviceToHost));
+  const int m = st[GG_V_ITER] % 3;  // var holds var0 * 2^m
+  if (m) {
+    HIP_TRY(gg_launch_scale_var(g->d_var, g->nall, m == 1 ? 0.5 : 0.25, g->s_main));
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  if (out) {
+    unsigned long long bad = 0;
+    memcpy(&bad, &st[GG_V_BAD], sizeof bad);
+    out->iterations = st[GG_V_ITER];
+    out->flux_checks = st[GG_V_CHECKS];
+    out->mismatches = bad > 0x7FFFFFFFull ? 0x7FFFFFFF : (int)bad;
+    out->first_iteration = st[GG_V_CLAIM] ? st[GG_V_FIRST_ITER] : 0;
+    out->first_point = st[GG_V_CLAIM] ? g->new2old[(size_t)(st[GG_V_FIRST_IDX] / 3)] : -1;
+    out->first_component = st[GG_V_CLAIM] ? st[GG_V_FIRST_IDX] % 3 : -1;
+    out->seen = out->expected = 0.0;
+    if (st[GG_V_CLAIM]) {
+      memcpy(&out->seen, &st[GG_V_SEEN], sizeof(double));
+      memcpy(&out->expected, &st[GG_V_EXPECT], sizeof(double));
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------- one process per GPU: RCCL from C
+// The halo exchange of a step issued straight from this library: one ncclGroup of
+// ncclSend/ncclRecv per iteration on the context's comm stream, between the two step brackets
+// -- the analogue of exchange_dbl_mpi_send / _post_recv (src/exchange_data_mpi.c:96-166) with
+// the receive side being the ghost block itself.  A host pays ONE call per iteration (or one
+// per hipGraph replay of several).  RCCL is resolved at run time from the library the process
+// already uses (PyTorch ships its own librccl.so; a C host names the system one), so this
+// library has no link-time dependency on it.
+namespace {
+struct rccl_api {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+} rccl;
+
+#define RCCL_TRY(expr)                                                                              \
+  do {                                                                                              \
+    ncclResult_t r_ = (expr);                                                                       \
+    if (r_ != ncclSuccess)                                                                          \
+      return fail("%s failed: %s [%s:%d]", #expr, rccl.GetErrorString ? rccl.GetErrorString(r_) : "?", \
+                  __FILE__, __LINE__);                                                              \
+  } while (0)
+
+// this iteration's messages: sends from the packed arena, receives into the current ghost block
+int enqueue_exchange(cfdp_gpu *g) {
+  RCCL_TRY(rccl.GroupStart());
+  for (size_t s = 0; s < g->partner.size(); s++) {
+    size_t sb = 0, rb = 0;
+    void *sp = cfdp_gpu_send_ptr(g, (int)s, &sb), *rp = cfdp_gpu_recv_ptr(g, (int)s, &rb);
+    if (sb) RCCL_TRY(rccl.Send(sp, sb / sizeof(double), ncclDouble, g->peer[s], g->comm, g->s_comm));
+    if (rb) RCCL_TRY(rccl.Recv(rp, rb / sizeof(double), ncclDouble, g->peer[s], g->comm, g->s_comm));
+  }
+  RCCL_TRY(rccl.GroupEnd());
+  return 0;
+}
+
+int one_step(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {
+  if (cfdp_gpu_step_pre(g, with_exchange, overlap)) return 1;
+  if (g->pending_exchange && enqueue_exchange(g)) return 1;
+  return cfdp_gpu_step_post(g, with_flux, flux_mode);
+}
+}  // namespace
+
+int cfdp_rccl_load(const char *libpath) {
+  if (rccl.lib) return 0;
+  const char *names[] = {libpath, "librccl.so.1", "librccl.so"};
+  for (const char *n : names) {
+    if (!n || !*n) continue;
+    rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (rccl.lib) break;
+  }
+  if (!rccl.lib) return fail("cannot load RCCL (%s): %s", libpath ? libpath : "librccl.so.1", dlerror());
+#define RCCL_SYM(field, name)                                                      \
+  do {                                                                             \
+    *(void **)(&rccl.field) = dlsym(rccl.lib, name);                               \
+    if (!rccl.field) { rccl.lib = nullptr; return fail("RCCL symbol %s not found", name); } \
+  } while (0)
+  RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+  RCCL_SYM(CommInitRank, "ncclCommInitRank");
+  RCCL_SYM(CommDestroy, "ncclCommDestroy");
+  RCCL_SYM(GroupStart, "ncclGroupStart");
+  RCCL_SYM(GroupEnd, "ncclGroupEnd");
+  RCCL_SYM(Send, "ncclSend");
+  RCCL_SYM(Recv, "ncclRecv");
+  RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+  return 0;
+}
+
+int cfdp_rccl_unique_id(void *id128) {
+  if (!rccl.lib) return fail("cfdp_rccl_load() has not been called");
+  if (!id128) return fail("null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  RCCL_TRY(rccl.GetUniqueId(static_cast<ncclUniqueId *>(id128)));
+  return 0;
+}
+
+int cfdp_gpu_rccl_init(cfdp_gpu *g, const void *id128, int nranks, int rank, const int *rank_of_partner) {
+  NEED_UPLOAD(g);
+  if (!rccl.lib) return fail("cfdp_rccl_load() has not been called");
+  if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail("bad communicator arguments");
+  if (g->comm) return fail("this context already has a communicator");
+  g->peer.resize(g->partner.size());
+  for (size_t s = 0; s < g->partner.size(); s++) {
+    g->peer[s] = rank_of_partner ? rank_of_partner[s] : g->partner[s];
+    if (g->peer[s] < 0 || g->peer[s] >= nranks)
+      return fail("partner %d maps to communicator rank %d outside [0,%d)", g->partner[s], g->peer[s], nranks);
+  }
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  RCCL_TRY(rccl.CommInitRank(&g->comm, nranks, id, rank));
+  return 0;
+}
+
+int cfdp_gpu_rccl_finalize(cfdp_gpu *g) {
+  if (!g) return fail("null context");
+  if (g->comm) {
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipDeviceSynchronize());
+    RCCL_TRY(rccl.CommDestroy(g->comm));
+    g->comm = nullptr;
+  }
+  return 0;
+}
+
+// the RCCL group of the iteration opened by cfdp_gpu_step_pre (nothing if that step has no exchange)
+int cfdp_gpu_exchange_rccl(cfdp_gpu *g) {
+  NEED_UPLOAD(g);
+  if (!g->pending_exchange) return 0;
+  if (!g->comm) return fail("no communicator: call cfdp_gpu_rccl_init()");
+  return enqueue_exchange(g);
+}
+
+int cfdp_gpu_step_rccl(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {
+  NEED_UPLOAD(g);
+  if (with_exchange && !g->partner.empty() && !g->comm) return fail("no communicator: call cfdp_gpu_rccl_init()");
+  return one_step(g, with_exchange, overlap, with_flux, flux_mode);
+}
+
+// `steps` iterations enqueued by one call.  (Capturing the step -- RCCL group included -- in a
+// hipGraph was tried: with RCCL 2.26.6 / ROCm 7.0 hipStreamEndCapture crashes once ncclSend/
+// ncclRecv have been captured, so the steps are stream launches: ~54 us of host time each.)
+int cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
+                            int flux_mode) {
+  NEED_UPLOAD(g);
+  if (steps < 1) return fail("steps must be >= 1");
+  if (with_exchange && !g->partner.empty() && !g->comm) return fail("no communicator: call cfdp_gpu_rccl_init()");
+  for (int i = 0; i < steps; i++)
+    if (one_step(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
+  return 0;
+}
+
+// --------------------------------------- one process per GPU: xGMI write + notify (HIP IPC)
+// See gg_push_kernel.  Setup: every rank exports its block (cfdp_gpu_ipc_export), the host
+// exchanges the 64-byte handles and tells each rank, per partner slot, where in the partner's
+// block its rows land for either parity and where its arrival counter is (cfdp_gpu_ipc_connect);
+// cfdp_gpu_ipc_ready uploads the tables and switches the context's ghost block to the landing
+// arenas.  A step needs no communication library and no host involvement beyond kernel launches,
+// so a run of steps is replayed from one hipGraph.
+namespace {
+double g_ipc_wait_seconds = 0.0;
+}
+// polls (~1 us each) before a device-side wait for a partner gives up: about 10 s by default
+extern "C++" long cfdp_detail::ipc_max_polls() {
+  if (g_ipc_wait_seconds <= 0.0) {
+    const char *e = getenv("CFDP_IPC_WAIT_SECONDS");
+    g_ipc_wait_seconds = e && atof(e) > 0 ? atof(e) : 10.0;
+  }
+  return (long)(g_ipc_wait_seconds * 1e6);
+}
+
+extern "C++" void cfdp_detail::ipc_release(cfdp_gpu *g) {
+  auto &I = g->ipc;
+  I.wait_pending = false;
+  if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
+  if (I.graph_rem) { (void)hipGraphExecDestroy(I.graph_rem); I.graph_rem = nullptr; }
+  I.graph_n = I.graph_rem_n = 0;
+  for (void *p : I.opened) (void)hipIpcCloseMemHandle(p);
+  I.opened.clear(); I.opened_handle.clear();
+  for (int par = 0; par < 2; par++) { (void)hipFree(I.d_dst[par]); I.d_dst[par] = nullptr; I.dst[par].clear(); }
+  (void)hipFree(I.d_rflag); I.d_rflag = nullptr; I.rflag.clear();
+  (void)hipFree(I.d_slot_of_row); (void)hipFree(I.d_send_off);
+  (void)hipFree(I.d_tile_off); (void)hipFree(I.d_ent); (void)hipFree(I.d_ent_row);
+  (void)hipFree(I.d_pt_first); (void)hipFree(I.d_tile_xoff);
+  I.d_pt_first = nullptr; I.d_tile_xoff = nullptr;
+  I.d_slot_of_row = I.d_send_off = I.d_tile_off = I.d_ent = I.d_ent_row = nullptr;
+  I.inkernel = false;
+  (void)hipFree(I.d_done); (void)hipFree(I.d_need); (void)hipFree(I.d_tile_mask);
+  I.d_done = I.d_need = nullptr; I.d_tile_mask = nullptr; I.per_partner = false;
+  (void)hipFree(I.flags); I.flags = nullptr;
+  (void)hipFree(I.block); I.block = nullptr;
+  I.on = false; I.xiter = 0;
+}
+
+namespace {
+int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
+  const bool comm = with_exchange && !g->partner.empty();
+  g->pending_exchange = false;
+  g->iter++;
+  const bool fused = g->will_fuse();
+  if (!fused && flush_flux(g)) return 1;
+  auto grad_tiles = [&](int which, hipStream_t st) { return fused ? launch_fused(g, which, st) : launch_grad(g, which, st); };
+  // a pending wait for the previous exchange is absorbed by the boundary tiles of a pushing fused pass;
+  // every other schedule reads ghost rows without that check and needs the wait kernel first
+  if (!(comm && fused && g->ipc.inkernel && g->ipc.wait_inkernel) && ipc_settle(g)) return 1;
+  if (!comm) {
+    if (grad_tiles(CFDP_TILES_ALL, g->s_main)) return 1;
+    if (fused) fused_done(g);
+  } else {
+    auto &I = g->ipc;
+    const int nslots = (int)g->partner.size(), par = (int)((I.xiter + 1) & 1);
+    const gg_grad_view src = fused ? g->alt_view() : g->grad_view();  // the buffer this iteration's gradients go to
+    int pushed = 0;
+    if (fused && I.inkernel) {
+      // ONE launch for all tiles: the boundary tiles (first in the grid) push their send rows to the
+      // partners straight from their registers, the last of them raises the flags; the partners'
+      // rows arrive while the interior tiles run.  (Both exchange schedules map to this one: a
+      // fork/join between two streams costs 8-18 us per iteration inside a hipGraph.)
+      gg_push_args pa;
+      pa.tile_off = I.d_tile_off; pa.ent = I.d_ent; pa.ent_row = I.d_ent_row; pa.dst = I.d_dst[par];
+      pa.hdr = g->ipc_hdr(); pa.rflag = I.d_rflag; pa.done = I.d_done;
+      pa.need = I.per_partner ? I.d_need : nullptr; pa.tile_mask = I.per_partner ? I.d_tile_mask : nullptr;
+      pa.pt_first = I.d_pt_first; pa.pt_stride = I.pt_stride; pa.tile_xoff = I.d_tile_xoff;
+      pa.nbtiles = g->nbtiles; pa.nslots = nslots;
+      pa.inv_after_flag = I.mode == 2 ? 1 : 0;
+      pa.wait_polls = I.wait_pending && I.wait_inkernel && !I.fault_skip_wait ? (long)ipc_max_polls() : 0;
+      const int rc = launch_fused(g, CFDP_TILES_ALL, g->s_main, &pa);
+      if (rc == 1) return 1;
+      pushed = rc == 0;
+      if (pushed) I.wait_pending = false;  // absorbed (or there was none)
+      else if (ipc_settle(g)) return 1;    // no fused kernel fits these tiles: the separate kernels below
+    }
+    if (pushed) {
+    } else if (overlap) {
+      // boundary tiles -> push -> notify on the comm stream, the interior tiles on the main stream at
+      // the same time (see cfdp_gpu_step_pre); the wait joins them
+      if (fork_comm(g)) return 1;  // the comm stream forks off the main stream here
+      if (grad_tiles(CFDP_TILES_BOUNDARY, g->s_comm)) return 1;
+      HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_comm));
+      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, g->s_comm));
+      HIP_TRY(hipEventRecord(g->ev_senddone, g->s_comm));
+      if (grad_tiles(CFDP_TILES_INTERIOR, g->s_main)) return 1;
+      HIP_TRY(hipStreamWaitEvent(g->s_main, g->ev_senddone, 0));
+    } else {
+      if (grad_tiles(CFDP_TILES_ALL, g->s_main)) return 1;
+      HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_main));
+      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, g->s_main));
+    }
+    if (fused) fused_done(g);
+    I.xiter++;  // from here on the ghost block is the arena this exchange lands in
+    g->main_marked = false;
+    // the wait for this exchange: left to the boundary tiles of the next pushing pass (one launch per
+    // iteration), or -- ipc_settle -- to a wait kernel in front of whatever else reads the ghost rows first
+    I.wait_pending = true;
+    if (!(pushed && I.wait_inkernel) && ipc_settle(g)) return 1;
+  }
+  return 0;
+}
+
+int ipc_post(cfdp_gpu *g, int with_flux, int flux_mode);
+
+int one_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {
+  if (ipc_pre(g, with_exchange, overlap)) return 1;
+  return ipc_post(g, with_flux, flux_mode);
+}
+
+int ipc_post(cfdp_gpu *g, int with_flux, int flux_mode) {
+  if (with_flux) {
+    if (flux_mode != CFDP_FLUX_CONSISTENT && flux_mode != CFDP_FLUX_REFERENCE) return fail("bad flux mode %d", flux_mode);
+    if (g->fusion && g->d_grad_alt) g->flux_pending = flux_mode;
+    else if (launch_flux(g, flux_mode, g->s_main)) return 1;
+  }
+  if (scaled_tail(g, scaled_lag(g, with_flux), true, g->s_main)) return 1;
+  // no end-of-iteration marker here (each costs ~5 us on the device): a later step that needs to
+  // fork its comm stream records one itself (fork_comm), and the single-stream schedules need none
+  g->main_marked = false;
+  return 0;
+}
+}  // namespace
+
+// CFDP_IPC_MODE = coarse | split | fine (CFDP_IPC_FINEGRAINED=1 is the older spelling of fine)
+static int ipc_mode_from_env() {
+  if (const char *m = getenv("CFDP_IPC_MODE")) {
+    if (!strcmp(m, "fine")) return 1;
+    if (!strcmp(m, "split")) return 2;
+    if (!strcmp(m, "coarse")) return 0;
+  }
+  const char *fg = getenv("CFDP_IPC_FINEGRAINED");
+  return fg && atoi(fg) != 0 ? 1 : 0;
+}
+
+// a partner's block (or flag block), mapped once per handle
+static int ipc_open(cfdp_gpu *g, const void *handle64, unsigned char **base_out) {
+  auto &I = g->ipc;
+  void *base = nullptr;
+  for (size_t i = 0; i < I.opened.size(); i++)
+    if (!memcmp(I.opened_handle[i].data(), handle64, 64)) base = I.opened[i];
+  if (!base) {
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof h);
+    HIP_TRY(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+    I.opened.push_back(base);
+    I.opened_handle.emplace_back((const unsigned char *)handle64, (const unsigned char *)handle64 + 64);
+  }
+  *base_out = static_cast<unsigned char *>(base);
+  return 0;
+}
+
+int cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes) {
+  NEED_UPLOAD(g);
+  if (!handle64) return fail("null argument");
+  if ((int)g->partner.size() > GG_IPC_MAXSLOTS) return fail("more than %d partners", GG_IPC_MAXSLOTS);
+  for (size_t s = 0; s < g->partner.size(); s++)  // the double-buffered arenas rely on traffic in both directions
+    if (g->send_off[s + 1] == g->send_off[s] || g->recv_off[s + 1] == g->recv_off[s])
+      return fail("partner %d is not a two-way partner", g->partner[s]);
+  // the two landing arenas are safe without credit messages because only tiles that hold send
+  // points read ghost rows, and those tiles are done before this rank's next push is announced
+  if (g->interior_reads_ghosts)
+    return fail("a tile without send points reads ghost rows (one-way halo): not supported by this exchange");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "HIP IPC handles are 64 bytes");
+  ipc_release(g);
+  auto &I = g->ipc;
+  I.land_bytes = (((size_t)(g->nall - g->nown) * 21 * sizeof(double)) + 255) & ~(size_t)255;
+  const size_t bytes = GG_IPC_HDR_BYTES + 2 * I.land_bytes;
+  I.mode = ipc_mode_from_env();
+  if (I.mode == 1) HIP_TRY(hipExtMallocWithFlags((void **)&I.block, bytes, hipDeviceMallocFinegrained));
+  else HIP_TRY(hipMalloc(&I.block, bytes));
+  HIP_TRY(hipMemset(I.block, 0, bytes));
+  if (I.mode == 2) {  // the flag words alone in fine-grained memory (the header of `block` stays unused)
+    HIP_TRY(hipExtMallocWithFlags((void **)&I.flags, 64 * 1024, hipDeviceMallocFinegrained));
+    HIP_TRY(hipMemset(I.flags, 0, 64 * 1024));
+  }
+  hipIpcMemHandle_t h;
+  HIP_TRY(hipIpcGetMemHandle(&h, I.block));
+  memcpy(handle64, &h, sizeof h);
+  memcpy(I.my_handle, &h, sizeof h);
+  if (land_bytes) *land_bytes = I.land_bytes;
+  const int nslots = (int)g->partner.size();
+  I.dst[0].assign(nslots, nullptr); I.dst[1].assign(nslots, nullptr); I.rflag.assign(nslots, nullptr);
+  return 0;
+}
+
+int cfdp_gpu_ipc_connect(cfdp_gpu *g, int slot, const void *partner_handle64, size_t land_off0,
+                         size_t land_off1, size_t flag_off) {
+  NEED_UPLOAD(g);
+  auto &I = g->ipc;
+  if (!I.block) return fail("cfdp_gpu_ipc_export() first");
+  if (slot < 0 || slot >= (int)g->partner.size() || !partner_handle64) return fail("bad partner slot");
+  unsigned char *b = nullptr;
+  if (ipc_open(g, partner_handle64, &b)) return 1;
+  I.dst[0][slot] = reinterpret_cast<double *>(b + land_off0);
+  I.dst[1][slot] = reinterpret_cast<double *>(b + land_off1);
+  I.rflag[slot] = reinterpret_cast<int *>(b + flag_off);
+  return 0;
+}
+
+// the handle of the block that holds this rank's flag words: a block of its own in split mode, else the main block
+int cfdp_gpu_ipc_export_flags(cfdp_gpu *g, void *handle64) {
+  NEED_UPLOAD(g);
+  auto &I = g->ipc;
+  if (!I.block || !handle64) return fail("cfdp_gpu_ipc_export() first");
+  if (I.flags) {
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, I.flags));
+    memcpy(handle64, &h, sizeof h);
+  } else {
+    memcpy(handle64, I.my_handle, 64);
+  }
+  return 0;
+}
+
+// my arrival counter at partner `slot` lives at flag_off in the block of THAT handle (after cfdp_gpu_ipc_connect)
+int cfdp_gpu_ipc_connect_flags(cfdp_gpu *g, int slot, const void *partner_flags_handle64, size_t flag_off) {
+  NEED_UPLOAD(g);
+  auto &I = g->ipc;
+  if (!I.block) return fail("cfdp_gpu_ipc_export() first");
+  if (slot < 0 || slot >= (int)g->partner.size() || !partner_flags_handle64) return fail("bad partner slot");
+  unsigned char *b = nullptr;
+  if (ipc_open(g, partner_flags_handle64, &b)) return 1;
+  I.rflag[slot] = reinterpret_cast<int *>(b + flag_off);
+  return 0;
+}
+
+// MEASUREMENT ONLY (tools/loopback_probe.py): partner slot `slot` is this rank ITSELF -- its rows land in its own arenas
+// at the slot's receive offset, its flag is its own flag word.  The ghost rows then hold this rank's own send rows (wrong
+// values, right traffic): what one iteration of the write + notify protocol costs when the partner is never late.
+int cfdp_gpu_ipc_connect_loopback(cfdp_gpu *g, int slot) {
+  NEED_UPLOAD(g);
+  auto &I = g->ipc;
+  if (!I.block) return fail("cfdp_gpu_ipc_export() first");
+  if (slot < 0 || slot >= (int)g->partner.size()) return fail("bad partner slot");
+  if (g->send_off[slot + 1] - g->send_off[slot] > g->recv_off[slot + 1] - g->recv_off[slot])
+    return fail("loopback needs a receive slice at least as long as the send slice (slot %d)", slot);
+  const size_t base = GG_IPC_HDR_BYTES + (size_t)g->recv_off[slot] * 21 * sizeof(double);
+  I.dst[0][slot] = reinterpret_cast<double *>(I.block + base);
+  I.dst[1][slot] = reinterpret_cast<double *>(I.block + base + I.land_bytes);
+  I.rflag[slot] = g->ipc_hdr() + slot;
+  return 0;
+}
+
+// what the exchange set up by cfdp_gpu_ipc_ready does: bit 0 the fused pass pushes and notifies itself, bit 1 its
+// boundary tiles wait themselves, bit 2 per-partner notification and wait masks, bits 4-5 the memory mode
+// (0 coarse, 1 fine, 2 split)
+int cfdp_gpu_ipc_mode(const cfdp_gpu *g) {
+  if (!g || !g->ipc.block) return -1;
+  const auto &I = g->ipc;
+  return (I.inkernel ? 1 : 0) | (I.inkernel && I.wait_inkernel ? 2 : 0) | (I.per_partner ? 4 : 0) | (I.mode << 4);
+}
+
+int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
+  NEED_UPLOAD(g);
+  auto &I = g->ipc;
+  if (!I.block) return fail("cfdp_gpu_ipc_export() first");
+  const int nslots = (int)g->partner.size();
+  for (int s = 0; s < nslots; s++)
+    if (!I.dst[0][s] || !I.dst[1][s] || !I.rflag[s]) return fail("partner slot %d is not connected", s);
+  const size_t nsend = (size_t)g->send_off.back();
+  std::vector<int> slot_of_row(nsend ? nsend : 1, 0);
+  for (int s = 0; s < nslots; s++)
+    for (int j = g->send_off[s]; j < g->send_off[s + 1]; j++) slot_of_row[j] = s;
+  for (int par = 0; par < 2; par++) {
+    HIP_TRY(hipMalloc(&I.d_dst[par], sizeof(double *) * (size_t)(nslots ? nslots : 1)));
+    if (nslots) HIP_TRY(hipMemcpy(I.d_dst[par], I.dst[par].data(), sizeof(double *) * (size_t)nslots, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMalloc(&I.d_rflag, sizeof(int *) * (size_t)(nslots ? nslots : 1)));
+  if (nslots) HIP_TRY(hipMemcpy(I.d_rflag, I.rflag.data(), sizeof(int *) * (size_t)nslots, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&I.d_slot_of_row, sizeof(int) * slot_of_row.size()));
+  HIP_TRY(hipMemcpy(I.d_slot_of_row, slot_of_row.data(), sizeof(int) * slot_of_row.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&I.d_send_off, sizeof(int) * g->send_off.size()));
+  HIP_TRY(hipMemcpy(I.d_send_off, g->send_off.data(), sizeof(int) * g->send_off.size(), hipMemcpyHostToDevice));
+  {  // the send rows of every boundary tile: (tile-local point | slot << 16, row in the partner's slice)
+    std::vector<int> tile_off((size_t)g->ntiles + 1, 0), ent(nsend ? nsend : 1, 0), ent_row(nsend ? nsend : 1, 0), tile_of(nsend ? nsend : 1, 0);
+    bool ok = nslots <= 0x7FFF;
+    for (size_t j = 0; j < nsend && ok; j++) {
+      const int p = g->send_idx_host[j];
+      int lo = 0, hi = g->nbtiles - 1, t = -1;  // boundary tiles hold the send points, sorted by pstart
+      while (lo <= hi) {
+        const int mid = (lo + hi) / 2;
+        if (p < g->h_tiles[mid].pstart) hi = mid - 1;
+        else if (p >= g->h_tiles[mid].pstart + g->h_tiles[mid].npts) lo = mid + 1;
+        else { t = mid; break; }
+      }
+      if (t < 0 || p - g->h_tiles[t].pstart > 0xFFFF) { ok = false; break; }
+      tile_of[j] = t;
+      tile_off[t + 1]++;
+    }
+    I.inkernel = false;
+    if (ok && nsend) {
+      for (int t = 0; t < g->ntiles; t++) tile_off[t + 1] += tile_off[t];
+      // a point's FIRST destination (message order) goes into the point-major table and to the front of its tile's
+      // entries; further destinations (points on an edge or corner between partners) behind them, from tile_xoff on
+      // (stride = the lanes-per-point groups of the LARGEST workgroup a launch over all tiles can have: every thread of
+      // a boundary tile's workgroup reads its group's entry, also the groups beyond the tile's points)
+      int tpmax = 1;
+      for (int t = 0; t < g->ntiles; t++) tpmax = g->h_tiles[t].npts > tpmax ? g->h_tiles[t].npts : tpmax;
+      I.pt_stride = (tpmax + 63) & ~63;
+      std::vector<int2> pt_first((size_t)(g->nbtiles ? g->nbtiles : 1) * I.pt_stride, make_int2(-1, 0));
+      std::vector<int> tile_xoff((size_t)g->ntiles + 1, 0), nfirst((size_t)g->ntiles, 0);
+      std::vector<char> is_first(nsend, 0);
+      for (size_t j = 0; j < nsend; j++) {
+        const int t = tile_of[j], li = g->send_idx_host[j] - g->h_tiles[t].pstart;
+        int2 &f = pt_first[(size_t)t * I.pt_stride + li];
+        if (f.x < 0) { f = make_int2(slot_of_row[j], (int)j - g->send_off[slot_of_row[j]]); is_first[j] = 1; nfirst[t]++; }
+      }
+      std::vector<int> fill(tile_off.begin(), tile_off.end() - 1), fillx((size_t)g->ntiles, 0);
+      for (int t = 0; t < g->ntiles; t++) { tile_xoff[t] = tile_off[t] + nfirst[t]; fillx[t] = tile_xoff[t]; }
+      tile_xoff[g->ntiles] = tile_off[g->ntiles];
+      for (size_t j = 0; j < nsend; j++) {
+        const int t = tile_of[j], s = slot_of_row[j], at = is_first[j] ? fill[t]++ : fillx[t]++;
+        ent[at] = (g->send_idx_host[j] - g->h_tiles[t].pstart) | (s << 16);
+        ent_row[at] = (int)j - g->send_off[s];
+      }
+      HIP_TRY(hipMalloc(&I.d_pt_first, sizeof(int2) * pt_first.size()));
+      HIP_TRY(hipMemcpy(I.d_pt_first, pt_first.data(), sizeof(int2) * pt_first.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&I.d_tile_xoff, sizeof(int) * tile_xoff.size()));
+      HIP_TRY(hipMemcpy(I.d_tile_xoff, tile_xoff.data(), sizeof(int) * tile_xoff.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&I.d_tile_off, sizeof(int) * tile_off.size()));
+      HIP_TRY(hipMemcpy(I.d_tile_off, tile_off.data(), sizeof(int) * tile_off.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&I.d_ent, sizeof(int) * ent.size()));
+      HIP_TRY(hipMemcpy(I.d_ent, ent.data(), sizeof(int) * ent.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&I.d_ent_row, sizeof(int) * ent_row.size()));
+      HIP_TRY(hipMemcpy(I.d_ent_row, ent_row.data(), sizeof(int) * ent_row.size(), hipMemcpyHostToDevice));
+      const char *e = getenv("CFDP_IPC_INKERNEL");
+      // the tiles push what they have just computed; a send point WITHOUT faces is computed by nobody
+      // and its stored row must travel (as pack / the push kernel send it, and the reference's
+      // exchange_dbl_copy_in, src/threads.c:791-813): such partitions keep the separate push kernel
+      I.inkernel = g->nbtiles > 0 && !g->faceless_send && !(e && atoi(e) == 0);
+      const char *w = getenv("CFDP_IPC_WAIT_INKERNEL");  // 0: always a separate wait kernel (A/B timing)
+      I.wait_inkernel = !(w && atoi(w) == 0);
+      // per-partner notification needs: every boundary tile reads ghost rows only of partners it sends to (then the
+      // flags a tile waits for also cover the rows it is about to overwrite at those partners, see gg_kernels.hip)
+      std::vector<unsigned long long> smask((size_t)g->nbtiles, 0ull);
+      std::vector<int> need((size_t)(nslots ? nslots : 1), 0);
+      for (int t = 0; t < g->nbtiles; t++)
+        for (int e2 = tile_off[t]; e2 < tile_off[t + 1]; e2++) smask[(size_t)t] |= 1ull << (ent[e2] >> 16);
+      bool pp = nslots <= GG_IPC_MAXSLOTS && (int)g->tile_recv_mask.size() == g->nbtiles;
+      for (int t = 0; t < g->nbtiles && pp; t++) pp = (g->tile_recv_mask[(size_t)t] & ~smask[(size_t)t]) == 0;
+      for (int t = 0; t < g->nbtiles; t++)
+        for (int s2 = 0; s2 < nslots; s2++)
+          if ((smask[(size_t)t] >> s2) & 1ull) need[(size_t)s2]++;
+      for (int s2 = 0; s2 < nslots; s2++) pp = pp && need[(size_t)s2] > 0;
+      const char *ppe = getenv("CFDP_IPC_PER_PARTNER");  // 0: one counter, all flags raised by the last boundary tile (A/B)
+      I.per_partner = pp && !(ppe && atoi(ppe) == 0);
+      HIP_TRY(hipMalloc(&I.d_need, sizeof(int) * need.size()));
+      HIP_TRY(hipMemcpy(I.d_need, need.data(), sizeof(int) * need.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&I.d_tile_mask, sizeof(unsigned long long) * (smask.size() + 1)));
+      if (!smask.empty())
+        HIP_TRY(hipMemcpy(I.d_tile_mask, smask.data(), sizeof(unsigned long long) * smask.size(), hipMemcpyHostToDevice));
+      const char *f = getenv("CFDP_IPC_FAULT");
+      I.fault_skip_wait = f && !strcmp(f, "skip_wait");
+      if (I.fault_skip_wait) fprintf(stderr, "[cfdp] FAULT INJECTION: boundary tiles do not wait for the previous exchange (CFDP_IPC_FAULT)\n");
+    }
+  }
+  HIP_TRY(hipMalloc(&I.d_done, sizeof(int) * (GG_IPC_MAXSLOTS + 1) * GG_DONE_STRIDE));
+  HIP_TRY(hipMemset(I.d_done, 0, sizeof(int) * (GG_IPC_MAXSLOTS + 1) * GG_DONE_STRIDE));
+  if (flush_flux(g)) return 1;
+  HIP_TRY(hipDeviceSynchronize());
+  // the ghost rows move into the landing arenas
+  if (g->nall > g->nown)
+    for (int par = 0; par < 2; par++)
+      HIP_TRY(hipMemcpy(g->land(par), g->d_grad + (size_t)g->nown * 10, sizeof(double) * 21 * (size_t)(g->nall - g->nown),
+                        hipMemcpyDeviceToDevice));
+  I.xiter = 0;
+  I.on = true;
+  g->drop_graphs();
+  return 0;
+}
+
+// switch between the landing arenas and the ghost block of grad (e.g. to time another transport
+// on the same context); the mappings stay
+int cfdp_gpu_ipc_enable(cfdp_gpu *g, int on) {
+  NEED_UPLOAD(g);
+  auto &I = g->ipc;
+  if (on && (!I.block || !I.d_rflag)) return fail("cfdp_gpu_ipc_ready() has not been called");
+  if (flush_flux(g)) return 1;
+  HIP_TRY(hipDeviceSynchronize());
+  I.on = on != 0;
+  g->drop_graphs();
+  return 0;
+}
+
+// how long a device-side wait polls before it gives up (process-wide; also CFDP_IPC_WAIT_SECONDS).
+// Graphs captured earlier keep the bound they were captured with.
+int cfdp_ipc_set_wait_seconds(double seconds) {
+  if (!(seconds > 0.0)) return fail("the wait bound must be positive");
+  g_ipc_wait_seconds = seconds;
+  return 0;
+}
+
+int cfdp_gpu_ipc_disconnect(cfdp_gpu *g) {
+  if (!g) return fail("null context");
+  HIP_TRY(hipSetDevice(g->device));
+  HIP_TRY(hipDeviceSynchronize());
+  ipc_release(g);
+  return 0;
+}
+
+// 1 if a wait for a partner's rows gave up (the partner is gone or far behind), else 0; -1 on error
+int cfdp_gpu_ipc_error(cfdp_gpu *g) {
+  if (!g || !g->ipc.block) return 0;
+  if (hipSetDevice(g->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+  int h[64];
+  if (hipMemcpy(h, g->ipc_hdr(), sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  const int *e = h + GG_IPC_ERR;
+  if (getenv("CFDP_DEBUG_TRACE"))
+    fprintf(stderr, "[cfdp] ipc state: host xiter %ld, device iteration counter %d, arrival counter of slot 0: %d; "
+                    "%d waits gave up (last: slot %d, waiting for %d, saw %d)\n",
+            g->ipc.xiter, h[GG_IPC_ITER], h[0], e[4], e[1], e[2], e[3]);
+  return e[0] != 0;
+}
+
+// for hosts that call the two face loops separately: the part of an iteration before the flux
+// (gradients, push, notify, wait) and the flux part
+int cfdp_gpu_step_ipc_post(cfdp_gpu *g, int with_flux, int flux_mode) {
+  NEED_UPLOAD(g);
+  if (!g->ipc.on) return fail("cfdp_gpu_ipc_ready() has not been called");
+  return ipc_post(g, with_flux, flux_mode);
+}
+
+int cfdp_gpu_step_ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
+  NEED_UPLOAD(g);
+  if (!g->ipc.on) return fail("cfdp_gpu_ipc_ready() has not been called");
+  return ipc_pre(g, with_exchange, overlap);
+}
+
+int cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode) {
+  NEED_UPLOAD(g);
+  if (!g->ipc.on) return fail("cfdp_gpu_ipc_ready() has not been called");
+  return one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode);
+}
+
+// `steps` iterations.  use_graph: after two lead-in steps (the first iteration of a run has no flux to
+// fuse with), the steps are replayed from hipGraphs -- both streams, the push / notify / wait kernels
+// included: whole chunks of 50 from one graph, the even part of the remainder from a second one (an
+// even count restores the parity of the landing arenas and of the two grad buffers, which the kernels'
+// arguments bake in), at most one step launched from the streams -- so short runs replay as well.
+int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
+                           int flux_mode, int use_graph) {
+  NEED_UPLOAD(g);
+  if (!g->ipc.on) return fail("cfdp_gpu_ipc_ready() has not been called");
+  if (steps < 1) return fail("steps must be >= 1");
+  auto &I = g->ipc;
+  const int full = 50;  // steps per replay of the main graph (2 kernels each with the in-kernel push)
+  int done = 0;
+  if (use_graph && steps >= 4) {
+    for (; done < 2; done++)
+      if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
+    if (I.xiter & 1) {  // a graph is tied to the arena parity it was captured at: even
+      if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
+      done++;
+    }
+    // (the arena the ghost rows are read from is baked into the kernels' arguments too)
+    if (I.g_exch != with_exchange || I.g_overlap != overlap || I.g_flux != with_flux || I.g_mode != flux_mode ||
+        I.g_cur != g->d_grad || I.g_xpar != (int)(I.xiter & 1)) {
+      if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
+      if (I.graph_rem) { (void)hipGraphExecDestroy(I.graph_rem); I.graph_rem = nullptr; }
+      I.graph_n = I.graph_rem_n = 0;
+    }
+    auto capture = [&](hipGraphExec_t &slot, int &slot_n, int n) -> bool {  // false: run from the streams instead
+      if (slot && slot_n == n) return true;
+      if (slot) { (void)hipGraphExecDestroy(slot); slot = nullptr; }
+      slot_n = 0;
+      const double *cur0 = g->d_grad;
+      const int pend0 = g->flux_pending;
+      const long iter0 = g->iter, x0 = I.xiter;
+      const unsigned passes0 = g->fused_passes;
+      const bool wait0 = I.wait_pending;  // a chunk starts and ends with the wait of its last exchange pending
+      hipGraph_t gr = nullptr;
+      if (hipStreamBeginCapture(g->s_main, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return false; }
+      g->main_marked = false;  // the first captured step must fork off a record made INSIDE the capture
+      int rc = 0;
+      for (int i = 0; i < n && !rc; i++) rc = one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode);
+      hipError_t ec = hipStreamEndCapture(g->s_main, &gr);
+      (void)hipEventRecord(g->ev_fork, g->s_main);      // events last recorded inside a capture may not
+      (void)hipEventRecord(g->ev_senddone, g->s_comm);  // be waited for outside it: re-arm them
+      (void)mark_main(g);
+      const bool ok = !rc && ec == hipSuccess && gr && g->d_grad == cur0 && g->flux_pending == pend0 && I.wait_pending == wait0;
+      if (ok && hipGraphInstantiate(&slot, gr, nullptr, nullptr, 0) != hipSuccess) slot = nullptr;
+      if (gr) (void)hipGraphDestroy(gr);
+      g->iter = iter0;
+      I.xiter = x0;  // nothing of the capture has run
+      g->fused_passes = passes0;
+      I.wait_pending = wait0;
+      if (!ok || !slot) {
+        if (g->d_grad != cur0) { std::swap(g->d_grad, g->d_grad_alt); std::swap(g->own_grad, g->own_grad_alt); }
+        g->flux_pending = pend0;
+        (void)hipGetLastError();
+        return false;
+      }
+      slot_n = n;
+      I.g_exch = with_exchange; I.g_overlap = overlap; I.g_flux = with_flux; I.g_mode = flux_mode; I.g_cur = g->d_grad;
+      I.g_xpar = (int)(I.xiter & 1);
+      return true;
+    };
+    auto replay = [&](hipGraphExec_t ge, int n) -> int {
+      HIP_TRY(hipGraphLaunch(ge, g->s_main));
+      // (a replay does not touch the event OBJECTS recorded inside the capture: whatever is ordered
+      // after "the previous iteration" later needs a fresh record -- fork_comm makes one)
+      g->main_marked = false;
+      g->iter += n;
+      if (with_exchange && !g->partner.empty()) I.xiter += n;
+      done += n;
+      return 0;
+    };
+    if (steps - done >= full && capture(I.graph, I.graph_n, full))
+      while (steps - done >= full)
+        if (replay(I.graph, full)) return 1;
+    const int rem = (steps - done) & ~1;
+    if (rem >= 2 && rem < full && capture(I.graph_rem, I.graph_rem_n, rem) && replay(I.graph_rem, rem)) return 1;
+  }
+  for (; done < steps; done++)
+    if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
+  return 0;
+}
+
+}  // extern "C"
