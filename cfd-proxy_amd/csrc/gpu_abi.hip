@@ -420,6 +420,7 @@ int cfdp_gpu_set_variant(cfdp_gpu *g, int grad_lanes, int flux_lanes) {
   if (grad_lanes == 0) grad_lanes = 4;
   if (flux_lanes == 0) flux_lanes = 8;
   if (!ok(grad_lanes) || !ok(flux_lanes)) return fail("lanes per point must be 1, 2, 4 or 8");
+  if (g->grad_lanes != grad_lanes || g->flux_lanes != flux_lanes) g->ipc.drop_graph_sets();  // the kernel forms are baked in
   g->grad_lanes = grad_lanes;
   g->flux_lanes = flux_lanes;
   return 0;

@@ -114,10 +114,25 @@ struct cfdp_gpu {
     // the previous exchange -- they read whatever the landing arena holds.  Exists so that a test can show that the
     // scaled-field validation sees a ghost row read one exchange early, and that a comparison of final states does not
     bool fault_skip_wait = false;
-    hipGraphExec_t graph = nullptr, graph_rem = nullptr;  // main chunk; what is left after whole chunks
-    int graph_n = 0, graph_rem_n = 0;
-    int g_exch = -1, g_overlap = -1, g_flux = -1, g_mode = -1, g_xpar = -1;
-    const double *g_cur = nullptr;
+    // hipGraphs of cfdp_gpu_run_steps_ipc, one set per configuration: a captured chunk has the schedule, the flux mode, the
+    // arena parity AND the current grad buffer baked into its kernels' arguments.  Runs of different schedules alternate
+    // (a benchmark times with exchange / without / bulk in turn) and an odd number of passes flips the grad buffers, so
+    // several sets stay cached -- a set that had to be re-captured inside a timed region would be timed with its capture
+    struct graph_set {
+      hipGraphExec_t graph = nullptr, graph_rem = nullptr;  // main chunk of 50 steps; what is left after whole chunks
+      int graph_n = 0, graph_rem_n = 0;
+      int exch = -1, overlap = -1, flux = -1, mode = -1, xpar = -1, scaled = -1;
+      const double *cur = nullptr;
+      unsigned long used = 0;
+    } gs[8];
+    unsigned long gs_clock = 0;
+    void drop_graph_sets() {
+      for (auto &x : gs) {
+        if (x.graph) (void)hipGraphExecDestroy(x.graph);
+        if (x.graph_rem) (void)hipGraphExecDestroy(x.graph_rem);
+        x = graph_set();
+      }
+    }
   } ipc;
   double *land(int parity) const {
     return reinterpret_cast<double *>(ipc.block + GG_IPC_HDR_BYTES + (size_t)parity * ipc.land_bytes);
@@ -160,7 +175,8 @@ struct cfdp_gpu {
   const double *graph_cur = nullptr;  // d_grad at the last capture: the graphs' pointers are baked in
   const double *graph_cur_slot[2] = {nullptr, nullptr};  // ... per slot ([0] graph, [1] graph_rem)
   const double *graph_whole_final = nullptr;  // whole-run graph: the buffer holding its last gradients
-  void drop_graphs() {
+  void drop_graphs() {  // every cached graph has the grad buffers / kernel variants of its capture baked in
+    ipc.drop_graph_sets();
     if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
     if (graph_rem) { (void)hipGraphExecDestroy(graph_rem); graph_rem = nullptr; }
     graph_iters = graph_rem_iters = 0;

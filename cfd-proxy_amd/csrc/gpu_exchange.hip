@@ -14,12 +14,7 @@ extern "C" {
 // compute_psd_flux) ends with the validation kernel: compare the flux the step produced with reference * 2^e, then
 // var *= 2, 2, 1/4, ...  Every step must exchange and compute the flux while the mode is on.  end: the deferred flux of
 // the last iteration is compared too, var is restored exactly, the evidence is returned.
-extern "C++" void cfdp_detail::drop_ipc_graphs(cfdp_gpu *g) {
-  auto &I = g->ipc;
-  if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
-  if (I.graph_rem) { (void)hipGraphExecDestroy(I.graph_rem); I.graph_rem = nullptr; }
-  I.graph_n = I.graph_rem_n = 0;
-}
+extern "C++" void cfdp_detail::drop_ipc_graphs(cfdp_gpu *g) { g->ipc.drop_graph_sets(); }
 
 int cfdp_gpu_scaled_check_begin(cfdp_gpu *g) {
   NEED_UPLOAD(g);
@@ -245,9 +240,7 @@ extern "C++" long cfdp_detail::ipc_max_polls() {
 extern "C++" void cfdp_detail::ipc_release(cfdp_gpu *g) {
   auto &I = g->ipc;
   I.wait_pending = false;
-  if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
-  if (I.graph_rem) { (void)hipGraphExecDestroy(I.graph_rem); I.graph_rem = nullptr; }
-  I.graph_n = I.graph_rem_n = 0;
+  I.drop_graph_sets();
   for (void *p : I.opened) (void)hipIpcCloseMemHandle(p);
   I.opened.clear(); I.opened_handle.clear();
   for (int par = 0; par < 2; par++) { (void)hipFree(I.d_dst[par]); I.d_dst[par] = nullptr; I.dst[par].clear(); }
@@ -676,13 +669,14 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
   const int full = 50;  // steps per replay of the main graph (2 kernels each with the in-kernel push)
   int done = 0;
   if (use_graph && steps >= 4) {
-    // The first iteration of a run has no flux to fuse with: it would take the un-fused schedule (gradient kernel on two
-    // streams, push, notify and wait kernels: 57-120 us per step in loopback where the pushing fused pass takes 41).  In a
-    // batch of exchanging steps that all compute the flux, pretend the previous flux is pending again instead: the first
-    // pass recomputes it from the gradients and ghost rows it was computed from (the same values; psd_flux is rewritten
-    // by every step of the batch anyway) and the run is in its steady state -- and in its hipGraphs -- from step one.
-    if (with_flux && with_exchange && !g->partner.empty() && g->fusion && g->d_grad_alt && g->flux_pending < 0 && I.inkernel &&
-        !g->sc.on)
+    // The first iteration of a run has no flux to fuse with: it would take the un-fused schedule (with exchange: gradient
+    // kernel on two streams, push, notify and wait kernels: 57-120 us per step in loopback where the pushing fused pass
+    // takes 41) from the streams.  In a batch of steps that all compute the flux, pretend the previous flux is pending
+    // again instead: the first pass recomputes it from the gradients and ghost rows it was computed from (the same values;
+    // psd_flux is rewritten by every step of the batch anyway) and the run is in its steady state -- and in its
+    // hipGraphs -- from step one, with and without exchange alike (a benchmark compares the two).
+    if (with_flux && g->fusion && g->d_grad_alt && g->flux_pending < 0 && !g->sc.on &&
+        (!with_exchange || g->partner.empty() || I.inkernel))
       g->flux_pending = flux_mode;
     // lead-in steps from the streams until the state every captured chunk starts and ends in is reached: a flux pending
     // (fused schedule), the arena parity even
@@ -692,13 +686,24 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
       done++;
     }
-    // (the arena the ghost rows are read from is baked into the kernels' arguments too)
-    if (I.g_exch != with_exchange || I.g_overlap != overlap || I.g_flux != with_flux || I.g_mode != flux_mode ||
-        I.g_cur != g->d_grad || I.g_xpar != (int)(I.xiter & 1)) {
-      if (I.graph) { (void)hipGraphExecDestroy(I.graph); I.graph = nullptr; }
-      if (I.graph_rem) { (void)hipGraphExecDestroy(I.graph_rem); I.graph_rem = nullptr; }
-      I.graph_n = I.graph_rem_n = 0;
+    // the graph set of this configuration (the arena the ghost rows are read from and the current grad buffer are baked
+    // into the kernels' arguments too), or the least recently used one to capture into
+    cfdp_gpu::ipc_state::graph_set *S = nullptr;
+    for (auto &x : I.gs)
+      if (x.exch == with_exchange && x.overlap == overlap && x.flux == with_flux && x.mode == flux_mode && x.cur == g->d_grad &&
+          x.xpar == (int)(I.xiter & 1) && x.scaled == (int)g->sc.on)
+        S = &x;
+    if (!S) {
+      S = &I.gs[0];
+      for (auto &x : I.gs)
+        if (x.used < S->used) S = &x;
+      if (S->graph) (void)hipGraphExecDestroy(S->graph);
+      if (S->graph_rem) (void)hipGraphExecDestroy(S->graph_rem);
+      *S = cfdp_gpu::ipc_state::graph_set();
+      S->exch = with_exchange; S->overlap = overlap; S->flux = with_flux; S->mode = flux_mode; S->cur = g->d_grad;
+      S->xpar = (int)(I.xiter & 1); S->scaled = (int)g->sc.on;
     }
+    S->used = ++I.gs_clock;
     auto capture = [&](hipGraphExec_t &slot, int &slot_n, int n) -> bool {  // false: run from the streams instead
       if (slot && slot_n == n) return true;
       if (slot) { (void)hipGraphExecDestroy(slot); slot = nullptr; }
@@ -731,8 +736,6 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
         return false;
       }
       slot_n = n;
-      I.g_exch = with_exchange; I.g_overlap = overlap; I.g_flux = with_flux; I.g_mode = flux_mode; I.g_cur = g->d_grad;
-      I.g_xpar = (int)(I.xiter & 1);
       return true;
     };
     auto replay = [&](hipGraphExec_t ge, int n) -> int {
@@ -745,11 +748,11 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       done += n;
       return 0;
     };
-    if (steps - done >= full && capture(I.graph, I.graph_n, full))
+    if (steps - done >= full && capture(S->graph, S->graph_n, full))
       while (steps - done >= full)
-        if (replay(I.graph, full)) return 1;
+        if (replay(S->graph, full)) return 1;
     const int rem = (steps - done) & ~1;
-    if (rem >= 2 && rem < full && capture(I.graph_rem, I.graph_rem_n, rem) && replay(I.graph_rem, rem)) return 1;
+    if (rem >= 2 && rem < full && capture(S->graph_rem, S->graph_rem_n, rem) && replay(S->graph_rem, rem)) return 1;
   }
   for (; done < steps; done++)
     if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;

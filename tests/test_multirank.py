@@ -39,6 +39,17 @@ def _launch(world, extra, extra_env=None, rejected_ok=False):
     if rejected_ok and all(p.returncode == 77 for p in procs):  # every rank alike: the validation rejected the mode
         ev = [l for l in outs[0].splitlines() if l.startswith("MODE_REJECTED ")]
         return ev[-1] if ev else "MODE_REJECTED"
+    if any(p.returncode != 0 or f"RANK_OK {r}" not in out for r, (p, out) in enumerate(zip(procs, outs))):
+        try:  # keep every rank's whole output where a GPU box's results are collected
+            import time
+            d = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, f"multirank_failure_{int(time.time())}.log"), "w") as fh:
+                fh.write(f"world {world} extra {extra} env {extra_env}\n")
+                for r, (p, out) in enumerate(zip(procs, outs)):
+                    fh.write(f"\n===== rank {r} rc {p.returncode}\n{out}\n")
+        except OSError:
+            pass
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in out, out[-3000:]
     return None
