@@ -127,6 +127,9 @@ struct cfdp_gpu {
     } gs[8];
     unsigned long gs_clock = 0;
     void drop_graph_sets() {
+      bool any = false;
+      for (auto &x : gs) any = any || x.graph || x.graph_rem;
+      if (any) (void)hipDeviceSynchronize();  // a graph that is still replaying must not be destroyed under it
       for (auto &x : gs) {
         if (x.graph) (void)hipGraphExecDestroy(x.graph);
         if (x.graph_rem) (void)hipGraphExecDestroy(x.graph_rem);

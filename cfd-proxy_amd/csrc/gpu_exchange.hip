@@ -51,10 +51,11 @@ int cfdp_gpu_scaled_check_end(cfdp_gpu *g, cfdp_scaled_check *out) {
   const int rc = flush_flux(g);  // compares the last iteration's flux as well
   g->sc.on = false;
   g->flux_lanes = g->sc.saved_flux_lanes;
+  const hipError_t es = hipDeviceSynchronize();  // (a graph that is still replaying must not be destroyed under it)
   g->drop_graphs();
   drop_ipc_graphs(g);
   if (rc) return 1;
-  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(es);
   int st[GG_V_WORDS];
   HIP_TRY(hipMemcpy(st, g->sc.d_state, sizeof st, hipMemcpyDeviceToHost));
   const int m = st[GG_V_ITER] % 3;  // var holds var0 * 2^m
@@ -697,6 +698,7 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       S = &I.gs[0];
       for (auto &x : I.gs)
         if (x.used < S->used) S = &x;
+      if (S->graph || S->graph_rem) HIP_TRY(hipStreamSynchronize(g->s_main));  // (it may still be replaying)
       if (S->graph) (void)hipGraphExecDestroy(S->graph);
       if (S->graph_rem) (void)hipGraphExecDestroy(S->graph_rem);
       *S = cfdp_gpu::ipc_state::graph_set();
@@ -706,7 +708,11 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
     S->used = ++I.gs_clock;
     auto capture = [&](hipGraphExec_t &slot, int &slot_n, int n) -> bool {  // false: run from the streams instead
       if (slot && slot_n == n) return true;
-      if (slot) { (void)hipGraphExecDestroy(slot); slot = nullptr; }
+      if (slot) {  // another length wanted: the old one may still be replaying
+        (void)hipStreamSynchronize(g->s_main);
+        (void)hipGraphExecDestroy(slot);
+        slot = nullptr;
+      }
       slot_n = 0;
       const double *cur0 = g->d_grad;
       const int pend0 = g->flux_pending;
