@@ -185,6 +185,8 @@ def main() -> None:
     ap.add_argument("--no-files", action="store_true", help="generate domains in memory (skip the loader)")
     ap.add_argument("--no-finest", action="store_true", help="skip the finest-level single-GPU roofline run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    ap.add_argument("--no-loopback", action="store_true",
+                    help="skip the loopback measurement of the exchange protocol's own cost (N = 1 only)")
     ap.add_argument("--no-weak", action="store_true", help="skip the extra weak-scaling measurement at --gpus 2 / 4")
     ap.add_argument("--cpu-samples", type=int, default=7)
     ap.add_argument("--transport", default="auto", choices=["auto", "ipc", "rccl", "torch", "staged"],
@@ -476,6 +478,57 @@ def main() -> None:
             out["finest_level"] = fl
             p1.close()
             d1.free()
+    if rank == 0 and world == 1 and not args.no_loopback and not args.no_fusion:
+        # ---- what the xGMI write + notify protocol itself costs per iteration when no partner is ever late: rank 0's partition
+        # of the 8-GPU configs on THIS GPU, every partner slot looped back to the rank's own landing arenas and flag words
+        # (cfdp_gpu_ipc_connect_loopback: wrong ghost values, right traffic, right protocol).  comm_free / with_exchange is an
+        # UPPER bound of the overlap efficiency a rank with a GPU of its own can reach (DESIGN appendix C.4)
+        t_lb = lap("finest level", t_phase)
+        try:
+            lb = {}
+            for name in ("dualgrid.384", "dualgrid.192"):
+                c8 = mg.bench_config(name, 8)
+                gp8 = pkg.gen_params(*c8["dims"], ndomains=c8["ndomains"])
+                parts8 = [mg.build_rank_partition(gp8, c8["ndomains"], 8, r, via_files=False)[0] for r in range(8)]
+                reqs = [{int(k): (v[0], v[1]) for k, v in pkg.merge_requests(p).items()} for p in parts8]
+                mg.exchange_requests(parts8[0], 0, 8, None, all_requests=reqs)
+                g8 = pkg.GpuPartition(parts8[0], device=device)
+                g8.set_fusion(True)
+                g8.ipc_export()
+                for s_ in range(len(g8.partners())):
+                    g8._ck(g8.lib.cfdp_gpu_ipc_connect_loopback(g8.h, s_))
+                g8.ipc_ready()
+
+                def lb_time(steps, reps, **kw):
+                    g8.run_steps_ipc(200, **kw)
+                    g8.sync()
+                    best = float("inf")
+                    for _ in range(reps):
+                        t_ = time.perf_counter()
+                        g8.run_steps_ipc(steps, **kw)
+                        g8.sync()
+                        best = min(best, (time.perf_counter() - t_) / steps)
+                    return best * 1e6
+                free = lb_time(1000, 3, with_exchange=False, overlap=True)
+                exch = lb_time(1000, 3, with_exchange=True, overlap=True)
+                free20 = lb_time(20, 5, with_exchange=False, overlap=True)
+                exch20 = lb_time(20, 5, with_exchange=True, overlap=True)
+                lb[name] = {"partition": f"rank 0 of 8: {parts8[0].nown} points, {len(g8.partners())} partners, "
+                                         f"{g8.stats['nbtiles']} boundary tiles of {g8.stats['ntiles']}",
+                            "us_per_iteration_comm_free": free, "us_per_iteration_with_exchange": exch,
+                            "efficiency_bound": free / exch, "steps20_comm_free": free20, "steps20_with_exchange": exch20,
+                            "steps20_ratio": free20 / exch20, "wait_timeouts": int(g8.ipc_error() != 0),
+                            "protocol": g8.ipc_mode()}
+                g8.ipc_disconnect()
+                g8.close()
+                for p8 in parts8:
+                    p8.free()
+            lb["note"] = ("ONE GPU, every partner slot looped back to the rank's own arenas and flags: the protocol's own cost with a "
+                          "partner that is never late; an upper bound of the overlap efficiency, not a measurement of it")
+            out["exchange_protocol_loopback"] = lb
+        except Exception as e:  # never costs the line
+            out["exchange_protocol_loopback"] = {"error": repr(e)[:300]}
+        t_phase = lap("exchange protocol in loopback", t_lb)
     # ---- CPU baseline on rank 0's host cores, at every N: the COMPILED REFERENCE (oracle/_ref/ref_dump_raw: the
     # reference's own OpenMP path, src/solver.c:42-58 comm_free loop + flux) when the binary is there,
     # with the oracle's port of the same algorithm class beside it ----
@@ -546,7 +599,7 @@ def main() -> None:
             cpu_dom.free()
             part = None
     if rank == 0:
-        lap("finest level + cpu baseline", t_phase)
+        lap("cpu baseline" if "finest level" in walls else "finest level + cpu baseline", t_phase)
         walls["total (this process, after imports)"] = round(time.time() - t_start, 2)
         out["wall_s"] = walls
         print(json.dumps(out))

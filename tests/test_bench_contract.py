@@ -33,6 +33,13 @@ def test_bench_line(gpu):
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_dump_raw")):
         assert cb["kind"] == "reference" and cb["port"]["kind"] == "port", cb
     assert out["value"] > 0 and out["ms_per_step"] > 0
+    # the exchange protocol's own cost, measured in loopback on this GPU (an upper bound of the overlap efficiency)
+    lb = out["exchange_protocol_loopback"]
+    for name in ("dualgrid.384", "dualgrid.192"):
+        e = lb[name]
+        assert e["wait_timeouts"] == 0 and 0.5 < e["efficiency_bound"] <= 1.05 and e["protocol"]["notify"] == "per partner", e
+        assert e["us_per_iteration_with_exchange"] >= 0.95 * e["us_per_iteration_comm_free"], e
+    assert "wall_s" in out and out["wall_s"]["exchange protocol in loopback"] < 60
 
 
 def test_bench_configs_name_the_baseline_workloads(pkg):
