@@ -484,6 +484,8 @@ def main() -> None:
         # (cfdp_gpu_ipc_connect_loopback: wrong ghost values, right traffic, right protocol).  comm_free / with_exchange is an
         # UPPER bound of the overlap efficiency a rank with a GPU of its own can reach (DESIGN appendix C.4)
         t_lb = lap("finest level", t_phase)
+        mode0 = os.environ.get("CFDP_IPC_MODE")
+        os.environ.setdefault("CFDP_IPC_MODE", mg.ipc_mode_attempts()[0])  # the memory mode the hosts try first
         try:
             lb = {}
             for name in ("dualgrid.384", "dualgrid.192"):
@@ -528,6 +530,8 @@ def main() -> None:
             out["exchange_protocol_loopback"] = lb
         except Exception as e:  # never costs the line
             out["exchange_protocol_loopback"] = {"error": repr(e)[:300]}
+        if mode0 is None:
+            os.environ.pop("CFDP_IPC_MODE", None)
         t_phase = lap("exchange protocol in loopback", t_lb)
     # ---- CPU baseline on rank 0's host cores, at every N: the COMPILED REFERENCE (oracle/_ref/ref_dump_raw: the
     # reference's own OpenMP path, src/solver.c:42-58 comm_free loop + flux) when the binary is there,
