@@ -89,7 +89,7 @@ hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view
 // xGMI write + notify exchange (see gg_kernels.hip): header words of a rank's IPC block
 enum { GG_ROW_STRIDE = 208 };  // >= 1024 / 5 + 1 rows: every piece index of the 256-thread fused pass
 enum { GG_DONE_STRIDE = 32 };  // the completion counters of push_tile_done sit on cache lines of their own (atomics of hundreds of tiles)
-enum { GG_IPC_MAXSLOTS = 48, GG_IPC_ITER = 48, GG_IPC_ERR = 49, GG_IPC_DONE = 56, GG_IPC_HDR_BYTES = 256 };
+enum { GG_IPC_MAXSLOTS = 48, GG_IPC_ITER = 48, GG_IPC_ERR = 49, GG_IPC_HDR_BYTES = 256 };
 hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row, const int *send_off,
                           const gg_grad_view &grad, double *const *dst, hipStream_t stream);
 hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, hipStream_t stream);
