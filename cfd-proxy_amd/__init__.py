@@ -199,7 +199,8 @@ def _declare_host(lib: C.CDLL) -> None:
 class ScaledCheck(C.Structure):
     """cfdp_scaled_check (cfdproxy_hip.h): the evidence of a scaled-field validation run"""
     _fields_ = [("iterations", C.c_int), ("flux_checks", C.c_int), ("mismatches", C.c_int), ("first_iteration", C.c_int),
-                ("first_point", C.c_int), ("first_component", C.c_int), ("seen", C.c_double), ("expected", C.c_double)]
+                ("first_point", C.c_int), ("first_component", C.c_int), ("seen", C.c_double), ("expected", C.c_double),
+                ("var_mismatches", C.c_int)]
 
 
 def _declare_hip(lib: C.CDLL) -> None:

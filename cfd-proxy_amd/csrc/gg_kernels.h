@@ -102,6 +102,7 @@ enum { GG_V_ITER = 0, GG_V_CHECKS = 1, GG_V_BAD = 2, GG_V_CLAIM = 4, GG_V_FIRST_
 hipError_t gg_launch_validate(double *var, int nall, const double *flux, const double *fref, const unsigned char *skip,
                               int nown, int lag, bool do_scale, int *state, hipStream_t stream);
 hipError_t gg_launch_scale_var(double *var, int nall, double factor, hipStream_t stream);
+hipError_t gg_launch_var_check(const double *var, const double *var0, int nall, double factor, unsigned long long *bad, hipStream_t stream);
 // tile-resident iterations (gg_resident_kernel): K iterations in ONE launch, one workgroup per tile staying for all
 // of them; the iteration boundary is a drained-flag hand-off between neighbouring tiles
 struct gg_resident_args {

@@ -1353,6 +1353,21 @@ hipError_t gg_launch_validate(double *var, int nall, const double *flux, const d
   return hipGetLastError();
 }
 
+// diagnostics of the validation itself: how many elements of var are NOT var0 * f (the mode's own bookkeeping went wrong)
+__global__ __launch_bounds__(256) void gg_var_check_kernel(const double *__restrict__ var, const double *__restrict__ var0, int nvar,
+                                                           double f, unsigned long long *__restrict__ bad) {
+  int n = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nvar; i += gridDim.x * blockDim.x)
+    if ((i & 7) != 7 && !(var[i] == var0[i] * f)) n++;
+  if (n) atomicAdd(bad, (unsigned long long)n);
+}
+hipError_t gg_launch_var_check(const double *var, const double *var0, int nall, double factor, unsigned long long *bad, hipStream_t stream) {
+  int blocks = (nall * 8 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(gg_var_check_kernel, dim3(blocks), dim3(256), 0, stream, var, var0, nall * 8, factor, bad);
+  return hipGetLastError();
+}
+
 hipError_t gg_launch_scale_var(double *var, int nall, double factor, hipStream_t stream) {
   int blocks = (nall * 8 + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);

@@ -85,7 +85,7 @@ static void free_device(cfdp_gpu *g) {
   (void)hipFree(g->d_var); (void)hipFree(g->d_flux);
   (void)hipFree(g->d_nbr_off); (void)hipFree(g->d_nbr); (void)hipFree(g->d_resident_state);
   g->d_nbr_off = g->d_nbr = g->d_resident_state = nullptr;
-  (void)hipFree(g->sc.d_state); (void)hipFree(g->sc.d_fref); (void)hipFree(g->sc.d_skip);
+  (void)hipFree(g->sc.d_state); (void)hipFree(g->sc.d_fref); (void)hipFree(g->sc.d_skip); (void)hipFree(g->sc.d_var0);
   g->sc = cfdp_gpu::scaled_state();
   if (g->own_grad) (void)hipFree(g->d_grad);
   if (g->own_grad_alt) (void)hipFree(g->d_grad_alt);

@@ -153,6 +153,7 @@ struct cfdp_gpu {
     int saved_flux_lanes = 0;
     int *d_state = nullptr;
     double *d_fref = nullptr;
+    double *d_var0 = nullptr;   // var as it was at _begin: _end verifies var == var0 * 2^(iterations mod 3) before it restores it
     unsigned char *d_skip = nullptr;
   } sc;
   std::vector<int> faceless;           // owned points without faces, device numbering

@@ -472,7 +472,7 @@ class RankSolver:
         finally:
             ev = self.gpu.scaled_check_end()
         err = float(self.gpu.ipc_error() != 0) if self.transport == "ipc" else 0.0
-        t = torch.tensor([float(ev["mismatches"]), float(ev["mismatches"] > 0), err], dtype=torch.float64,
+        t = torch.tensor([float(ev["mismatches"]), float(ev["mismatches"] > 0), err, float(ev["var_mismatches"])], dtype=torch.float64,
                          device=self._coll_device())
         dist.all_reduce(t)
         tmin = torch.tensor([float(ev["flux_checks"])], dtype=torch.float64, device=self._coll_device())
@@ -486,9 +486,10 @@ class RankSolver:
         out = {"steps": int(sum(batches)), "flux_fields_compared_per_rank": int(tmin.item()),
                "stale_reads": int(t[0].item()), "ranks_with_stale_reads": int(t[1].item()),
                "wait_timeouts": int(t[2].item()), "first": next((f for f in firsts if f), None),
+               "var_bookkeeping_errors": int(t[3].item()),
                "check": "var scaled by 2, 2, 1/4, ... after every iteration; the flux of every step == reference x 2^e, "
                         "bit for bit, compared on the device",
-               "ok": bool(t[0].item() == 0 and t[2].item() == 0 and tmin.item() >= sum(batches) - 1)}
+               "ok": bool(t[0].item() == 0 and t[2].item() == 0 and t[3].item() == 0 and tmin.item() >= sum(batches) - 1)}
         dist.barrier()
         return out
 

@@ -243,6 +243,8 @@ typedef struct cfdp_scaled_check {
   int first_point;      /* ... its point, file numbering, or -1                                         */
   int first_component;
   double seen, expected;
+  int var_mismatches;   /* elements of var that were not var(begin) * 2^(iterations mod 3) at _end: the mode's own
+                           bookkeeping -- must be 0 for the verdict to mean anything                          */
 } cfdp_scaled_check;
 int  cfdp_gpu_scaled_check_begin(cfdp_gpu *g);
 int  cfdp_gpu_scaled_check_end(cfdp_gpu *g, cfdp_scaled_check *out);

@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--per-device", action="store_true",
                     help="one device per rank (LOCAL_RANK) and the nccl backend: the real multi-GPU set-up")
     ap.add_argument("--soak", type=int, default=0, help="extra iterations before the values are checked")
+    ap.add_argument("--repeat-check", type=int, default=0,
+                    help="development: only the scaled-field check of the fused schedule, this many times; the evidence of the "
+                         "first failure is printed")
     ap.add_argument("--mode-may-be-rejected", action="store_true",
                     help="the memory mode named by CFDP_IPC_MODE may be REJECTED by the set-up validation (a question only "
                          "hardware answers): then print the evidence and exit with code 77 instead of failing")
@@ -116,6 +119,25 @@ def main():
                 print("STALE_READ_EVIDENCE " + json.dumps(ev), flush=True)
             assert not ev["ok"] and ev["stale_reads"] > 0 and ev["first"] is not None, ev
             assert ev["wait_timeouts"] == 0, ev
+            solver.close()
+            print(f"RANK_OK {rank}", flush=True)
+            dist.destroy_process_group()
+            return
+        if args.repeat_check:
+            import json
+            real = mg.RankSolver.validate_exchange
+            mg.RankSolver.validate_exchange = lambda self: True
+            solver = mg.RankSolver(part, rank, world, device, dist, transport=args.transport, tile_points=32, fusion=True)
+            mg.RankSolver.validate_exchange = real
+            bad = 0
+            for i in range(args.repeat_check):
+                ev = solver.stale_read_check(batches=(1, 2, 3, 5, 8, 57))
+                if not ev["ok"]:
+                    bad += 1
+                    if rank == 0:
+                        print(f"CHECK {i} FAILED " + json.dumps(ev), flush=True)
+            if rank == 0:
+                print(f"REPEAT_CHECK {args.repeat_check} runs, {bad} failed", flush=True)
             solver.close()
             print(f"RANK_OK {rank}", flush=True)
             dist.destroy_process_group()
