@@ -696,6 +696,11 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
       done++;
     }
+    // A captured chunk starts and ends with the wait for its last exchange PENDING (its first pass waits in the kernel, or
+    // behind a wait kernel): a chunk captured that way is right whatever the state at replay -- a wait for flags that have
+    // arrived long ago returns at once -- whereas a chunk captured with nothing pending (right behind a sync, which
+    // settles the wait) would skip the wait of its first pass and could not close in the state it started in.
+    if (with_exchange && !g->partner.empty()) I.wait_pending = true;
     // the graph set of this configuration (the arena the ghost rows are read from and the current grad buffer are baked
     // into the kernels' arguments too), or the least recently used one to capture into
     cfdp_gpu::ipc_state::graph_set *S = nullptr;
