@@ -94,6 +94,7 @@ hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row
                           const gg_grad_view &grad, double *const *dst, hipStream_t stream);
 hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, hipStream_t stream);
 hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, hipStream_t stream);
+hipError_t gg_launch_jitter(unsigned *rng, int max_us, hipStream_t stream);  // tests: a pseudo-random idle time in front of a step
 // scaled-field validation of an exchange (gg_validate_kernel): words of its device-side state block (16 ints, 8-byte
 // aligned): gradient launches so far, flux fields compared, mismatching values (64 bit), first mismatch (claimed,
 // iteration, seen, expected, index into flux[nown][3]), the ticket of the last-block election

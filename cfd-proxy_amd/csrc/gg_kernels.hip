@@ -1375,6 +1375,22 @@ hipError_t gg_launch_scale_var(double *var, int nall, double factor, hipStream_t
   return hipGetLastError();
 }
 
+// TESTS ONLY (CFDP_IPC_JITTER_US): one thread idles for a pseudo-random time in [0, max_us) in front of a step.  The
+// generator's state lives on the device, so every replay of a hipGraph draws new delays: ranks drift against each other
+// step by step, and a hole in the exchange protocol that runs in lockstep never hit shows up in the scaled-field check.
+__global__ void gg_jitter_kernel(unsigned *__restrict__ rng, int max_us) {
+  unsigned x = *rng;
+  x ^= x << 13; x ^= x >> 17; x ^= x << 5;  // xorshift32
+  *rng = x;
+  const long long ticks = (long long)(x % (unsigned)(max_us > 0 ? max_us : 1)) * 100;  // s_memrealtime: 100 MHz
+  const unsigned long long start = __builtin_amdgcn_s_memrealtime();
+  while ((long long)(__builtin_amdgcn_s_memrealtime() - start) < ticks) __builtin_amdgcn_s_sleep(16);
+}
+hipError_t gg_launch_jitter(unsigned *rng, int max_us, hipStream_t stream) {
+  hipLaunchKernelGGL(gg_jitter_kernel, dim3(1), dim3(1), 0, stream, rng, max_us);
+  return hipGetLastError();
+}
+
 hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row, const int *send_off,
                           const gg_grad_view &grad, double *const *dst, hipStream_t stream) {
   if (nsend <= 0) return hipSuccess;

@@ -114,6 +114,10 @@ struct cfdp_gpu {
     // the previous exchange -- they read whatever the landing arena holds.  Exists so that a test can show that the
     // scaled-field validation sees a ghost row read one exchange early, and that a comparison of final states does not
     bool fault_skip_wait = false;
+    // TESTS ONLY (CFDP_IPC_JITTER_US=M): a pseudo-random idle time of up to M microseconds in front of every step, drawn on
+    // the device (new delays at every hipGraph replay): ranks drift against each other step by step
+    int jitter_us = 0;
+    unsigned *d_rng = nullptr;
     // hipGraphs of cfdp_gpu_run_steps_ipc, one set per configuration: a captured chunk has the schedule, the flux mode, the
     // arena parity AND the current grad buffer baked into its kernels' arguments.  Runs of different schedules alternate
     // (a benchmark times with exchange / without / bulk in turn) and an odd number of passes flips the grad buffers, so

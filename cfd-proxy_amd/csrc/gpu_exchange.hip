@@ -4,6 +4,7 @@
 #include "gpu_ctx.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 extern "C" {
 
@@ -257,7 +258,8 @@ extern "C++" void cfdp_detail::ipc_release(cfdp_gpu *g) {
   (void)hipFree(I.d_rflag); I.d_rflag = nullptr; I.rflag.clear();
   (void)hipFree(I.d_slot_of_row); (void)hipFree(I.d_send_off);
   (void)hipFree(I.d_tile_off); (void)hipFree(I.d_ent); (void)hipFree(I.d_ent_row);
-  (void)hipFree(I.d_pt_first); (void)hipFree(I.d_tile_xoff);
+  (void)hipFree(I.d_pt_first); (void)hipFree(I.d_tile_xoff); (void)hipFree(I.d_rng);
+  I.d_rng = nullptr; I.jitter_us = 0;
   I.d_pt_first = nullptr; I.d_tile_xoff = nullptr;
   I.d_slot_of_row = I.d_send_off = I.d_tile_off = I.d_ent = I.d_ent_row = nullptr;
   I.inkernel = false;
@@ -271,6 +273,10 @@ extern "C++" void cfdp_detail::ipc_release(cfdp_gpu *g) {
 namespace {
 int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   const bool comm = with_exchange && !g->partner.empty();
+  if (g->ipc.jitter_us > 0 && g->ipc.d_rng) {
+    g->main_marked = false;
+    HIP_TRY(gg_launch_jitter(g->ipc.d_rng, g->ipc.jitter_us, g->s_main));
+  }
   g->pending_exchange = false;
   g->iter++;
   const bool fused = g->will_fuse();
@@ -582,6 +588,15 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       HIP_TRY(hipMalloc(&I.d_tile_mask, sizeof(unsigned long long) * (smask.size() + 1)));
       if (!smask.empty())
         HIP_TRY(hipMemcpy(I.d_tile_mask, smask.data(), sizeof(unsigned long long) * smask.size(), hipMemcpyHostToDevice));
+      if (const char *j = getenv("CFDP_IPC_JITTER_US")) {
+        I.jitter_us = atoi(j) > 0 ? atoi(j) : 0;
+        if (I.jitter_us) {
+          const unsigned seed = 2463534242u ^ (unsigned)(uintptr_t)g ^ (unsigned)getpid() * 2654435761u;
+          HIP_TRY(hipMalloc(&I.d_rng, sizeof(unsigned)));
+          HIP_TRY(hipMemcpy(I.d_rng, &seed, sizeof seed, hipMemcpyHostToDevice));
+          fprintf(stderr, "[cfdp] TEST MODE: up to %d us of random idle time in front of every step (CFDP_IPC_JITTER_US)\n", I.jitter_us);
+        }
+      }
       const char *f = getenv("CFDP_IPC_FAULT");
       I.fault_skip_wait = f && !strcmp(f, "skip_wait");
       if (I.fault_skip_wait) fprintf(stderr, "[cfdp] FAULT INJECTION: boundary tiles do not wait for the previous exchange (CFDP_IPC_FAULT)\n");

@@ -81,6 +81,17 @@ def test_multirank_xgmi_write_notify_between_processes_on_one_gpu(gpu):
 
 
 @pytest.mark.gpu
+def test_multirank_xgmi_write_notify_under_random_skew(gpu):
+    """the same checks while every rank idles for a pseudo-random time (up to 40 us: several passes of these meshes) in
+    front of every step -- drawn on the device, so every hipGraph replay draws new delays (CFDP_IPC_JITTER_US): the ranks
+    drift against each other step by step, and a hole in the wait / notify / double-buffer protocol that lockstep runs never
+    hit would show up in the scaled-field soak (400 steps) and in the value checks of every schedule"""
+    env = {"CFDP_IPC_WAIT_INKERNEL": "1", "CFDP_IPC_JITTER_US": "40"}
+    _launch(3, ["--gpu", "--transport", "ipc", "--files", "--soak", "400"], extra_env=env)
+    _launch(4, ["--gpu", "--transport", "ipc", "--dims", "16,16,12", "--ndomains", "8", "--soak", "400"], extra_env=env)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"CFDP_IPC_MODE": "split"}, {"CFDP_IPC_MODE": "fine"}, {"CFDP_IPC_PER_PARTNER": "0"},
                                  {"CFDP_IPC_WAIT_INKERNEL": "0"}, {"CFDP_IPC_INKERNEL": "0"}])
 def test_multirank_xgmi_write_notify_other_rungs(gpu, env):
