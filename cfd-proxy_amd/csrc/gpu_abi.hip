@@ -173,7 +173,7 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   g->own_grad = g->own_sendbuf = true;
   HIP_TRY(hipMemcpy(g->d_tiles, p->tiles, sizeof(cfdp_tile_desc) * (size_t)p->ntiles, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(g->d_blob, p->blob, (size_t)p->blob_bytes, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(g->d_halo, 0, sizeof(int) * (size_t)(p->nhalo_total + 1)));
+  HIP_TRY(cfdp_memset_sync(g->d_halo, 0, sizeof(int) * (size_t)(p->nhalo_total + 1)));
   if (p->nhalo_total)
     HIP_TRY(hipMemcpy(g->d_halo, p->halo_idx, sizeof(int) * (size_t)p->nhalo_total, hipMemcpyHostToDevice));
   {  // row lists at a fixed stride, when every tile fits one (the 256-thread fused pass: <= 204 rows)
@@ -233,9 +233,9 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
     if (p->degree[i] == 0) g->faceless.push_back(i);
   if (nsend)
     HIP_TRY(hipMemcpy(g->d_sendidx, p->send_idx, sizeof(int) * nsend, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(g->d_var, 0, sizeof(double) * 8 * (size_t)p->nall));
-  HIP_TRY(hipMemset(g->d_grad, 0, sizeof(double) * 21 * (size_t)p->nall));
-  HIP_TRY(hipMemset(g->d_flux, 0, sizeof(double) * 3 * (size_t)p->nown));
+  HIP_TRY(cfdp_memset_sync(g->d_var, 0, sizeof(double) * 8 * (size_t)p->nall));
+  HIP_TRY(cfdp_memset_sync(g->d_grad, 0, sizeof(double) * 21 * (size_t)p->nall));
+  HIP_TRY(cfdp_memset_sync(g->d_flux, 0, sizeof(double) * 3 * (size_t)p->nown));
   g->uploaded = true;
   if (g->fusion) return cfdp_gpu_set_fusion(g, 1);
   return 0;
@@ -247,7 +247,7 @@ int cfdp_gpu_bind_grad(cfdp_gpu *g, void *dev_grad) {
   if (!dev_grad) return fail("null device pointer");
   if ((uintptr_t)dev_grad & 15) return fail("grad buffer must be 16-byte aligned");
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(dev_grad, g->d_grad, sizeof(double) * 21 * (size_t)g->nall, hipMemcpyDeviceToDevice));
+  HIP_TRY(cfdp_copy_d2d_sync(dev_grad, g->d_grad, sizeof(double) * 21 * (size_t)g->nall));
   if (g->own_grad) (void)hipFree(g->d_grad);
   g->d_grad = static_cast<double *>(dev_grad);
   g->own_grad = false;
@@ -315,7 +315,7 @@ int cfdp_gpu_set_fusion(cfdp_gpu *g, int on) {
   if (!g->d_grad_alt) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMalloc(&g->d_grad_alt, sizeof(double) * 21 * (size_t)g->nall));
-    HIP_TRY(hipMemcpy(g->d_grad_alt, g->d_grad, sizeof(double) * 21 * (size_t)g->nall, hipMemcpyDeviceToDevice));
+    HIP_TRY(cfdp_copy_d2d_sync(g->d_grad_alt, g->d_grad, sizeof(double) * 21 * (size_t)g->nall));
     g->own_grad_alt = true;
   }
   g->fusion = 1;
@@ -328,8 +328,7 @@ int cfdp_gpu_bind_grad_alt(cfdp_gpu *g, void *dev_grad) {
   if (!dev_grad) return fail("null device pointer");
   if ((uintptr_t)dev_grad & 15) return fail("grad buffer must be 16-byte aligned");
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(dev_grad, g->d_grad_alt ? g->d_grad_alt : g->d_grad, sizeof(double) * 21 * (size_t)g->nall,
-                    hipMemcpyDeviceToDevice));
+  HIP_TRY(cfdp_copy_d2d_sync(dev_grad, g->d_grad_alt ? g->d_grad_alt : g->d_grad, sizeof(double) * 21 * (size_t)g->nall));
   if (g->d_grad_alt && g->own_grad_alt) (void)hipFree(g->d_grad_alt);
   g->d_grad_alt = static_cast<double *>(dev_grad);
   g->own_grad_alt = false;
@@ -1168,7 +1167,7 @@ int cfdp_gpu_debug_phase_stamps(cfdp_gpu *g, int passes, unsigned long long *sta
   unsigned long long *d = nullptr;
   const size_t n = (size_t)g->ntiles * 24;  // 8 per tile, then 4 x 4 per wave
   HIP_TRY(hipMalloc(&d, n * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(d, 0, n * sizeof(unsigned long long)));
+  HIP_TRY(cfdp_memset_sync(d, 0, n * sizeof(unsigned long long)));
   HIP_TRY(gg_set_stamp_buffer(d));
   if (launch_grad(g, CFDP_TILES_ALL, g->s_main)) return 1;
   const int saved = gg_debug_flags;

@@ -29,6 +29,19 @@ using cfdp_detail::fail;
       return fail("%s failed: %s [%s:%d]", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// hipMemset and device-to-device hipMemcpy run on the null stream and return BEFORE the bytes are there; the context's
+// streams are non-blocking (no implicit order with the null stream), so work enqueued on them right afterwards may run
+// first -- and a late memset / copy then lands on top of live data.  (Found as a once-in-dozens failure on a fresh box,
+// where the first use of the copy engine is slow: DESIGN appendix C.5.)  These forms wait.
+static inline hipError_t cfdp_memset_sync(void *p, int v, size_t n) {
+  const hipError_t e = hipMemset(p, v, n);
+  return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+static inline hipError_t cfdp_copy_d2d_sync(void *dst, const void *src, size_t n) {
+  const hipError_t e = hipMemcpy(dst, src, n, hipMemcpyDeviceToDevice);
+  return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+
 #define NEED_UPLOAD(g)                                                 \
   do {                                                                 \
     if (!(g) || !(g)->uploaded) return fail("no plan uploaded");       \

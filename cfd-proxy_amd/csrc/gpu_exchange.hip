@@ -31,9 +31,9 @@ int cfdp_gpu_scaled_check_begin(cfdp_gpu *g) {
     HIP_TRY(hipMalloc(&g->sc.d_skip, skip.size()));
     HIP_TRY(hipMemcpy(g->sc.d_skip, skip.data(), skip.size(), hipMemcpyHostToDevice));
   }
-  HIP_TRY(hipMemset(g->sc.d_state, 0, GG_V_WORDS * sizeof(int)));
+  HIP_TRY(cfdp_memset_sync(g->sc.d_state, 0, GG_V_WORDS * sizeof(int)));
   if (!g->sc.d_var0) HIP_TRY(hipMalloc(&g->sc.d_var0, sizeof(double) * 8 * (size_t)g->nall));
-  HIP_TRY(hipMemcpy(g->sc.d_var0, g->d_var, sizeof(double) * 8 * (size_t)g->nall, hipMemcpyDeviceToDevice));
+  HIP_TRY(cfdp_copy_d2d_sync(g->sc.d_var0, g->d_var, sizeof(double) * 8 * (size_t)g->nall));
   // bit for bit: the reference must come from the kernel form the steps will use.  The flux phase of the fused pass
   // sums a point's faces on 4 lanes, the separate flux kernel by default on 8 (another association): with fused
   // iterations on, the separate kernel -- reference now, last iteration's deferred flux later -- runs on 4 as well
@@ -41,7 +41,7 @@ int cfdp_gpu_scaled_check_begin(cfdp_gpu *g) {
   if (g->fusion && g->d_grad_alt) g->flux_lanes = 4;
   if (launch_flux(g, g->last_flux_mode, g->s_main)) return 1;
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(g->sc.d_fref, g->d_flux, nf * sizeof(double), hipMemcpyDeviceToDevice));
+  HIP_TRY(cfdp_copy_d2d_sync(g->sc.d_fref, g->d_flux, nf * sizeof(double)));
   g->sc.on = true;
   g->drop_graphs();  // graphs captured without the validation kernel
   drop_ipc_graphs(g);
@@ -65,13 +65,13 @@ int cfdp_gpu_scaled_check_end(cfdp_gpu *g, cfdp_scaled_check *out) {
   unsigned long long var_bad = 0;
   {
     unsigned long long *d_bad = reinterpret_cast<unsigned long long *>(g->sc.d_state + 12);  // (words 12..13 of the state block)
-    HIP_TRY(hipMemset(d_bad, 0, sizeof(unsigned long long)));
+    HIP_TRY(cfdp_memset_sync(d_bad, 0, sizeof(unsigned long long)));
     HIP_TRY(gg_launch_var_check(g->d_var, g->sc.d_var0, g->nall, m == 0 ? 1.0 : (m == 1 ? 2.0 : 4.0), d_bad, g->s_main));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(&var_bad, d_bad, sizeof var_bad, hipMemcpyDeviceToHost));
   }
   // restore exactly (from the copy: also right if the bookkeeping slipped)
-  HIP_TRY(hipMemcpy(g->d_var, g->sc.d_var0, sizeof(double) * 8 * (size_t)g->nall, hipMemcpyDeviceToDevice));
+  HIP_TRY(cfdp_copy_d2d_sync(g->d_var, g->sc.d_var0, sizeof(double) * 8 * (size_t)g->nall));
   if (out) {
     unsigned long long bad = 0;
     memcpy(&bad, &st[GG_V_BAD], sizeof bad);
@@ -407,10 +407,10 @@ int cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes) {
   I.mode = ipc_mode_from_env();
   if (I.mode == 1) HIP_TRY(hipExtMallocWithFlags((void **)&I.block, bytes, hipDeviceMallocFinegrained));
   else HIP_TRY(hipMalloc(&I.block, bytes));
-  HIP_TRY(hipMemset(I.block, 0, bytes));
+  HIP_TRY(cfdp_memset_sync(I.block, 0, bytes));
   if (I.mode == 2) {  // the flag words alone in fine-grained memory (the header of `block` stays unused)
     HIP_TRY(hipExtMallocWithFlags((void **)&I.flags, 64 * 1024, hipDeviceMallocFinegrained));
-    HIP_TRY(hipMemset(I.flags, 0, 64 * 1024));
+    HIP_TRY(cfdp_memset_sync(I.flags, 0, 64 * 1024));
   }
   hipIpcMemHandle_t h;
   HIP_TRY(hipIpcGetMemHandle(&h, I.block));
@@ -603,14 +603,13 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
     }
   }
   HIP_TRY(hipMalloc(&I.d_done, sizeof(int) * (GG_IPC_MAXSLOTS + 1) * GG_DONE_STRIDE));
-  HIP_TRY(hipMemset(I.d_done, 0, sizeof(int) * (GG_IPC_MAXSLOTS + 1) * GG_DONE_STRIDE));
+  HIP_TRY(cfdp_memset_sync(I.d_done, 0, sizeof(int) * (GG_IPC_MAXSLOTS + 1) * GG_DONE_STRIDE));
   if (flush_flux(g)) return 1;
   HIP_TRY(hipDeviceSynchronize());
   // the ghost rows move into the landing arenas
   if (g->nall > g->nown)
     for (int par = 0; par < 2; par++)
-      HIP_TRY(hipMemcpy(g->land(par), g->d_grad + (size_t)g->nown * 10, sizeof(double) * 21 * (size_t)(g->nall - g->nown),
-                        hipMemcpyDeviceToDevice));
+      HIP_TRY(cfdp_copy_d2d_sync(g->land(par), g->d_grad + (size_t)g->nown * 10, sizeof(double) * 21 * (size_t)(g->nall - g->nown)));
   I.xiter = 0;
   I.on = true;
   g->drop_graphs();
