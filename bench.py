@@ -48,6 +48,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 UNIT_POINTS = 262144   # one level-2 mesh (64^3 stand-in of dualgrid.* lvl 2)
+# seconds of the same iterations run (untimed) right in front of every timed region, see condition(); 0 = none
+CONDITION_S = float(os.environ.get("CFDP_BENCH_CONDITION_S", "0.25"))
 
 
 def usable_cores() -> int:
@@ -263,7 +265,33 @@ def main() -> None:
                 dist.barrier()
             solver.synchronize()
 
-        def timed(steps: int, **kw) -> float:
+        cond = {"steps": 0}
+
+        def condition(**kw) -> None:
+            """CONDITION_S seconds of the same iterations right in front of a timed region (untimed, like the warm-up):
+            the chip reaches the clock it sustains only after ~0.2 s of continuous load, and a 20-step region behind 5
+            warm-up steps runs 8 % below it (tools/clock_ramp_probe.py: 39.8 us/step after 5 steps, 38.3 after 500,
+            36.4 after 5000, 35.6 in a long run) -- a solver runs in the sustained state.  Every rank runs the same
+            count (whole 50-pass graphs: the graph of the timed run stays instantiated)."""
+            if CONDITION_S <= 0:
+                return
+            run = ((lambda n: solver.gpu.run_iterations(n + 1, with_flux=True, use_graph=True)) if world == 1
+                   else (lambda n: solver.run_steps(n, **kw)))
+            if not cond["steps"]:
+                run(100)
+                solver.synchronize()
+                t = time.perf_counter()
+                run(200)
+                solver.synchronize()
+                dt200 = time.perf_counter() - t
+                if dist is not None:
+                    tt = torch.tensor([dt200], dtype=torch.float64, device=coll_device)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+                    dt200 = float(tt.item())
+                cond["steps"] = 50 * max(2, min(2000, int(np.ceil(CONDITION_S / max(dt200, 1e-6) * 4))))
+            run(cond["steps"])
+
+        def timed(steps: int, conditioned: bool = True, **kw) -> float:
             """seconds for exactly `steps` steps, max over ranks.  The hipGraphs the run replays are
             built before the timed region: captured without executing (one partition), or by one untimed
             rehearsal of the same schedule (several ranks: a capture there includes the exchange kernels)"""
@@ -271,6 +299,11 @@ def main() -> None:
                 solver.gpu.prepare_iterations(steps, with_flux=True)
             else:
                 solver.run_steps(steps if steps <= 5000 else 100 + steps % 50, **kw)
+            if conditioned:
+                condition(**kw)
+                # ... and every graph instantiated again: an executable graph that other work has gone through the
+                # device behind starts 60-100 us late on an idle device (tools/clock_ramp_probe.py)
+                solver.gpu.refresh_graphs()
             barrier()
             t = time.perf_counter()
             if world == 1:
@@ -300,6 +333,7 @@ def main() -> None:
                 solver.gpu.run_iterations(max(args.warmup, 1), with_flux=True, use_graph=True)
             else:
                 solver.run_steps(max(args.warmup, 1), with_exchange=True, overlap=True)
+            dt_cold = timed(args.steps, conditioned=False, with_exchange=True, overlap=True)
             dt = timed(args.steps, with_exchange=True, overlap=True)
             if world == 1:
                 break
@@ -316,6 +350,10 @@ def main() -> None:
         mesh_points = dims[0] * dims[1] * dims[2]
         res = {
             "value": its * mesh_points / UNIT_POINTS, "ms_per_step": dt / args.steps * 1e3, "scaling": cfg["scaling"],
+            # the same K steps timed the same way straight behind the W warm-up steps (chip below its sustained clock)
+            "clock_conditioning": {"seconds": CONDITION_S, "steps": cond["steps"],
+                                   "unconditioned_ms_per_step": dt_cold / args.steps * 1e3,
+                                   "unconditioned_value": args.steps / dt_cold * mesh_points / UNIT_POINTS},
             "config": {
                 "workload": cfg["workload"], "baseline_config": cfg["name"],
                 "mesh_points": mesh_points, "domains": ndom, "domains_per_gpu": ndom // world,
@@ -367,7 +405,7 @@ def main() -> None:
     }
     if role != world:
         out["config"]["rehearsal"] = f"{world} ranks standing in for the {role}-GPU line (CFDP_BENCH_AS_GPUS)"
-    for k in ("exchange_check", "overlap"):
+    for k in ("clock_conditioning", "exchange_check", "overlap"):
         if k in res:
             out[k] = res[k]
 
@@ -428,7 +466,7 @@ def main() -> None:
             solver = part = None
         try:
             xres, _, _ = measure(mg.bench_config(extra[1], world))
-            out[extra[0]] = {k: xres[k] for k in ("value", "ms_per_step", "scaling", "config", "exchange_check", "overlap")
+            out[extra[0]] = {k: xres[k] for k in ("value", "ms_per_step", "scaling", "config", "clock_conditioning", "exchange_check", "overlap")
                              if k in xres}
         except Exception as e:  # the extra must never cost the line
             out[extra[0]] = {"error": repr(e)[:300]}

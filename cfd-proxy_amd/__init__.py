@@ -252,6 +252,7 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_time_kernels.argtypes = [vp, C.c_int, C.c_int, P(C.c_float), P(C.c_float)]
     lib.cfdp_gpu_run_iterations.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, P(C.c_float)]
     lib.cfdp_gpu_prepare_iterations.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.cfdp_gpu_refresh_graphs.argtypes = [vp]
     lib.cfdp_gpu_scaled_check_begin.argtypes = [vp]
     lib.cfdp_gpu_scaled_check_end.argtypes = [vp, P(ScaledCheck)]
     lib.cfdp_rccl_load.argtypes = [C.c_char_p]
@@ -860,6 +861,10 @@ class GpuPartition:
     def prepare_iterations(self, iters: int, with_flux: bool = True, flux_mode: int = FLUX_CONSISTENT) -> None:
         """capture the hipGraphs run_iterations(iters) replays, without executing anything"""
         self._ck(self.lib.cfdp_gpu_prepare_iterations(self.h, iters, int(with_flux), flux_mode))
+
+    def refresh_graphs(self) -> None:
+        """instantiate every cached hipGraph again (in front of a short timed run on an idle device): cfdp_gpu_refresh_graphs"""
+        self._ck(self.lib.cfdp_gpu_refresh_graphs(self.h))
 
     def scaled_check_begin(self) -> None:
         """the flux held now becomes the reference; from here every step ends with the validation kernel (compare the

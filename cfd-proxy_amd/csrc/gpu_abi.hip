@@ -1079,8 +1079,10 @@ static int run_or_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int 
   // starts by recomputing every gradient and may end in either buffer (graph_whole_final says which)
   auto capture = [&](hipGraphExec_t &slot, int &slot_n, int n) -> int {  // 0 ok, 1 error
     const double *&slot_cur = g->graph_cur_slot[&slot == &g->graph ? 0 : 1];
+    hipGraph_t &tmpl = &slot == &g->graph ? g->graph_tmpl : g->graph_rem_tmpl;
     if (slot && slot_n == n && (n < 0 || slot_cur == g->d_grad)) return 0;
     if (slot) { (void)hipGraphExecDestroy(slot); slot = nullptr; }
+    if (tmpl) { (void)hipGraphDestroy(tmpl); tmpl = nullptr; }
     slot_n = 0;
     hipGraph_t gr = nullptr;
     const double *cur0 = g->d_grad;
@@ -1097,8 +1099,12 @@ static int run_or_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int 
     if (rc) { if (gr) (void)hipGraphDestroy(gr); return 1; }
     HIP_TRY(ec);
     if (swapped && n > 0) { (void)hipGraphDestroy(gr); return fail("graph chunk must leave the grad buffers in place"); }
-    HIP_TRY(hipGraphInstantiate(&slot, gr, nullptr, nullptr, 0));
-    HIP_TRY(hipGraphDestroy(gr));
+    if (hipGraphInstantiate(&slot, gr, nullptr, nullptr, 0) != hipSuccess) {
+      slot = nullptr;
+      (void)hipGraphDestroy(gr);
+      return fail("hipGraphInstantiate failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    tmpl = gr;  // kept: cfdp_gpu_refresh_graphs instantiates from it again
     slot_n = n;
     if (n < 0) g->graph_whole_final = swapped ? g->d_grad_alt : g->d_grad;
     g->graph_flux = with_flux; g->graph_mode = flux_mode;
@@ -1154,6 +1160,30 @@ int cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode
 int cfdp_gpu_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode) {
   NEED_UPLOAD(g);
   return run_or_prepare_iterations(g, iters, with_flux, flux_mode, 1, false, nullptr);
+}
+
+int cfdp_gpu_refresh_graphs(cfdp_gpu *g) {
+  NEED_UPLOAD(g);
+  HIP_TRY(hipDeviceSynchronize());  // none of them may be replaying
+  int lost = 0;
+  auto again = [&](hipGraphExec_t &exec, hipGraph_t tmpl, int &n) {
+    if (!exec || !tmpl) return;
+    (void)hipGraphExecDestroy(exec);
+    exec = nullptr;
+    if (hipGraphInstantiate(&exec, tmpl, nullptr, nullptr, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      exec = nullptr;
+      n = 0;  // the next run captures it anew
+      lost++;
+    }
+  };
+  again(g->graph, g->graph_tmpl, g->graph_iters);
+  again(g->graph_rem, g->graph_rem_tmpl, g->graph_rem_iters);
+  for (auto &x : g->ipc.gs) {
+    again(x.graph, x.tmpl, x.graph_n);
+    again(x.graph_rem, x.tmpl_rem, x.graph_rem_n);
+  }
+  return lost ? fail("%d graph(s) could not be instantiated again (they will be captured anew)", lost) : 0;
 }
 
 // diagnostics (tools/phase_stamps.py): run `passes` fused passes with phase stamping on and return, per tile, 8

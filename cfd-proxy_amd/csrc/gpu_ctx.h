@@ -137,6 +137,7 @@ struct cfdp_gpu {
     // several sets stay cached -- a set that had to be re-captured inside a timed region would be timed with its capture
     struct graph_set {
       hipGraphExec_t graph = nullptr, graph_rem = nullptr;  // main chunk of 50 steps; what is left after whole chunks
+      hipGraph_t tmpl = nullptr, tmpl_rem = nullptr;        // what they were instantiated from (cfdp_refresh_exec)
       int graph_n = 0, graph_rem_n = 0;
       int exch = -1, overlap = -1, flux = -1, mode = -1, xpar = -1, scaled = -1;
       const double *cur = nullptr;
@@ -150,6 +151,8 @@ struct cfdp_gpu {
       for (auto &x : gs) {
         if (x.graph) (void)hipGraphExecDestroy(x.graph);
         if (x.graph_rem) (void)hipGraphExecDestroy(x.graph_rem);
+        if (x.tmpl) (void)hipGraphDestroy(x.tmpl);
+        if (x.tmpl_rem) (void)hipGraphDestroy(x.tmpl_rem);
         x = graph_set();
       }
     }
@@ -192,6 +195,7 @@ struct cfdp_gpu {
   // hipGraphs of cfdp_gpu_run_iterations: [0] the main chunk (50 fused passes / 25 iterations), [1] what
   // is left of a run after whole chunks -- so that ANY iteration count is replayed, not stream-launched
   hipGraphExec_t graph = nullptr, graph_rem = nullptr;
+  hipGraph_t graph_tmpl = nullptr, graph_rem_tmpl = nullptr;  // what they were instantiated from (cfdp_refresh_exec)
   int graph_iters = 0, graph_rem_iters = 0, graph_flux = -1, graph_mode = -1, graph_gl = 0, graph_fl = 0, graph_fuse = -1;
   const double *graph_cur = nullptr;  // d_grad at the last capture: the graphs' pointers are baked in
   const double *graph_cur_slot[2] = {nullptr, nullptr};  // ... per slot ([0] graph, [1] graph_rem)
@@ -200,6 +204,8 @@ struct cfdp_gpu {
     ipc.drop_graph_sets();
     if (graph) { (void)hipGraphExecDestroy(graph); graph = nullptr; }
     if (graph_rem) { (void)hipGraphExecDestroy(graph_rem); graph_rem = nullptr; }
+    if (graph_tmpl) { (void)hipGraphDestroy(graph_tmpl); graph_tmpl = nullptr; }
+    if (graph_rem_tmpl) { (void)hipGraphDestroy(graph_rem_tmpl); graph_rem_tmpl = nullptr; }
     graph_iters = graph_rem_iters = 0;
   }
 

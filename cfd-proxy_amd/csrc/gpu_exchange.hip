@@ -729,18 +729,22 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       if (S->graph || S->graph_rem) HIP_TRY(hipStreamSynchronize(g->s_main));  // (it may still be replaying)
       if (S->graph) (void)hipGraphExecDestroy(S->graph);
       if (S->graph_rem) (void)hipGraphExecDestroy(S->graph_rem);
+      if (S->tmpl) (void)hipGraphDestroy(S->tmpl);
+      if (S->tmpl_rem) (void)hipGraphDestroy(S->tmpl_rem);
       *S = cfdp_gpu::ipc_state::graph_set();
       S->exch = with_exchange; S->overlap = overlap; S->flux = with_flux; S->mode = flux_mode; S->cur = g->d_grad;
       S->xpar = (int)(I.xiter & 1); S->scaled = (int)g->sc.on;
     }
     S->used = ++I.gs_clock;
     auto capture = [&](hipGraphExec_t &slot, int &slot_n, int n) -> bool {  // false: run from the streams instead
+      hipGraph_t &tmpl = &slot == &S->graph ? S->tmpl : S->tmpl_rem;
       if (slot && slot_n == n) return true;
       if (slot) {  // another length wanted: the old one may still be replaying
         (void)hipStreamSynchronize(g->s_main);
         (void)hipGraphExecDestroy(slot);
         slot = nullptr;
       }
+      if (tmpl) { (void)hipGraphDestroy(tmpl); tmpl = nullptr; }
       slot_n = 0;
       const double *cur0 = g->d_grad;
       const int pend0 = g->flux_pending;
@@ -758,7 +762,8 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       (void)mark_main(g);
       const bool ok = !rc && ec == hipSuccess && gr && g->d_grad == cur0 && g->flux_pending == pend0 && I.wait_pending == wait0;
       if (ok && hipGraphInstantiate(&slot, gr, nullptr, nullptr, 0) != hipSuccess) slot = nullptr;
-      if (gr) (void)hipGraphDestroy(gr);
+      if (ok && slot) tmpl = gr;  // kept: cfdp_gpu_refresh_graphs instantiates from it again
+      else if (gr) (void)hipGraphDestroy(gr);
       g->iter = iter0;
       I.xiter = x0;  // nothing of the capture has run
       g->fused_passes = passes0;

@@ -283,6 +283,11 @@ int  cfdp_gpu_resident_qualifies(cfdp_gpu *g, const char **why);
 /* capture + instantiate the graphs cfdp_gpu_run_iterations(g, iters, ...) will replay; nothing
  * executes (keeps the capture out of a caller's timed region)                                  */
 int  cfdp_gpu_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode);
+/* instantiate every cached graph (those of cfdp_gpu_run_iterations and of cfdp_gpu_run_steps_ipc) again from the graph
+ * it was captured as; syncs the device first.  For a caller that times a SHORT run on an idle device: an executable
+ * graph instantiated before other work went through the device starts 60-100 us later than one instantiated just before
+ * its launch (measured); replays queued behind running work do not see that.  ~50 us per graph.  */
+int  cfdp_gpu_refresh_graphs(cfdp_gpu *g);
 
 /* multigrid "3V cycle" (documentation/CFD-Proxy.pdf p.3; levels = the -lvl files of
  * src/hybrid.f6.c:38-47, no transfer operators in the reference): `sweeps` iterations

@@ -169,6 +169,7 @@ def main():
                 assert ev["ok"] and ev["stale_reads"] == 0 and ev["flux_fields_compared_per_rank"] >= 75, (rank, fusion, overlap, ev)
                 if args.transport == "ipc":  # batches: lead-in steps + hipGraph replays of 50 + remainder
                     solver.run_steps(107, with_exchange=True, overlap=overlap)
+                    solver.gpu.refresh_graphs()  # the cached graph sets instantiated again (bench.py does, in front of a timed run)
                     solver.run_steps(52, with_exchange=True, overlap=overlap)
                     solver.run_steps(3, with_exchange=False, overlap=overlap)
                     assert solver.gpu.ipc_error() == 0

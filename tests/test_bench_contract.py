@@ -33,6 +33,9 @@ def test_bench_line(gpu):
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_dump_raw")):
         assert cb["kind"] == "reference" and cb["port"]["kind"] == "port", cb
     assert out["value"] > 0 and out["ms_per_step"] > 0
+    # the timed region sits behind ~0.25 s of the same iterations (sustained clock); the figure without is reported beside it
+    cc = out["clock_conditioning"]
+    assert cc["seconds"] > 0 and cc["steps"] >= 100 and cc["steps"] % 50 == 0 and cc["unconditioned_ms_per_step"] > 0, cc
     # the exchange protocol's own cost, measured in loopback on this GPU (an upper bound of the overlap efficiency)
     lb = out["exchange_protocol_loopback"]
     for name in ("dualgrid.384", "dualgrid.192"):
@@ -100,6 +103,7 @@ def _bench_two_ranks(transport, extra_env=None, expect=None, weak=False):
     assert out["config"]["transport"] == (expect or ("ipc" if transport == "auto" else transport))
     assert out["config"]["fused_iterations"]
     assert "cpu_baseline" not in out  # (--no-cpu here; the self-launched run below carries it)
+    assert out["clock_conditioning"]["steps"] % 50 == 0 and out["clock_conditioning"]["unconditioned_ms_per_step"] > 0
     return out
 
 
