@@ -79,10 +79,7 @@ hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_be
 hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refmode, int tile_begin,
                            int ntiles, int tile_points, int max_halo, int max_blob_qw, bool nt,
                            bool allow_split, hipStream_t stream, const gg_push_args *push = nullptr,
-                           bool reverse = false, int *persist_ctr = nullptr);
-// persist_ctr (GG_PERSIST_CTR_INTS ints, zero before the first launch, one launch at a time): the phase-split form runs with
-// workgroups that stay and prefetch their next tile into registers (gg_fused_persist_kernel) when no exchange rides in the pass
-enum { GG_PERSIST_CTR_INTS = 9 * 32 };
+                           bool reverse = false);
 // would gg_launch_fused run a fused kernel (not hipErrorNotSupported) for these tile sizes?
 bool gg_fused_fits(int tile_points, int max_halo, int max_blob_qw);
 hipError_t gg_launch_pack(const int *send_idx, int nsend, const gg_grad_view &grad, double *sendbuf,

@@ -227,14 +227,7 @@ __device__ __forceinline__ void push_from_registers(double *row, int eq0, const 
 // the rows (1.0 except in the staleness test of the tile-resident kernel).
 // MOVE (the data-movement floor, a diagnostic instantiation): no incidence is walked -- every row is stored as zeros
 // through the same slab and the same store instructions.
-// a workgroup barrier that orders LDS accesses only (LDSONLY): it does not wait for the wave's outstanding global loads
-// and stores, so loads issued for the NEXT tile stay in flight across it (gg_fused_persist_kernel); else __syncthreads()
-template <bool LDSONLY> __device__ __forceinline__ void tile_barrier() {
-  if constexpr (LDSONLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  else __syncthreads();
-}
-
-template <int LPP, bool NT, bool SYNC = false, int ST = 0, bool MOVE = false, bool LDSBAR = false, int DEEP = GG_DEEP_BATCH>
+template <int LPP, bool NT, bool SYNC = false, int ST = 0, bool MOVE = false>
 __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, const cfdp_tile_desc &td,
                                                   int tid, double *__restrict__ gradA,
                                                   double *__restrict__ gradB,
@@ -269,7 +262,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     const double *var_eq0 = var_l + eq0;
     int k = ks;
     if constexpr (NE <= 2)  // few registers per incidence: deeper batches (a point has ~14 incidences)
-      for (; k + DEEP <= ke; k += DEEP) grad_batch<DEEP, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
+      for (; k + GG_DEEP_BATCH <= ke; k += GG_DEEP_BATCH) grad_batch<GG_DEEP_BATCH, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
     for (; k + 4 <= ke; k += 4) grad_batch<4, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
     if (k + 2 <= ke) {
       grad_batch<2, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
@@ -283,7 +276,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   // remote store takes longest).  A point without faces is pushed by nobody (such partitions keep the push kernel)
   if (push_row && active && ke0 > ks) push_from_registers<NE>(push_row, eq0, acc, tmp);
   // SYNC: `stage` aliases a region of the tile image other waves may still be reading
-  if constexpr (SYNC) tile_barrier<LDSBAR>();
+  if constexpr (SYNC) __syncthreads();
   // ---- write the finished rows.  A lane holds NE*3 doubles of a 168-byte row; storing them
   // directly is 8 bytes per lane at a 24..168-byte stride (measured: the stores alone then
   // take longer than streaming the whole tile in).  Instead each wave transposes its PPW rows
@@ -623,7 +616,7 @@ __device__ __forceinline__ void glds16_nt(const uint4 *src, unsigned char *lds_w
 // once per incidence: 6 adds + 9 FMAs per incidence instead of ~48 fp64 operations -- the fp64
 // vector rate, not LDS or HBM, bounded this loop (measured: the flux phase cost 64 us of the
 // 331-us fused pass on the 128^3 mesh).  Differs from the reference's association by round-off.
-template <int LPP, bool REFMODE, bool LDSBAR = false>
+template <int LPP, bool REFMODE>
 __device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, double *g_l,
                                                   const cfdp_tile_desc &td, const int *__restrict__ hid,
                                                   int tid, int nthr, double *__restrict__ flux, int nown) {
@@ -645,7 +638,7 @@ __device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, dou
       g[0] = -0.5 * sts_xx; g[1] = -0.5 * sts_xy; g[2] = -0.5 * sts_xz;
       g[3] = -0.5 * sts_yy; g[4] = -0.5 * sts_yz; g[5] = -0.5 * sts_zz;
     }
-    tile_barrier<LDSBAR>();
+    __syncthreads();
   }
   const int li = tid / LPP, sub = tid % LPP;
   const bool active = li < npts;
@@ -1091,165 +1084,6 @@ void gg_fused_split_kernel(
   }
 }
 
-// ------------------------------------------------------------------ the fused pass with workgroups that stay
-// The phase-split pass above spends a third of a tile's life waiting for two dependent round trips (descriptor + row
-// numbers, then blob + rows: tools/phase_stamps.py) with nothing of the NEXT tile in flight -- the LDS a second staged
-// tile would need is what limits the CU to four tiles.  Here a workgroup stays and takes tile after tile; what it can
-// hold in REGISTERS of the next tile is requested while it computes the current one:
-//   * the next block id (one atomic of thread 0: per-XCD counters, so that a tile still runs on the XCD whose L2 holds
-//     its neighbours' rows; an XCD that has finished its share takes from the others) -- a phase ahead;
-//   * the next tile's descriptor and row numbers -- during the flux phase;
-//   * the next tile's blob, CB x 16 bytes per thread -- during the gradient phase; it drops into LDS at the top of
-//     the next round (the image LDS-DMA would have written).
-// Only the row gathers (they need the row region) remain exposed.  The barriers inside a round order LDS accesses only
-// (tile_barrier<true>): a __syncthreads() would wait for the loads in flight.  Values: the same per-tile functions.
-// ctr: 8 per-XCD block counters + 1 exit counter, 32 ints apart, zero before the first launch; the last workgroup to
-// leave zeroes them for the next launch (a graph replay needs no memset node).
-template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
-void gg_fused_persist_kernel(
-    const cfdp_tile_desc *__restrict__ tiles, int tile_begin, int ntiles, const uint4 *__restrict__ blob,
-    const int *__restrict__ halo_idx, const int *__restrict__ rowlist, const double *__restrict__ var /*[nall][8]*/,
-    const double *__restrict__ gradA_old /*[nown][10]*/, const double *__restrict__ ghost_old /*[nghost][21]*/,
-    double *__restrict__ flux /*[nown][3]*/, int nown,
-    double *__restrict__ gradA_new /*[nown][10]*/, double *__restrict__ gradB_new /*[nown][11]*/, int dbg, int *__restrict__ ctr) {
-  static_assert(KX >= KV && KX >= KG, "the shared row region must hold either set of rows");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int LPP = 4;
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, w0 = tid & ~63;
-  unsigned char *xbuf = smem + (size_t)CB * nthr * 16;  // the shared row region
-  volatile int *nextw = reinterpret_cast<volatile int *>(xbuf + (size_t)KX * nthr * 16);
-  const bool rev = (dbg & GG_DBG_REVERSE) != 0;
-  const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u);  // XCC_ID
-  // block ids: the first one is blockIdx.x (the grid has at most ntiles workgroups); further ones come from the counter
-  // of the XCD the workgroup runs on -- class x hands out x + 8 * (its first-round ids + count) -- and, once that share
-  // is used up, from the other classes (thread 0; rare: the tail of a launch).  Unique whatever XCC_ID says
-  auto take = [&](int x) -> int {
-    const int first_round = ((int)gridDim.x + 7 - x) >> 3;
-    return x + 8 * (first_round + atomicAdd(&ctr[x * 32], 1));
-  };
-  auto take_any = [&]() -> int {
-    for (int y = 1; y < 8; y++) {
-      const int b = take((xcd + y) & 7);
-      if (b < ntiles) return b;
-    }
-    return -1;
-  };
-  auto leave = [&]() {
-    if (tid == 0 && atomicAdd(&ctr[8 * 32], 1) == (int)gridDim.x - 1)
-      for (int x = 0; x < 9; x++) ctr[x * 32] = 0;  // everybody has taken its last id: zero for the next launch
-  };
-#ifdef GG_PERSIST_STAGGER
-  // experiment: the four workgroups of a CU start a quarter of a tile's life apart instead of in lockstep
-  for (int j = (int)blockIdx.x >> 8; j > 0; j--) __builtin_amdgcn_s_sleep(GG_PERSIST_STAGGER);
-#endif
-  int t = tile_begin + xcd_tile((int)blockIdx.x, ntiles, rev);
-  int hv[KV], hg[KG];
-  u32x4 B[CB];
-  cfdp_tile_desc td = tiles[t];
-  auto request_rows_numbers = [&](int tile) {
-    const int *rl = rowlist + (size_t)tile * GG_ROW_STRIDE;
-#pragma unroll
-    for (int k = 0; k < KV; k++) {
-      const int r = (tid + k * nthr) >> 2;
-      hv[k] = rl[r < GG_ROW_STRIDE - 1 ? r : GG_ROW_STRIDE - 1];
-    }
-#pragma unroll
-    for (int k = 0; k < KG; k++) {
-      const int r = (tid + k * nthr) / 5;
-      hg[k] = rl[r < GG_ROW_STRIDE - 1 ? r : GG_ROW_STRIDE - 1];
-    }
-  };
-  auto request_blob = [&](const cfdp_tile_desc &d) {
-    const u32x4 *b4 = reinterpret_cast<const u32x4 *>(blob + d.blob_off);
-    const int qmax = d.blob_qw - 1;
-#pragma unroll
-    for (int i = 0; i < CB; i++) {
-      const int q = w0 + i * nthr + lane;
-      if constexpr (NT) B[i] = __builtin_nontemporal_load(b4 + (q < qmax ? q : qmax));
-      else B[i] = b4[q < qmax ? q : qmax];
-    }
-  };
-  request_rows_numbers(t);
-  request_blob(td);
-  const unsigned char *abytes = reinterpret_cast<const unsigned char *>(gradA_old);
-  const unsigned char *hbytes = reinterpret_cast<const unsigned char *>(ghost_old);
-  const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
-  const int tid0 = tid;
-  int bcur = (int)blockIdx.x;
-  (void)bcur;
-  for (;;) {
-    // (an opaque copy of the thread id per round: what derives from it -- LDS addresses, lane-of-point numbers, slab
-    // pointers -- is recomputed every round instead of being hoisted out of the loop and kept in 60+ registers across it)
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, w0 = tid & ~63;
-    // the previous round's row stores are acknowledged, this tile's blob and row numbers are here
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int bnext = 0;
-#ifndef GG_PERSIST_STATIC
-    if (tid == 0) bnext = take(xcd);  // the block after this one: needed a phase from now
-#endif
-#pragma unroll
-    for (int i = 0; i < CB; i++) *reinterpret_cast<u32x4 *>(smem + (size_t)(w0 + i * nthr + lane) * 16) = B[i];
-    const int *hid = halo_idx + td.halo_off;
-#pragma unroll
-    for (int k = 0; k < KG; k++) {
-      const int q = tid + k * nthr, part = q - 5 * (q / 5);
-      const int row = hg[k];
-      if (row < nown)
-        glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * 80 + part * 16), xbuf + (size_t)(w0 + k * nthr) * 16);
-      else
-        glds16_sys(reinterpret_cast<const uint4 *>(hbytes + (size_t)(row - nown) * 168 + part * 16),
-                   xbuf + (size_t)(w0 + k * nthr) * 16);
-    }
-    u32x4 vr[KV];
-#pragma unroll
-    for (int k = 0; k < KV; k++) {
-      const int q = tid + k * nthr;
-      vr[k] = *reinterpret_cast<const u32x4 *>(gv4 + (size_t)hv[k] * 4 + (q & 3));
-    }
-#ifdef GG_PERSIST_STATIC
-    bcur += (int)gridDim.x;
-    if (tid == 0) nextw[0] = bcur < ntiles ? bcur : -1;
-#else
-    if (tid == 0) nextw[0] = bnext < ntiles ? bnext : take_any();
-#endif
-    __syncthreads();  // vmcnt(0) + barrier: blob written, gradient rows landed (var rows in registers), next id published
-    const int bn = nextw[0];
-    cfdp_tile_desc tdn = td;
-    int tn = t;
-    if (bn >= 0) {  // the next tile's descriptor and row numbers fly during the flux phase
-      tn = __builtin_amdgcn_readfirstlane(tile_begin + xcd_tile(bn, ntiles, rev));
-      tdn = tiles[tn];
-      request_rows_numbers(tn);
-    }
-    flux_tile_compute<LPP, REFMODE, true>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
-    tile_barrier<true>();  // every wave is done with the gradient rows: the region takes the var rows
-#pragma unroll
-    for (int k = 0; k < KV; k++) *reinterpret_cast<u32x4 *>(xbuf + (size_t)(tid + k * nthr) * 16) = vr[k];
-    tile_barrier<true>();
-#ifndef GG_PERSIST_NOB
-    if (bn >= 0) request_blob(tdn);  // ... and its blob during the gradient phase
-#endif
-#ifndef GG_PERSIST_DEEP
-#define GG_PERSIST_DEEP 4  // (deeper batches spill: 128 registers hold the next blob and row numbers too)
-#endif
-    grad_tile_compute<LPP, NT, true, 0, false, true, GG_PERSIST_DEEP>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
-                                                     CB * nthr * 16, 1.0, nullptr);
-    if (bn < 0) break;
-    tile_barrier<true>();  // every wave is done with the blob and the row region
-    td = tdn;
-    t = tn;
-#ifdef GG_PERSIST_NOB
-    request_blob(td);
-#endif
-  }
-  leave();
-}
-
 // ------------------------------------------------------------------ tile-resident iterations
 // Partitions of at most (workgroups per CU) x 256 tiles -- the strong-scaling regime of BASELINE configs 3-4, the
 // coarse levels of a V cycle; the reference's design point "everything lives in cache at ~100 points per core"
@@ -1648,21 +1482,6 @@ hipError_t launch_split(const gg_args &a, const gg_grad_view &gnew, int tile_beg
   return launch(gg_fused_split_kernel<R, N, 5, 4, 4, 4, D, L, P>, ntiles, block, (size_t)(5 + 4) * block * 16, stream, a.tiles, tile_begin,
                 a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa);
 }
-// the same pass with workgroups that stay (gg_fused_persist_kernel): as many as the device holds at once, 4 per CU
-template <bool R, bool N>
-hipError_t launch_persist(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
-                          int dbgf, int *ctr) {
-  static int slots = 0;
-  if (!slots) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      return hipErrorNotSupported;
-    slots = 4 * cus;
-  }
-  return launch(gg_fused_persist_kernel<R, N, 5, 4, 4, 4>, ntiles < slots ? ntiles : slots, block, (size_t)(5 + 4) * block * 16 + 16, stream,
-                a.tiles, tile_begin, ntiles, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b,
-                dbgf, ctr);
-}
 template <bool R, bool N>
 hipError_t launch_split_lp(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
                            int dbgf, const gg_push_args &pa) {
@@ -1758,7 +1577,7 @@ bool gg_fused_fits(int tile_points, int max_halo, int max_blob_qw) {
 
 hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refmode, int tile_begin,
                            int ntiles, int tile_points, int max_halo, int max_blob_qw, bool nt,
-                           bool allow_split, hipStream_t stream, const gg_push_args *push, bool reverse, int *persist_ctr) {
+                           bool allow_split, hipStream_t stream, const gg_push_args *push, bool reverse) {
   if (ntiles <= 0) return hipSuccess;
   const int dbgf = gg_debug_flags | (reverse ? GG_DBG_REVERSE : 0);
   gg_push_args pa;
@@ -1780,12 +1599,6 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
       if (!a.rowlist) return hipErrorNotSupported;
       return nt ? launch_split<false, true, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                 : launch_split<false, false, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
-    }
-    if (persist_ctr && a.rowlist && !(push && push->tile_off)) {  // no exchange rides in this pass: workgroups that stay
-      if (refmode) return nt ? launch_persist<true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, persist_ctr)
-                             : launch_persist<true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, persist_ctr);
-      return nt ? launch_persist<false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, persist_ctr)
-                : launch_persist<false, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, persist_ctr);
     }
     if (refmode) return nt ? launch_split_lp<true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                            : launch_split_lp<true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);

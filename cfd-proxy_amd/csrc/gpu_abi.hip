@@ -81,7 +81,7 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
 
 static void free_device(cfdp_gpu *g) {
   g->drop_graphs();
-  (void)hipFree(g->d_tiles); (void)hipFree(g->d_blob); (void)hipFree(g->d_halo); (void)hipFree(g->d_sendidx); (void)hipFree(g->d_rowlist); (void)hipFree(g->d_persist_ctr);
+  (void)hipFree(g->d_tiles); (void)hipFree(g->d_blob); (void)hipFree(g->d_halo); (void)hipFree(g->d_sendidx); (void)hipFree(g->d_rowlist);
   (void)hipFree(g->d_var); (void)hipFree(g->d_flux);
   (void)hipFree(g->d_nbr_off); (void)hipFree(g->d_nbr); (void)hipFree(g->d_resident_state);
   g->d_nbr_off = g->d_nbr = g->d_resident_state = nullptr;
@@ -91,7 +91,7 @@ static void free_device(cfdp_gpu *g) {
   if (g->own_grad_alt) (void)hipFree(g->d_grad_alt);
   if (g->own_sendbuf) (void)hipFree(g->d_sendbuf);
   g->d_grad_alt = nullptr; g->own_grad_alt = true; g->flux_pending = -1; g->iter = 0;
-  g->d_tiles = nullptr; g->d_blob = nullptr; g->d_halo = g->d_sendidx = nullptr; g->d_rowlist = nullptr; g->d_persist_ctr = nullptr;
+  g->d_tiles = nullptr; g->d_blob = nullptr; g->d_halo = g->d_sendidx = nullptr; g->d_rowlist = nullptr;
   g->d_var = g->d_grad = g->d_flux = g->d_sendbuf = nullptr;
   g->own_grad = g->own_sendbuf = true;
   g->uploaded = false;
@@ -192,8 +192,6 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
       }
       HIP_TRY(hipMalloc(&g->d_rowlist, rl.size() * sizeof(int)));
       HIP_TRY(hipMemcpy(g->d_rowlist, rl.data(), rl.size() * sizeof(int), hipMemcpyHostToDevice));
-      HIP_TRY(hipMalloc(&g->d_persist_ctr, GG_PERSIST_CTR_INTS * sizeof(int)));
-      HIP_TRY(cfdp_memset_sync(g->d_persist_ctr, 0, GG_PERSIST_CTR_INTS * sizeof(int)));
     }
   }
   {  // neighbour tiles = the owners of a tile's owned halo rows (symmetric: a cut face is stored with both tiles)
@@ -225,7 +223,6 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
     if (const char *e = getenv("CFDP_STREAMING")) g->streaming = atoi(e) != 0;
     g->alternate = g->streaming;
     if (const char *e = getenv("CFDP_ALTERNATE")) g->alternate = atoi(e) != 0;
-    if (const char *e = getenv("CFDP_FUSED_PERSIST")) g->persist = atoi(e) != 0;
   }
   g->send_idx_host.assign(p->send_idx, p->send_idx + nsend);
   g->faceless_send = false;
@@ -500,10 +497,8 @@ extern "C++" int cfdp_detail::launch_fused(cfdp_gpu *g, int which, hipStream_t s
   const tile_range r = range_of(g, which);
   if (push && !gg_fused_fits(r.tp, r.row_halo(), r.max_blob)) return 2;
   const bool reverse = g->alternate && which == CFDP_TILES_ALL && !push && (g->fused_passes++ & 1u);
-  // (one launch at a time may use the block counters: whole-partition passes on the context's main stream)
-  int *const persist_ctr = g->persist && which == CFDP_TILES_ALL && !push && st == g->s_main ? g->d_persist_ctr : nullptr;
   const hipError_t e = gg_launch_fused(a, gnew, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.row_halo(), r.max_blob,
-                                       g->streaming, !g->beside_rccl, st, push, reverse, persist_ctr);
+                                       g->streaming, !g->beside_rccl, st, push, reverse);
   if (e == hipErrorNotSupported && push) return 2;
   if (e == hipErrorNotSupported) {
     if (launch_flux_tiles(g, mode, which, st)) return 1;

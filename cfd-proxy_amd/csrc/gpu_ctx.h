@@ -61,8 +61,6 @@ struct cfdp_gpu {
   uint4 *d_blob = nullptr;
   int *d_halo = nullptr, *d_sendidx = nullptr;
   int *d_rowlist = nullptr;     // fixed-stride row lists of the fused pass (gg_args::rowlist), or null
-  int *d_persist_ctr = nullptr; // block counters of gg_fused_persist_kernel (GG_PERSIST_CTR_INTS, zero between launches)
-  bool persist = false;         // fused passes over all tiles without an exchange: workgroups that stay (CFDP_FUSED_PERSIST)
   // tile-resident iterations (gg_resident_kernel): the neighbour tiles of every tile (owners of its halo rows) and
   // one block [err: 4 ints][flags: ntiles ints] that is zeroed before every launch; resident: 0 off, 1 on when the
   // partition qualifies, 2 = the staleness test (G_k stores its rows times 2^(k-1))
