@@ -352,6 +352,7 @@ def main() -> None:
             "value": its * mesh_points / UNIT_POINTS, "ms_per_step": dt / args.steps * 1e3, "scaling": cfg["scaling"],
             # the same K steps timed the same way straight behind the W warm-up steps (chip below its sustained clock)
             "clock_conditioning": {"seconds": CONDITION_S, "steps": cond["steps"],
+                                   "untimed_steps_in_front_of_the_timed_region": max(args.warmup, 1) + cond["steps"],
                                    "unconditioned_ms_per_step": dt_cold / args.steps * 1e3,
                                    "unconditioned_value": args.steps / dt_cold * mesh_points / UNIT_POINTS},
             "config": {
