@@ -302,7 +302,7 @@ def main() -> None:
             if conditioned:
                 condition(**kw)
                 # ... and every graph instantiated again: an executable graph that other work has gone through the
-                # device behind starts 60-100 us late on an idle device (tools/clock_ramp_probe.py, DESIGN 9)
+                # device behind starts 60-100 us late on an idle device (tools/clock_ramp_probe.py, DESIGN 8)
                 solver.gpu.refresh_graphs()
             barrier()
             t = time.perf_counter()
