@@ -199,6 +199,16 @@ def main() -> None:
     ap.add_argument("--no-strong", action="store_true", help="skip the extra dualgrid.192 strong-scaling measurement at --gpus 8")
     args = ap.parse_args()
 
+    from __graft_entry__ import load_package
+    pkg = load_package()  # (the C host library only: nothing here touches the GPU)
+    # a run under an experiment switch (wrong values, ablated protocol, injected faults, test delays: host/experiments.c)
+    # is not a measurement of the product: no line
+    active = pkg.experiments_active()
+    if active:
+        print(f"bench.py: refusing to report a run made with experiment switches active: {' '.join(active)} "
+              f"(unset them or CFDP_EXPERIMENTS)", file=sys.stderr)
+        raise SystemExit(3)
+
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started plainly (no launcher): this process only launches the ranks, BEFORE anything touches the GPU
         # (counting devices does not initialise HIP on this image)
@@ -208,8 +218,6 @@ def main() -> None:
     import numpy as np
     import torch
 
-    from __graft_entry__ import load_package
-    pkg = load_package()
     from cfd_proxy_amd import multigpu as mg
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -407,6 +415,8 @@ def main() -> None:
         "data": "synthetic (F6-like dualgrid stand-in; the f6/dualgrid.N files are not distributed)",
         "config": res["config"],
     }
+    # every CFDP_* variable this run saw (experiment switches cannot be among them: refused above)
+    out["config"]["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("CFDP_")}
     if role != world:
         out["config"]["rehearsal"] = f"{world} ranks standing in for the {role}-GPU line (CFDP_BENCH_AS_GPUS)"
     for k in ("clock_conditioning", "exchange_check", "overlap"):

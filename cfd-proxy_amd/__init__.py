@@ -194,6 +194,10 @@ def _declare_host(lib: C.CDLL) -> None:
     lib.cfdp_group_link_raw.argtypes = [C.c_int, P(P(CommData))]
     lib.cfdp_group_link_raw.restype = None
     lib.cfdp_host_version.restype = C.c_char_p
+    lib.cfdp_experiment_getenv.argtypes = [C.c_char_p]
+    lib.cfdp_experiment_getenv.restype = C.c_char_p
+    lib.cfdp_experiment_switches.restype = C.c_char_p
+    lib.cfdp_experiments_active.argtypes = [C.c_char_p, C.c_size_t]
 
 
 class ScaledCheck(C.Structure):
@@ -215,8 +219,6 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_bind_grad.argtypes = [vp, vp]
     lib.cfdp_gpu_bind_sendbuf.argtypes = [vp, vp]
     lib.cfdp_gpu_set_fusion.argtypes = [vp, C.c_int]
-    lib.cfdp_gpu_set_resident.argtypes = [vp, C.c_int]
-    lib.cfdp_gpu_resident_qualifies.argtypes = [vp, P(C.c_char_p)]
     lib.cfdp_gpu_bind_grad_alt.argtypes = [vp, vp]
     lib.cfdp_gpu_time_fused.argtypes = [vp, C.c_int, C.c_int, P(C.c_float)]
     lib.cfdp_gpu_time_fused_movement.argtypes = [vp, C.c_int, P(C.c_float)]
@@ -566,6 +568,19 @@ def merge_scatter(part: Domain, dl: int, npoints_d: int, field: np.ndarray) -> n
     return out
 
 
+def experiment_switches() -> list:
+    """the environment variables host/experiments.c gates behind CFDP_EXPERIMENTS=1 (not the product path)"""
+    return host_lib().cfdp_experiment_switches().decode().split()
+
+
+def experiments_active() -> list:
+    """["NAME=value", ...] of the experiment switches that are set WITH the master key: a benchmark must not report
+    a run made under any of them (bench.py refuses)"""
+    buf = C.create_string_buffer(1024)
+    n = host_lib().cfdp_experiments_active(buf, len(buf))
+    return buf.value.decode().split() if n else []
+
+
 def algo_bytes_grad(nfaces: int, nown: int, nadd: int) -> float:
     return host_lib().cfdp_algo_bytes_grad(nfaces, nown, nadd)
 
@@ -840,16 +855,6 @@ class GpuPartition:
         g, f = C.c_float(), C.c_float()
         self._ck(self.lib.cfdp_gpu_time_kernels(self.h, iters, flux_mode, C.byref(g), C.byref(f)))
         return g.value, f.value
-
-    def set_resident(self, mode: int) -> None:
-        """tile-resident iterations (cfdp_gpu_set_resident): 0 off, 1 on where the partition qualifies, 2 staleness test"""
-        self._ck(self.lib.cfdp_gpu_set_resident(self.h, int(mode)))
-
-    def resident_qualifies(self):
-        """(True, None) or (False, reason)"""
-        why = C.c_char_p()
-        ok = self.lib.cfdp_gpu_resident_qualifies(self.h, C.byref(why))
-        return bool(ok), (why.value.decode() if why.value else None)
 
     def run_iterations(self, iters: int, with_flux: bool = True, flux_mode: int = FLUX_CONSISTENT,
                        use_graph: bool = True) -> float:

@@ -104,21 +104,6 @@ hipError_t gg_launch_validate(double *var, int nall, const double *flux, const d
                               int nown, int lag, bool do_scale, int *state, hipStream_t stream);
 hipError_t gg_launch_scale_var(double *var, int nall, double factor, hipStream_t stream);
 hipError_t gg_launch_var_check(const double *var, const double *var0, int nall, double factor, unsigned long long *bad, hipStream_t stream);
-// tile-resident iterations (gg_resident_kernel): K iterations in ONE launch, one workgroup per tile staying for all
-// of them; the iteration boundary is a drained-flag hand-off between neighbouring tiles
-struct gg_resident_args {
-  const int *nbr_off;   // [ntiles + 1]
-  const int *nbr;       // neighbour tiles (the owners of a tile's halo rows), <= 64 per tile
-  int *flags;           // [ntiles], zeroed before every launch: gradient passes a tile has finished
-  int *err;             // [4], zeroed before every launch: a wait gave up / tile / needed / seen
-  long max_polls;
-  int iters;            // K >= 1
-  int with_flux;
-};
-bool gg_resident_fits(int tile_points, int max_halo, int max_blob_qw);
-int gg_resident_capacity(void);  // workgroups of the resident kernel the device holds at once
-hipError_t gg_launch_resident(const gg_args &a, const gg_grad_view &w0, const gg_grad_view &w1, bool refmode, int ntiles,
-                              const gg_resident_args &ra, bool scale_test, hipStream_t stream);
 extern int gg_debug_flags;
 hipError_t gg_set_stamp_buffer(unsigned long long *dev);  // diagnostics: phase stamps of the split fused pass
 extern int gg_fused_split;

@@ -167,19 +167,10 @@ __device__ __forceinline__ void grad_batch(const uint32_t *__restrict__ inc, int
   }
 }
 
-// write-through (sc1) stores: the bytes leave this XCD's L2 for memory at once and the line is dropped, so that a
-// workgroup on ANY XCD that loads them `sc1` after the producer's drained flag reads them fresh INSIDE one launch
-// (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload stores, every storing wave drains vmcnt(0), barrier,
-// one lane's agent-scope flag store; 16 bytes per lane -- narrower sc1 stores are one fabric write each).  Inline
-// asm is invisible to the compiler's vmcnt bookkeeping: the caller drains with s_waitcnt vmcnt(0) before it signals.
+// write-through system-scope store (sc0 sc1): the bytes leave this device's caches with the store itself.  Inline asm is
+// invisible to the compiler's vmcnt bookkeeping: the caller drains with s_waitcnt vmcnt(0) before it signals.
 typedef unsigned int gg_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st16_sc1(void *p, gg_u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void st8_sc1(double *p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dwordx2 ... sc1
-}
-__device__ __forceinline__ void st16_sys(void *p, gg_u32x4 v) {  // global_store_dwordx4 ... sc0 sc1: write-through, system scope
+__device__ __forceinline__ void st16_sys(void *p, gg_u32x4 v) {  // global_store_dwordx4 ... sc0 sc1
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
 }
 // xGMI write + notify, a point's first destination, pushed from the REGISTERS of its lanes the moment the row is finished:
@@ -221,18 +212,15 @@ __device__ __forceinline__ void push_from_registers(double *row, int eq0, const 
   }
 }
 
-// ST: how the finished rows are stored.  0: 8 bytes per lane, contiguous runs (NT: non-temporal) -- the form of the
-// one-launch-per-pass kernels.  1: part A (the rows neighbouring tiles re-read) write-through, 16 bytes per lane;
-// part B plain -- the form of the tile-resident kernel, whose readers run in the same launch.  `scale` multiplies
-// the rows (1.0 except in the staleness test of the tile-resident kernel).
+// The finished rows are stored 8 bytes per lane in contiguous runs (NT: non-temporal).
 // MOVE (the data-movement floor, a diagnostic instantiation): no incidence is walked -- every row is stored as zeros
 // through the same slab and the same store instructions.
-template <int LPP, bool NT, bool SYNC = false, int ST = 0, bool MOVE = false>
+template <int LPP, bool NT, bool SYNC = false, bool MOVE = false>
 __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, const cfdp_tile_desc &td,
                                                   int tid, double *__restrict__ gradA,
                                                   double *__restrict__ gradB,
                                                   double *__restrict__ stage, int dbg = 0,
-                                                  int var_off = -1, double scale = 1.0, double *push_row = nullptr) {
+                                                  int var_off = -1, double *push_row = nullptr) {
   constexpr int NE = grad_cfg<LPP>::NE;
   constexpr int PPW = 64 / LPP;  // points per wave
   const int li = tid / LPP, sub = tid % LPP;
@@ -270,7 +258,6 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     }
     if (k < ke) grad_batch<1, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
     tmp = 1.0 / var_l[li * 8 + 7];  // 1/pvolume, src/gradients.c:138
-    if constexpr (ST == 1) tmp *= scale;
   }
   // this point's row goes to a partner: out of the registers, now (before the tile's own stores: the acknowledgement of a
   // remote store takes longest).  A point without faces is pushed by nobody (such partitions keep the push kernel)
@@ -296,8 +283,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
 #pragma unroll
           for (int c = 0; c < 3; c++) {
             const int d = (eq0 + j) * 3 + c;  // position in the 21-double row
-            if (ST == 1 && d < 10) st8_sc1(&ga[d], acc[j][c] * tmp);
-            else (d < 10 ? ga : gb)[d] = acc[j][c] * tmp;
+            (d < 10 ? ga : gb)[d] = acc[j][c] * tmp;
           }
         }
     }
@@ -328,15 +314,9 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     const size_t p0 = (size_t)(td.pstart + wp + h * SPP);
     double *ga = gradA + p0 * 10, *gb = gradB + p0 * 11;
     const int na = nvh * 10, nd = nvh * 21;
-    if constexpr (ST == 1) {
-      // part A: 80-byte rows, 5 pieces of 16 bytes each (slab and part A are 16-byte aligned); nvh * 5 <= 40 lanes
-      if (lane < nvh * 5) st16_sc1(ga + 2 * lane, *reinterpret_cast<const gg_u32x4 *>(slab + 2 * lane));
-      for (int c = na + lane; c < nd; c += 64) gb[c - na] = slab[SPP * 10 + c - na];
-    } else {
-      for (int c = lane; c < nd; c += 64) {
-        if (c < na) st_row<NT>(slab[c], &ga[c]);
-        else st_row<NT>(slab[SPP * 10 + c - na], &gb[c - na]);
-      }
+    for (int c = lane; c < nd; c += 64) {
+      if (c < na) st_row<NT>(slab[c], &ga[c]);
+      else st_row<NT>(slab[SPP * 10 + c - na], &gb[c - na]);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -896,7 +876,7 @@ void gg_fused_dma_kernel(
   }
   flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(gbuf), dbg,
-                                   CB * nthr * 16, 1.0, push_row);
+                                   CB * nthr * 16, push_row);
   push_tile_rows(pa, t, tid, nthr, td, gradA_new, gradB_new);
   push_tile_done(pa, t, tid, iter0);
 }
@@ -1070,8 +1050,8 @@ void gg_fused_split_kernel(
   for (int k = 0; k < KV; k++) *reinterpret_cast<u32x4 *>(xbuf + (size_t)(tid + k * nthr) * 16) = vr[k];
   __syncthreads();  // vmcnt(0) + barrier
   if constexpr (STAMP) gg_stamp(dbg, t, 4);  // var rows in place
-  grad_tile_compute<LPP, NT, true, 0, DIAG == 2>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
-                                                 CB * nthr * 16, 1.0, push_row);
+  grad_tile_compute<LPP, NT, true, DIAG == 2>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
+                                              CB * nthr * 16, push_row);
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 2);  // this wave is through its gradient phase (stores issued)
   if constexpr (STAMP) gg_stamp(dbg, t, 5);  // gradient arithmetic done, row stores issued (wave 0)
   if constexpr (STAMP) {
@@ -1081,154 +1061,6 @@ void gg_fused_split_kernel(
   if constexpr (PUSH) {
     if (!(dbg & 0x200)) push_tile_rows(pa, t, tid, nthr, td, gradA_new, gradB_new);
     if (!(dbg & 0x400)) push_tile_done(pa, t, tid, iter0, dbg);
-  }
-}
-
-// ------------------------------------------------------------------ tile-resident iterations
-// Partitions of at most (workgroups per CU) x 256 tiles -- the strong-scaling regime of BASELINE configs 3-4, the
-// coarse levels of a V cycle; the reference's design point "everything lives in cache at ~100 points per core"
-// (README.txt:39-40) -- run ALL their iterations in ONE launch: one workgroup per tile STAYS for K iterations.
-// What never changes is loaded once: the tile blob (normals, incidence lists) stays in LDS, the var rows of own and
-// halo points stay in registers (16 bytes x KV per thread; they drop into the row region for every gradient phase, as
-// in the phase-split pass).  Per iteration only the part-A rows of the previous gradients come in (own + halo, 80
-// bytes each) and the finished rows go out.  The iteration boundary is not a kernel boundary but a hand-off between
-// neighbouring tiles, in the guide's drained-flag form (MI355X_MICROARCH.md, inter-workgroup visibility):
-//   producer  part-A rows stored write-through (sc1, 16 B per lane), every wave s_waitcnt vmcnt(0), barrier, ONE
-//             lane stores flag[tile] = gradient passes finished (agent-scope atomic store = sc1)
-//   consumer  one wave polls the flags of the tile's neighbour tiles (one lane each, relaxed agent-scope loads,
-//             bounded, s_sleep between polls), barrier, then EVERY load of part-A rows is a global_load ... sc1 to
-//             registers (no L1, no stale copy), dropped into the LDS row region
-// Iteration k of a tile = G_k (gradients k -> buffer (k-1) & 1, flag = k) then F_k (flux of gradients k: reads its
-// neighbours' rows of that buffer, so it waits for their flag >= k).  G_(k+1) overwrites the buffer F_(k-1) read:
-// the tile has seen its neighbours' flag >= k by then, and a neighbour raises its flag to k only after its F_(k-1).
-// All tiles are co-resident (the host refuses grids beyond the device's capacity), every spin is bounded and leaves a
-// word in `err` when it gives up.  Values: the same per-tile functions as every other form -- bit for bit.
-// SCALE (tests only): G_k stores its rows times 2^(k-1), so F_k must produce flux x 2^(k-1) EXACTLY: a row left over
-// from two iterations ago (same buffer, same address, same value in the benchmark's constant field) cannot hide.
-template <int KG>
-__device__ __forceinline__ void ld16x_sc1(gg_u32x4 (&v)[KG], const void *const (&p)[KG]) {
-  static_assert(KG == 4, "one statement: the loads and their wait (inline-asm loads are not counted by the compiler)");
-  asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
-               "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-               : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-               : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3])
-               : "memory");
-}
-
-template <bool REFMODE, int CB, int KV, int KG, int KX, bool SCALE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
-void gg_resident_kernel(
-    const cfdp_tile_desc *__restrict__ tiles, const uint4 *__restrict__ blob, const int *__restrict__ halo_idx,
-    const int *__restrict__ rowlist, const double *__restrict__ var /*[nall][8]*/,
-    double *gradA0, double *gradB0, const double *ghost0, double *gradA1, double *gradB1, const double *ghost1,
-    double *__restrict__ flux /*[nown][3]*/, int nown, gg_resident_args ra) {
-  static_assert(KX >= KV && KX >= KG, "the shared row region must hold either set of rows");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int LPP = 4;
-  const int t = xcd_tile(blockIdx.x, gridDim.x);
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, w0 = tid & ~63;
-  // ---- once: row numbers (own rows, halo rows, padding), blob -> LDS, var rows -> registers
-  // goff[q]: where this thread's q-th 16-byte piece of the part-A rows comes from, as a byte offset into part A
-  // (owned rows) or, with bit 31 set, into the ghost block -- one register per piece, the bases are scalars
-  int hv[KV];
-  unsigned goff[KG];
-  const int *rl = rowlist + (size_t)t * GG_ROW_STRIDE;
-#pragma unroll
-  for (int k = 0; k < KV; k++) {
-    const int r = (tid + k * nthr) >> 2;
-    hv[k] = rl[r < GG_ROW_STRIDE - 1 ? r : GG_ROW_STRIDE - 1];
-  }
-#pragma unroll
-  for (int k = 0; k < KG; k++) {
-    const int q = tid + k * nthr, r = q / 5, part = q - 5 * r;
-    const int row = rl[r < GG_ROW_STRIDE - 1 ? r : GG_ROW_STRIDE - 1];
-    goff[k] = row < nown ? (unsigned)row * 80u + (unsigned)part * 16u
-                         : 0x80000000u | ((unsigned)(row - nown) * 168u + (unsigned)part * 16u);
-  }
-  const cfdp_tile_desc td = tiles[t];
-  const int *hid = halo_idx + td.halo_off;
-  const uint4 *b4 = blob + td.blob_off;
-  const int qmax = td.blob_qw - 1;
-#pragma unroll
-  for (int i = 0; i < CB; i++) {
-    const int q0 = w0 + i * nthr;
-    const int q = q0 + lane < qmax ? q0 + lane : qmax;
-    glds16(b4 + q, smem + (size_t)q0 * 16);
-  }
-  const uint4 *gv4 = reinterpret_cast<const uint4 *>(var);
-  gg_u32x4 vr[KV];
-#pragma unroll
-  for (int k = 0; k < KV; k++) vr[k] = *reinterpret_cast<const gg_u32x4 *>(gv4 + (size_t)hv[k] * 4 + ((tid + k * nthr) & 3));
-  // the neighbour tiles this tile waits for: wave 0, one lane each
-  const int n0 = ra.nbr_off[t], nn = ra.nbr_off[t + 1] - n0;
-  int mynbr = 0;
-  if (tid < nn) mynbr = ra.nbr[n0 + tid];
-  unsigned char *xbuf = smem + (size_t)CB * nthr * 16;  // the shared row region
-  __syncthreads();  // vmcnt(0) + barrier: the blob has landed, the var rows are in registers
-
-  const int tid0 = tid;
-  for (int k = 1; k <= ra.iters; k++) {
-    // (per-lane addresses derived from the thread number are re-formed every iteration: hoisted out of the loop as
-    // loop invariants they do not fit the 128 registers four workgroups per CU allow, and spill)
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int cur = (k - 1) & 1;
-    double *gA = cur ? gradA1 : gradA0, *gB = cur ? gradB1 : gradB0;
-    // (opaque per iteration: per-lane pointers into BOTH buffers, hoisted out of the loop, would spill)
-    asm volatile("" : "+s"(gA), "+s"(gB));
-    // ---- G_k: var rows into the row region, gradient phase, rows out (part A write-through), flag = k
-#pragma unroll
-    for (int q = 0; q < KV; q++) *reinterpret_cast<gg_u32x4 *>(xbuf + (size_t)(tid + q * nthr) * 16) = vr[q];
-    __syncthreads();
-    double scale = 1.0;
-    if constexpr (SCALE) scale = __hiloint2double((1023 + k - 1) << 20, 0);  // 2^(k-1)
-    grad_tile_compute<LPP, false, true, 1>(smem, td, tid, gA, gB, reinterpret_cast<double *>(xbuf), 0, CB * nthr * 16, scale);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains ...
-    __syncthreads();                                   // ... before ONE lane signals for all of them
-    if (tid == 0) __hip_atomic_store(ra.flags + t, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!ra.with_flux) continue;
-    // ---- F_k: wait for the neighbours' gradients k, part-A rows in (sc1, through registers), flux phase
-    if (tid < 64) {
-      bool ok = tid >= nn;
-      const int *myflag = ra.flags + mynbr;
-      if (!*(volatile int *)ra.err) {
-        long polls = 0;
-        for (;;) {
-          if (!ok) ok = __hip_atomic_load(myflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= k;
-          if (__all(ok)) break;
-          if (++polls > ra.max_polls) {  // bounded: a grid that is not fully resident must not hang the device
-            if (!ok && atomicCAS(ra.err, 0, 1) == 0) {
-              ra.err[1] = t;
-              ra.err[2] = k;
-              ra.err[3] = __hip_atomic_load(myflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            break;
-          }
-          __builtin_amdgcn_s_sleep(8);
-        }
-      }
-    }
-    __syncthreads();  // the polling wave's loads come after its poll; everybody else's after this barrier
-    {
-      const unsigned char *abytes = reinterpret_cast<const unsigned char *>(cur ? gradA1 : gradA0);
-      const unsigned char *hbytes = reinterpret_cast<const unsigned char *>(cur ? ghost1 : ghost0);
-      asm volatile("" : "+s"(abytes), "+s"(hbytes));
-      const void *src[KG];
-#pragma unroll
-      for (int q = 0; q < KG; q++) {
-        unsigned o = goff[q];
-        asm volatile("" : "+v"(o));  // (the addresses are formed here, per iteration: eight hoisted pointers would not fit)
-        src[q] = (o >> 31 ? hbytes : abytes) + (o & 0x7FFFFFFFu);
-      }
-      gg_u32x4 gr[KG];
-      ld16x_sc1<KG>(gr, src);
-#pragma unroll
-      for (int q = 0; q < KG; q++) *reinterpret_cast<gg_u32x4 *>(xbuf + (size_t)(tid + q * nthr) * 16) = gr[q];
-    }
-    __syncthreads();
-    flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
-    __syncthreads();  // every wave is done with the gradient rows: the region takes the var rows again
   }
 }
 
@@ -1638,40 +1470,3 @@ hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view
   return hipGetLastError();
 }
 
-// K iterations in ONE launch, one workgroup per tile staying for all of them (gg_resident_kernel).  `w0` is the buffer
-// G_1 writes (G_k writes buffer (k - 1) & 1).  hipErrorNotSupported: the tile sizes fit no instantiated capacity.
-// The caller guarantees co-residency (gg_resident_capacity) and has zeroed ra.flags / ra.err on this stream.
-bool gg_resident_fits(int tile_points, int max_halo, int max_blob_qw) {
-  const int block = ((tile_points * 4 + 63) / 64) * 64;
-  const int cb = (max_blob_qw + block - 1) / block;
-  const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;
-  const int kg = ((tile_points + max_halo) * 5 + block - 1) / block;
-  return block == 256 && cb >= 1 && kv >= 1 && kg >= 1 && cb <= 5 && kv <= 4 && kg <= 4 && (tile_points + max_halo) < GG_ROW_STRIDE;
-}
-
-int gg_resident_capacity(void) {
-  int dev = 0, cus = 0, per_cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  auto *k = gg_resident_kernel<false, 5, 4, 4, 4, false>;
-  const size_t lds = (size_t)(5 + 4) * 256 * 16;
-  if (allow_lds(k) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), 256, lds) != hipSuccess) return 0;
-  // the occupancy query can read one block per CU high for SGPR-heavy 256-thread kernels (MI355X_MICROARCH.md,
-  // Residency): the kernel's LDS image (36 KiB of 160) is what bounds it here, at 4 -- never count on more
-  if (per_cu > 4) per_cu = 4;
-  return per_cu * cus;
-}
-
-hipError_t gg_launch_resident(const gg_args &a, const gg_grad_view &w0, const gg_grad_view &w1, bool refmode, int ntiles,
-                              const gg_resident_args &ra, bool scale_test, hipStream_t stream) {
-  if (ntiles <= 0) return hipSuccess;
-  if (!a.rowlist) return hipErrorNotSupported;
-  const size_t lds = (size_t)(5 + 4) * 256 * 16;
-#define RESIDENT(R, S)                                                                                            \
-  launch(gg_resident_kernel<R, 5, 4, 4, 4, S>, ntiles, 256, lds, stream, a.tiles, a.blob, a.halo_idx, a.rowlist, a.var, \
-         w0.a, w0.b, (const double *)w0.ghost, w1.a, w1.b, (const double *)w1.ghost, a.flux, a.nown, ra)
-  if (scale_test) return refmode ? RESIDENT(true, true) : RESIDENT(false, true);
-  return refmode ? RESIDENT(true, false) : RESIDENT(false, false);
-#undef RESIDENT
-}

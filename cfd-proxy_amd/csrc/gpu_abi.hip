@@ -49,14 +49,7 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
   HIP_TRY(hipSetDevice(device));
   cfdp_gpu *g = new cfdp_gpu();
   g->device = device;
-  if (const char *e = getenv("CFDP_DEBUG_ABLATE")) gg_debug_flags = atoi(e);
-  if (const char *e = getenv("CFDP_RESIDENT")) {
-    g->resident = atoi(e);
-    if (g->resident < 0 || g->resident > 2) {
-      delete g;
-      return fail("CFDP_RESIDENT=%s: 0 (off), 1 (on where the partition qualifies) or 2 (staleness test)", e);
-    }
-  }
+  if (const char *e = cfdp_experiment_getenv("CFDP_DEBUG_ABLATE")) gg_debug_flags = atoi(e);  // honoured only with CFDP_EXPERIMENTS=1
   if (const char *e = getenv("CFDP_FUSED_SPLIT")) gg_fused_split = atoi(e);
   HIP_TRY(hipStreamCreateWithFlags(&g->s_main, hipStreamNonBlocking));
   {
@@ -83,8 +76,6 @@ static void free_device(cfdp_gpu *g) {
   g->drop_graphs();
   (void)hipFree(g->d_tiles); (void)hipFree(g->d_blob); (void)hipFree(g->d_halo); (void)hipFree(g->d_sendidx); (void)hipFree(g->d_rowlist);
   (void)hipFree(g->d_var); (void)hipFree(g->d_flux);
-  (void)hipFree(g->d_nbr_off); (void)hipFree(g->d_nbr); (void)hipFree(g->d_resident_state);
-  g->d_nbr_off = g->d_nbr = g->d_resident_state = nullptr;
   (void)hipFree(g->sc.d_state); (void)hipFree(g->sc.d_fref); (void)hipFree(g->sc.d_skip); (void)hipFree(g->sc.d_var0);
   g->sc = cfdp_gpu::scaled_state();
   if (g->own_grad) (void)hipFree(g->d_grad);
@@ -193,28 +184,6 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
       HIP_TRY(hipMalloc(&g->d_rowlist, rl.size() * sizeof(int)));
       HIP_TRY(hipMemcpy(g->d_rowlist, rl.data(), rl.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-  }
-  {  // neighbour tiles = the owners of a tile's owned halo rows (symmetric: a cut face is stored with both tiles)
-    std::vector<int> tile_of((size_t)p->nown, -1), off((size_t)p->ntiles + 1, 0), nbr;
-    for (int t = 0; t < p->ntiles; t++)
-      for (int i = 0; i < p->tiles[t].npts; i++) tile_of[(size_t)p->tiles[t].pstart + i] = t;
-    std::vector<int> seen((size_t)p->ntiles, -1);
-    g->max_nbr = 0;
-    for (int t = 0; t < p->ntiles; t++) {
-      for (int h = 0; h < p->tiles[t].nhalo; h++) {
-        const int row = p->halo_idx[p->tiles[t].halo_off + h];
-        if (row >= p->nown) continue;
-        const int u = tile_of[row];
-        if (u >= 0 && u != t && seen[u] != t) { seen[u] = t; nbr.push_back(u); }
-      }
-      off[(size_t)t + 1] = (int)nbr.size();
-      if (off[(size_t)t + 1] - off[t] > g->max_nbr) g->max_nbr = off[(size_t)t + 1] - off[t];
-    }
-    HIP_TRY(hipMalloc(&g->d_nbr_off, off.size() * sizeof(int)));
-    HIP_TRY(hipMalloc(&g->d_nbr, (nbr.size() + 1) * sizeof(int)));
-    HIP_TRY(hipMalloc(&g->d_resident_state, (((size_t)p->ntiles + 4 + 3) & ~(size_t)3) * sizeof(int)));
-    HIP_TRY(hipMemcpy(g->d_nbr_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
-    if (!nbr.empty()) HIP_TRY(hipMemcpy(g->d_nbr, nbr.data(), nbr.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   g->vol.assign(p->vol, p->vol + p->nown);
   {  // blob + var rows + grad rows streamed per iteration vs the 256 MiB Infinity Cache
@@ -874,80 +843,6 @@ int cfdp_gpu_time_fused(cfdp_gpu *g, int iters, int flux_mode, float *ms_fused) 
   return flush_flux(g);
 }
 
-// ---- tile-resident iterations: K iterations of one partition in ONE launch (gg_resident_kernel)
-// Qualifies: every tile co-resident on the device, tile sizes within the phase-split pass's capacity, fixed-stride
-// row lists, at most 64 neighbour tiles per tile, both grad buffers bound.  cfdp_gpu_run_iterations never exchanges
-// (a partition with partners keeps its ghost rows as they are, like compute_gradients_gg_comm_free); the in-kernel
-// exchange of cfdp_gpu_run_steps_ipc rides in the one-launch-per-pass form only.
-static bool resident_qualifies(const cfdp_gpu *g, const char **why) {
-  const char *w = nullptr;
-  const int tp = g->tp[0] > g->tp[1] ? g->tp[0] : g->tp[1];
-  const int mr = g->max_rows[0] > g->max_rows[1] ? g->max_rows[0] : g->max_rows[1];
-  const int mb = g->max_blob[0] > g->max_blob[1] ? g->max_blob[0] : g->max_blob[1];
-  if (!g->d_grad_alt) w = "fused iterations are off (no second grad buffer)";
-  else if (g->ipc.on) w = "xGMI landing arenas in use (the resident kernel reads the grad buffers' own ghost blocks)";
-  else if (!g->d_rowlist) w = "no fixed-stride row lists (tiles of more than 64 points or 204 rows)";
-  else if (tp > 64 || !gg_resident_fits(64, mr - 64 > 0 ? mr - 64 : 0, mb)) w = "a tile exceeds the 36-KiB LDS image";
-  else if (g->max_nbr > 64) w = "a tile has more than 64 neighbour tiles";
-  else if (g->ntiles > gg_resident_capacity()) w = "more tiles than the device holds workgroups at once";
-  if (why) *why = w;
-  return w == nullptr;
-}
-
-static long resident_max_polls() {
-  double sec = 2.0;
-  if (const char *e = getenv("CFDP_RESIDENT_WAIT_SECONDS")) sec = atof(e);
-  return (long)(sec * 1e6 / 0.4) + 1;  // a poll + s_sleep(8) round is >= 0.4 us
-}
-
-static int run_resident(cfdp_gpu *g, int iters, int with_flux, int flux_mode, float *ms_total) {
-  hipStream_t st = g->s_main;
-  if (flush_flux(g)) return 1;
-  gg_resident_args ra;
-  ra.nbr_off = g->d_nbr_off; ra.nbr = g->d_nbr;
-  ra.err = g->d_resident_state; ra.flags = g->d_resident_state + 4;
-  ra.max_polls = resident_max_polls();
-  ra.iters = iters; ra.with_flux = with_flux;
-  const size_t state_bytes = (((size_t)g->ntiles + 4 + 3) & ~(size_t)3) * sizeof(int);
-  HIP_TRY(hipEventRecord(g->ev_a, st));
-  HIP_TRY(hipMemsetAsync(g->d_resident_state, 0, state_bytes, st));
-  g->main_marked = false;
-  const gg_args a = g->args();
-  HIP_TRY(gg_launch_resident(a, g->grad_view(), g->alt_view(), flux_mode == CFDP_FLUX_REFERENCE, g->ntiles, ra,
-                             g->resident == 2, st));
-  HIP_TRY(hipEventRecord(g->ev_b, st));
-  HIP_TRY(hipEventSynchronize(g->ev_b));
-  if ((iters - 1) & 1) {  // G_k wrote buffer (k - 1) & 1: the last gradients are in the other buffer
-    std::swap(g->d_grad, g->d_grad_alt);
-    std::swap(g->own_grad, g->own_grad_alt);
-  }
-  g->flux_pending = -1;
-  g->resident_runs++;
-  int err[4] = {0, 0, 0, 0};
-  HIP_TRY(hipMemcpy(err, g->d_resident_state, sizeof err, hipMemcpyDeviceToHost));
-  if (err[0])
-    return fail("tile-resident iterations: tile %d gave up waiting for its neighbours' iteration %d (saw %d) -- the grid "
-                "was not fully resident; results are invalid", err[1], err[2], err[3]);
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, g->ev_a, g->ev_b));
-  if (ms_total) *ms_total = ms;
-  return 0;
-}
-
-int cfdp_gpu_set_resident(cfdp_gpu *g, int mode) {
-  if (!g) return fail("null context");
-  if (mode < 0 || mode > 2) return fail("resident mode must be 0 (off), 1 (on where the partition qualifies) or 2 (staleness test)");
-  g->resident = mode;
-  return 0;
-}
-
-// 1: run_iterations would run the tile-resident kernel; 0: it would not, *why says why (static text)
-int cfdp_gpu_resident_qualifies(cfdp_gpu *g, const char **why) {
-  if (!g || !g->uploaded) { if (why) *why = "no plan uploaded"; return 0; }
-  if (hipSetDevice(g->device) != hipSuccess) { if (why) *why = "device"; return 0; }
-  return resident_qualifies(g, why) ? 1 : 0;
-}
-
 // The data-movement floor of the fused pass: the same kernel with neither face loop (a diagnostic instantiation:
 // every load, every store, zeros as results), timed exactly as cfdp_gpu_time_fused times the real pass.  What the
 // real pass takes beyond it is arithmetic and latency its resident tiles do not hide.  Leaves grad / flux holding one
@@ -1024,16 +919,6 @@ static int run_or_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int 
   if (iters < 1) return fail("iters must be >= 1");
   if (with_flux && flux_mode != CFDP_FLUX_CONSISTENT && flux_mode != CFDP_FLUX_REFERENCE)
     return fail("bad flux mode %d", flux_mode);
-  if (g->resident && g->fusion && resident_qualifies(g, nullptr)) {
-    if (!run) return 0;  // nothing to capture: the run is one launch
-    if (run_resident(g, iters, with_flux, flux_mode, ms_total) == 0) return 0;
-    // a neighbour wait gave up: the grid was not co-resident after all (other work on the device: ranks sharing it,
-    // another stream, a profiler).  Say so, switch tile residency off for this context and run the K iterations the
-    // usual way -- every gradient is recomputed from var, so nothing of the failed launch survives
-    fprintf(stderr, "[cfdp] %s -- tile-resident iterations are off for this context from here on; re-running from hipGraphs\n", g_err);
-    g->resident = 0;
-    HIP_TRY(hipDeviceSynchronize());
-  }
   if (flush_flux(g)) return 1;
   hipStream_t st = g->s_main;
   const bool fuse = g->fusion && g->d_grad_alt && with_flux;

@@ -61,12 +61,6 @@ struct cfdp_gpu {
   uint4 *d_blob = nullptr;
   int *d_halo = nullptr, *d_sendidx = nullptr;
   int *d_rowlist = nullptr;     // fixed-stride row lists of the fused pass (gg_args::rowlist), or null
-  // tile-resident iterations (gg_resident_kernel): the neighbour tiles of every tile (owners of its halo rows) and
-  // one block [err: 4 ints][flags: ntiles ints] that is zeroed before every launch; resident: 0 off, 1 on when the
-  // partition qualifies, 2 = the staleness test (G_k stores its rows times 2^(k-1))
-  int *d_nbr_off = nullptr, *d_nbr = nullptr, *d_resident_state = nullptr;
-  int max_nbr = 0, resident = 0;
-  long resident_runs = 0;
   double *d_var = nullptr, *d_grad = nullptr, *d_flux = nullptr,
          *d_sendbuf = nullptr;
   bool own_grad = true, own_sendbuf = true;

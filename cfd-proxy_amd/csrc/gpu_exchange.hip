@@ -588,7 +588,7 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       HIP_TRY(hipMalloc(&I.d_tile_mask, sizeof(unsigned long long) * (smask.size() + 1)));
       if (!smask.empty())
         HIP_TRY(hipMemcpy(I.d_tile_mask, smask.data(), sizeof(unsigned long long) * smask.size(), hipMemcpyHostToDevice));
-      if (const char *j = getenv("CFDP_IPC_JITTER_US")) {
+      if (const char *j = cfdp_experiment_getenv("CFDP_IPC_JITTER_US")) {
         I.jitter_us = atoi(j) > 0 ? atoi(j) : 0;
         if (I.jitter_us) {
           const unsigned seed = 2463534242u ^ (unsigned)(uintptr_t)g ^ (unsigned)getpid() * 2654435761u;
@@ -597,7 +597,7 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
           fprintf(stderr, "[cfdp] TEST MODE: up to %d us of random idle time in front of every step (CFDP_IPC_JITTER_US)\n", I.jitter_us);
         }
       }
-      const char *f = getenv("CFDP_IPC_FAULT");
+      const char *f = cfdp_experiment_getenv("CFDP_IPC_FAULT");
       I.fault_skip_wait = f && !strcmp(f, "skip_wait");
       if (I.fault_skip_wait) fprintf(stderr, "[cfdp] FAULT INJECTION: boundary tiles do not wait for the previous exchange (CFDP_IPC_FAULT)\n");
     }

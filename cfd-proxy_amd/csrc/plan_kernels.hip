@@ -371,7 +371,7 @@ int exclusive_scan(const int *d_in, int n, int *d_out /*[n+1]*/) {
 
 // CFDP_PLAN_FAIL_STAGE=1|5 (tests): the stage fails the way an out-of-memory hipMalloc would
 bool fail_injected(int stage) {
-  const char *e = getenv("CFDP_PLAN_FAIL_STAGE");
+  const char *e = cfdp_experiment_getenv("CFDP_PLAN_FAIL_STAGE");  // honoured only with CFDP_EXPERIMENTS=1
   return e && atoi(e) == stage;
 }
 

@@ -408,7 +408,8 @@ static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P
    * are stored with ONE of them (the lower tile id); the other tile's planes simply do not hold them (its incidence
    * words point past its planes).  What the fused pass and its movement floor take then is an UPPER BOUND on what
    * "cut-face normals owned by one tile, fetched by the other through L2" can gain: the fetch itself is free here. */
-  const int exp_owned = getenv("CFDP_EXP_OWNED_NORMALS") && atoi(getenv("CFDP_EXP_OWNED_NORMALS")) != 0;
+  const char *exp_owned_s = cfdp_experiment_getenv("CFDP_EXP_OWNED_NORMALS"); /* honoured only with CFDP_EXPERIMENTS=1 */
+  const int exp_owned = exp_owned_s && atoi(exp_owned_s) != 0;
   for (int pass = 0; pass < 2; pass++) {
     if (pass == 1) {
       for (int t = 0; t < P->ntiles; t++) {

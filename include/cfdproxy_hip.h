@@ -269,17 +269,6 @@ int  cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mod
  * the pass; a diagnostic instantiation), timed as cfdp_gpu_time_fused times the real one; ms_pass = milliseconds per
  * pass.  grad / flux hold one correct iteration afterwards.                                                       */
 int  cfdp_gpu_time_fused_movement(cfdp_gpu *g, int iters, float *ms_pass);
-/* Tile-resident iterations (small partitions: the strong-scaling regime of the reference, README.txt:39-40 -- "everything
- * lives in cache"; the coarse levels of a V cycle).  mode 1: cfdp_gpu_run_iterations runs ALL its iterations in ONE launch
- * when the partition qualifies -- every tile co-resident on the device (<= 4 workgroups per CU), fused iterations on
- * (run_iterations never exchanges: ghost rows stay as they are): one workgroup per tile stays for the whole run, tile blob in LDS and var rows in registers loaded once,
- * per iteration only the neighbours' 80-byte gradient rows in and the finished rows out; the iteration boundary is a
- * drained-flag hand-off between neighbouring tiles instead of a kernel boundary.  Values: bit-identical.  mode 0 (default):
- * off.  mode 2: test form -- iteration k stores its gradients times 2^(k-1), so that a stale row cannot hide.
- * cfdp_gpu_resident_qualifies: 1, or 0 with *why = static text naming the first condition that fails.  A run whose
- * neighbour wait gives up (the grid was not fully resident after all) fails with an error, it never hangs.     */
-int  cfdp_gpu_set_resident(cfdp_gpu *g, int mode);
-int  cfdp_gpu_resident_qualifies(cfdp_gpu *g, const char **why);
 /* capture + instantiate the graphs cfdp_gpu_run_iterations(g, iters, ...) will replay; nothing
  * executes (keeps the capture out of a caller's timed region)                                  */
 int  cfdp_gpu_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode);

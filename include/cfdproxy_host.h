@@ -15,6 +15,7 @@
 #define CFDPROXY_HOST_H
 
 #include "cfdproxy_dropin.h"
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -188,6 +189,16 @@ void cfdp_fill_var(double (*var)[NGRAD], const int *gid, int npoints, int kind,
                    int nx, int ny, int nz);
 
 const char *cfdp_host_version(void);
+
+/* Experiment switches (host/experiments.c): environment variables that make the library compute something other than
+ * the product path (timing experiments with wrong values, protocol ablations, fault / failure injection, test delays).
+ * cfdp_experiment_getenv(name): the variable's value if it is set AND CFDP_EXPERIMENTS=1, else NULL; says once on
+ * stderr which of the two happened.  cfdp_experiment_switches(): the registered names, space separated.
+ * cfdp_experiments_active(buf, len): how many of them are set with the master key present (what a benchmark must
+ * refuse to report under); buf receives "NAME=value ..." */
+const char *cfdp_experiment_getenv(const char *name);
+const char *cfdp_experiment_switches(void);
+int cfdp_experiments_active(char *buf, size_t len);
 
 #ifdef __cplusplus
 }

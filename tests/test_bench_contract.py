@@ -266,3 +266,64 @@ def test_bench_eight_gpu_code_path_rehearsed_by_four_ranks_on_a_tiny_mesh(gpu):
     assert any(k.startswith("ipc") and v["ok"] for k, v in val.items()), val
     assert out["config"]["exchange_protocol"]["notify"] == "per partner", out["config"]["exchange_protocol"]
     assert wall < 240, wall
+
+
+# ------------------------------------------------------------------ experiment switches are locked out of the product
+def test_experiment_switches_need_the_master_key(pkg):
+    """host/experiments.c: a switch that can make the library compute something other than the product path (wrong
+    values, ablated protocol, injected faults, test delays) is honoured only with CFDP_EXPERIMENTS=1, and says so"""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from __graft_entry__ import load_package\n"
+            "p = load_package(); v = p.host_lib().cfdp_experiment_getenv(b'CFDP_EXP_OWNED_NORMALS')\n"
+            "print('VALUE', v, p.experiments_active())\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("CFDP_")}
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, CFDP_EXP_OWNED_NORMALS="1"), capture_output=True, text=True)
+    assert r.returncode == 0 and "VALUE None []" in r.stdout and "IGNORED" in r.stderr, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, CFDP_EXP_OWNED_NORMALS="1", CFDP_EXPERIMENTS="1"),
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "VALUE b'1' ['CFDP_EXP_OWNED_NORMALS=1']" in r.stdout, r.stdout + r.stderr
+    assert "EXPERIMENT SWITCH ACTIVE: CFDP_EXP_OWNED_NORMALS=1" in r.stderr, r.stderr
+    for name in ("CFDP_EXP_OWNED_NORMALS", "CFDP_DEBUG_ABLATE", "CFDP_IPC_FAULT", "CFDP_PLAN_FAIL_STAGE", "CFDP_IPC_JITTER_US"):
+        assert name in pkg.experiment_switches()
+    # every getenv of a registered switch in the C / HIP sources goes through the gate
+    import glob
+    import re
+    for f in glob.glob(os.path.join(ROOT, "cfd-proxy_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "cfd-proxy_amd", "host", "*")):
+        if f.endswith("experiments.c") or not f.endswith((".c", ".h", ".hip")):
+            continue
+        src = open(f).read()
+        for name in pkg.experiment_switches():
+            assert not re.search(r'[^_]getenv\("%s"\)' % name, src), (f, name)
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_refuses_a_line_under_an_experiment_switch(gpus):
+    """no bench line can come from a run with an experiment switch active: non-zero exit, nothing on stdout -- decided
+    before anything touches the GPU (runs here)"""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("CFDP_") and k != "WORLD_SIZE"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2"],
+                       env=dict(env, CFDP_EXPERIMENTS="1", CFDP_DEBUG_ABLATE="256"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and not r.stdout.strip() and "refusing" in r.stderr and "CFDP_DEBUG_ABLATE=256" in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+def test_experiment_switch_without_the_master_key_changes_nothing(gpu):
+    """CFDP_EXP_OWNED_NORMALS=1 (the cut-face-normals experiment: values WRONG) and CFDP_DEBUG_ABLATE without
+    CFDP_EXPERIMENTS=1: the plan, the gradients and the flux are those of the product, bit for bit; with the key the
+    experiment really is on (the values differ) -- so the first half of this test is not vacuous"""
+    code = ("import sys, os, hashlib; sys.path.insert(0, %r)\n"
+            "os.environ['CFDP_PLAN_DEVICE'] = '1'\n"
+            "from __graft_entry__ import load_package\n"
+            "p = load_package(); d = p.gen_domain(p.gen_params(20, 18, 16, ndomains=1), 0); p.fill_var(d, None, p.VAR_HASH)\n"
+            "g = p.GpuPartition(d); g.set_fusion(True); g.run_iterations(3, True, 0, use_graph=False); g.pull_fields()\n"
+            "print('HASH', hashlib.sha256(d.grad.tobytes() + d.psd_flux.tobytes()).hexdigest())\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("CFDP_")}
+    def run(extra):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(env, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return [l for l in r.stdout.splitlines() if l.startswith("HASH")][-1], r.stderr
+    clean, _ = run({})
+    locked, err = run({"CFDP_EXP_OWNED_NORMALS": "1", "CFDP_DEBUG_ABLATE": "64"})
+    assert locked == clean and "IGNORED" in err, err
+    live, err = run({"CFDP_EXP_OWNED_NORMALS": "1", "CFDP_EXPERIMENTS": "1"})
+    assert live != clean and "EXPERIMENT SWITCH ACTIVE" in err, err

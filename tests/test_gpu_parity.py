@@ -876,117 +876,6 @@ def test_movement_only_instantiation_is_a_floor_and_leaves_real_values(gpu):
     dom.free()
 
 
-# ------------------------------------------------------------------ tile-resident iterations (one launch for K iterations)
-def _resident_case(pkg, which):
-    """partitions whose tiles are all co-resident on the device"""
-    from cfd_proxy_amd import multigpu as mg
-    if which == "whole 40x32x32":
-        dom = pkg.gen_domain(pkg.gen_params(40, 32, 32, ndomains=1), 0)
-        pkg.fill_var(dom, None, pkg.VAR_HASH)
-        return dom
-    name, world = which
-    cfg = mg.bench_config(name, world)
-    gp = pkg.gen_params(*cfg["dims"], ndomains=cfg["ndomains"])
-    parts = [mg.build_rank_partition(gp, cfg["ndomains"], world, r, via_files=False)[0] for r in range(world)]
-    reqs = [{int(k): (v[0], v[1]) for k, v in pkg.merge_requests(p).items()} for p in parts]
-    mg.exchange_requests(parts[0], 0, world, None, all_requests=reqs)
-    for p in parts[1:]:
-        p.free()
-    return parts[0]
-
-
-@pytest.mark.parametrize("which", ["whole 40x32x32", ("dualgrid.192", 8), ("dualgrid.384", 8)])
-@pytest.mark.parametrize("flux_mode", [0, 1])
-def test_tile_resident_iterations_are_bit_identical(gpu, which, flux_mode):
-    """K iterations in ONE launch (one workgroup per tile stays; the iteration boundary is a drained-flag hand-off
-    between neighbouring tiles) against the fused one-launch-per-pass path: gradients and flux bit for bit, for a
-    whole small mesh and for rank 0's partition of the 192-domain / 8-rank decomposition (BASELINE config 4:
-    iterations without exchange, ghost rows as they are).  Rank 0 of dualgrid.384 / 8 (4096+ tiles) does not qualify:
-    there the mode must leave the run to the one-launch-per-pass path, with the same values"""
-    pkg = gpu
-    dom = _resident_case(pkg, which)
-    rng = np.random.default_rng(11)
-    dom.grad[:] = rng.normal(size=dom.grad.shape)  # (ghost rows of a partition with partners: arbitrary but fixed)
-    # flux_lanes=4: the run's LAST flux comes from the separate flux kernel in the one-launch-per-pass path; with 4 lanes
-    # per point it splits a point's faces over lanes exactly as the flux phase of the fused pass (and of the resident
-    # kernel) does, so even that last flux is bit-identical (the default 8-lane kernel differs by rounding only)
-    g = pkg.GpuPartition(dom, flux_lanes=4)
-    g.set_fusion(True)
-    ok, why = g.resident_qualifies()
-    assert ok == (which != ("dualgrid.384", 8)), why
-    for K in (1, 2, 7, 40):
-        g.set_resident(0)
-        g.push_fields()
-        g.run_iterations(K, True, flux_mode, use_graph=True)
-        g.pull_fields()
-        g0, f0 = dom.grad.copy(), dom.psd_flux.copy()
-        dom.grad[: dom.nown] = -3.0
-        dom.psd_flux[:] = -3.0
-        g.push_fields()
-        g.set_resident(1)
-        g.run_iterations(K, True, flux_mode, use_graph=True)
-        g.pull_fields()
-        assert np.array_equal(dom.grad, g0), (which, K)
-        assert np.array_equal(dom.psd_flux[: dom.nown], f0[: dom.nown]), (which, K)
-        assert np.abs(g0[: dom.nown]).max() > 0 and np.abs(f0[: dom.nown]).max() > 0
-        dom.grad[:] = g0  # the next K starts from the same ghost rows
-    g.close()
-    dom.free()
-
-
-def test_tile_resident_iterations_never_read_a_stale_row(gpu):
-    """the benchmark's field is constant, so a row left over from two iterations ago (same buffer, same address) has
-    the same VALUE as the fresh one and could hide.  Test form of the kernel: iteration k stores its gradients times
-    2^(k-1) (exact), so its flux must be the true flux times 2^(k-1) EXACTLY -- a tile that read a neighbour's row of
-    iteration k-2 would be off by a factor of 4 in that neighbour's terms.  512 co-resident tiles, 33 iterations,
-    repeated, while a second stream keeps the memory system busy"""
-    pkg = gpu
-    dom = pkg.gen_domain(pkg.gen_params(32, 32, 32, ndomains=1), 0)
-    pkg.fill_var(dom, None, pkg.VAR_HASH)
-    g = pkg.GpuPartition(dom, flux_lanes=4)  # (the lane split of the fused / resident flux phase: see the test above)
-    g.set_fusion(True)
-    g.run_iterations(1, True, 0, use_graph=False)
-    g.pull_fields()
-    g1, f1 = dom.grad.copy(), dom.psd_flux.copy()
-    g.set_resident(2)
-    import torch
-    noise = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
-    side = torch.cuda.Stream()
-    for rep in range(6):
-        K = 33 - rep
-        with torch.cuda.stream(side):
-            for _ in range(20):
-                noise.add_(1.0)  # uneven load beside the resident kernel
-        g.run_iterations(K, True, 0, use_graph=True)
-        g.pull_fields()
-        assert np.array_equal(dom.grad[: dom.nown], np.ldexp(g1[: dom.nown], K - 1)), (rep, K)
-        assert np.array_equal(dom.psd_flux[: dom.nown], np.ldexp(f1[: dom.nown], K - 1)), (rep, K)
-    torch.cuda.synchronize()
-    g.close()
-    dom.free()
-
-
-def test_tile_resident_mode_leaves_large_partitions_to_the_graph_path(gpu):
-    """a partition with more tiles than the device holds workgroups does not qualify (and says why); run_iterations
-    then runs the one-launch-per-pass path as before"""
-    pkg = gpu
-    dom = pkg.gen_domain(pkg.gen_params(64, ndomains=1), 0)
-    pkg.fill_var(dom, None, pkg.VAR_HASH)
-    g = pkg.GpuPartition(dom)
-    g.set_fusion(True)
-    ok, why = g.resident_qualifies()
-    assert not ok and "more tiles than the device holds" in why, why
-    g.run_iterations(3, True, 0, use_graph=True)
-    g.pull_fields()
-    g0 = dom.grad.copy()
-    g.set_resident(1)
-    g.run_iterations(3, True, 0, use_graph=True)
-    g.pull_fields()
-    assert np.array_equal(dom.grad, g0)
-    g.close()
-    dom.free()
-
-
 # ------------------------------------------------------------------ BASELINE.json configs 3-5
 @pytest.mark.parametrize("label,n,nd,G", [
     ("dualgrid.48 lvl 2 on 4 ranks", 64, 48, 4),
@@ -1171,9 +1060,11 @@ def test_device_plan_stage_that_fails_hands_over_to_the_host_stage(gpu, stage, m
     pkg = gpu
     d = pkg.gen_domain(pkg.gen_params(20, 18, 16, ndomains=1), 0)
     host = pkg.Plan(d, tile_points=64)
+    monkeypatch.setenv("CFDP_EXPERIMENTS", "1")  # the master key of every experiment switch (host/experiments.c)
     monkeypatch.setenv("CFDP_PLAN_FAIL_STAGE", str(stage))
     dev = pkg.Plan(d, tile_points=64, device_stages=3)
     monkeypatch.delenv("CFDP_PLAN_FAIL_STAGE")
+    monkeypatch.delenv("CFDP_EXPERIMENTS")
     a, b = _plan_bytes(pkg, host), _plan_bytes(pkg, dev)
     for k in a:
         assert a[k] == b[k], (stage, k)

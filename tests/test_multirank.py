@@ -86,7 +86,7 @@ def test_multirank_xgmi_write_notify_under_random_skew(gpu):
     front of every step -- drawn on the device, so every hipGraph replay draws new delays (CFDP_IPC_JITTER_US): the ranks
     drift against each other step by step, and a hole in the wait / notify / double-buffer protocol that lockstep runs never
     hit would show up in the scaled-field soak (400 steps) and in the value checks of every schedule"""
-    env = {"CFDP_IPC_WAIT_INKERNEL": "1", "CFDP_IPC_JITTER_US": "40"}
+    env = {"CFDP_IPC_WAIT_INKERNEL": "1", "CFDP_IPC_JITTER_US": "40", "CFDP_EXPERIMENTS": "1"}
     _launch(3, ["--gpu", "--transport", "ipc", "--files", "--soak", "400"], extra_env=env)
     _launch(4, ["--gpu", "--transport", "ipc", "--dims", "16,16,12", "--ndomains", "8", "--soak", "400"], extra_env=env)
 
@@ -112,7 +112,8 @@ def test_scaled_field_check_sees_a_ghost_row_read_one_exchange_early(gpu, world,
     The scaled-field check (var x 2, 2, 1/4 per iteration, the flux of every step compared on the device) must FAIL
     it.  Reference analogue: the stage / flag lock-step asserts at every receive, src/exchange_data_mpi.c:189,439."""
     extra = ["--gpu", "--inject-early-read"] + (["--dims", "16,16,12", "--ndomains", "8"] if world == 4 else [])
-    _launch(world, extra, extra_env={"CFDP_IPC_FAULT": "skip_wait", "CFDP_IPC_MODE": mode, "CFDP_IPC_WAIT_INKERNEL": "1"})
+    _launch(world, extra, extra_env={"CFDP_IPC_FAULT": "skip_wait", "CFDP_EXPERIMENTS": "1", "CFDP_IPC_MODE": mode,
+                                    "CFDP_IPC_WAIT_INKERNEL": "1"})
 
 
 @pytest.mark.gpu

@@ -13,6 +13,7 @@ for n in [int(x) for x in sys.argv[1:]] or [64, 128]:
     dom = pkg.gen_domain(gp, 0)
     pkg.fill_var(dom, None, pkg.VAR_HASH)
     for exp in ("0", "1", "0", "1"):
+        os.environ["CFDP_EXPERIMENTS"] = "1"
         os.environ["CFDP_EXP_OWNED_NORMALS"] = exp
         part = pkg.GpuPartition(dom)
         part.set_fusion(True)

@@ -21,6 +21,7 @@ def timed(g, steps, **kw):
 for label, bits in (("everything", 0), ("no wait", 0x100), ("no row pushes", 0x200), ("no wait, no counting/flags", 0x500),
                     ("no wait, no pushes, no counting", 0x700), ("no wait, no per-slot atomics/flags", 0x900),
                     ("no wait, no drain+barrier", 0x1100), ("no wait, neither", 0x1900)):
+    os.environ["CFDP_EXPERIMENTS"] = "1"
     os.environ["CFDP_DEBUG_ABLATE"] = str(bits)
     g = pkg.GpuPartition(part)
     g.set_fusion(True)

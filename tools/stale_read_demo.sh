@@ -3,7 +3,7 @@
 # Prints what the old checks (final states) and the scaled-field check say about that broken path.
 PORT=${PORT:-29571}
 for r in 0 1; do
-  RANK=$r LOCAL_RANK=$r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT OMP_NUM_THREADS=2 CFDP_IPC_FAULT=skip_wait CFDP_IPC_WAIT_INKERNEL=1 CFDP_IPC_MODE=${1:-coarse} \
+  RANK=$r LOCAL_RANK=$r WORLD_SIZE=2 MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT OMP_NUM_THREADS=2 CFDP_EXPERIMENTS=1 CFDP_IPC_FAULT=skip_wait CFDP_IPC_WAIT_INKERNEL=1 CFDP_IPC_MODE=${1:-coarse} \
     python tests/_rank_worker.py --gpu --inject-early-read > gpurun_out/stale_demo_r$r.log 2>&1 &
 done
 wait
