@@ -265,6 +265,14 @@ def main() -> None:
         if world > 1 and args.transport == "auto":
             solver.choose_transport()
             tl = lap(f"{tag}: transport probe", tl)
+        # can rank 0's device reach the devices it sees (by bus id)?  A launcher that shows every rank one device leaves
+        # only the device itself here; the IPC mappings of the write + notify exchange do not depend on it
+        peer_row = {}
+        try:
+            for j in range(ndev):
+                peer_row[pkg.device_bus_id(j)] = True if j == device else bool(torch.cuda.can_device_access_peer(device, j))
+        except Exception as e:
+            peer_row = {"error": repr(e)[:120]}
         t_setup = time.time() - t0
 
         def barrier():
@@ -380,7 +388,15 @@ def main() -> None:
                 "mesh_iterations_per_s": its, "via_dualgrid_files": not args.no_files,
                 "tiles": solver.gpu.stats["ntiles"], "tile_points": solver.gpu.stats["tile_points"],
                 "setup_s": round(t_setup, 2),
+                # WHICH hardware the ranks ran on (PCI bus ids gathered from every rank; what the RCCL communicator itself
+                # counts): a rehearsal on a shared device can never be read as a scaling point
+                "device_of_rank": solver.census["device_of_rank"], "distinct_devices": solver.census["distinct_devices"],
+                "ranks_per_device": solver.census["ranks_per_device"],
+                "rccl_nranks": (solver.gpu.rccl_nranks() or None) if world > 1 else None,
+                "process_group": {"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist is not None else None,
+                "peer_access_of_rank0": peer_row,
             },
+            "shared_gpu": bool(solver.census["shared_gpu"]),
         }
         if world > 1:
             res["exchange_check"] = chk
@@ -419,6 +435,10 @@ def main() -> None:
     out["config"]["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("CFDP_")}
     if role != world:
         out["config"]["rehearsal"] = f"{world} ranks standing in for the {role}-GPU line (CFDP_BENCH_AS_GPUS)"
+    out["shared_gpu"] = res["shared_gpu"]
+    if res["shared_gpu"]:
+        out["shared_gpu_note"] = (f"{world} ranks on {out['config']['distinct_devices']} device(s): a rehearsal of the code path; "
+                                  f"rates and scaling mean nothing")
     for k in ("clock_conditioning", "exchange_check", "overlap"):
         if k in res:
             out[k] = res[k]
@@ -536,8 +556,6 @@ def main() -> None:
         # (cfdp_gpu_ipc_connect_loopback: wrong ghost values, right traffic, right protocol).  comm_free / with_exchange is an
         # UPPER bound of the overlap efficiency a rank with a GPU of its own can reach (DESIGN appendix C.4)
         t_lb = lap("finest level", t_phase)
-        mode0 = os.environ.get("CFDP_IPC_MODE")
-        os.environ.setdefault("CFDP_IPC_MODE", mg.ipc_mode_attempts()[0])  # the memory mode the hosts try first
         try:
             lb = {}
             for name in ("dualgrid.384", "dualgrid.192"):
@@ -546,35 +564,68 @@ def main() -> None:
                 parts8 = [mg.build_rank_partition(gp8, c8["ndomains"], 8, r, via_files=False)[0] for r in range(8)]
                 reqs = [{int(k): (v[0], v[1]) for k, v in pkg.merge_requests(p).items()} for p in parts8]
                 mg.exchange_requests(parts8[0], 0, 8, None, all_requests=reqs)
-                g8 = pkg.GpuPartition(parts8[0], device=device)
-                g8.set_fusion(True)
-                g8.ipc_export()
-                for s_ in range(len(g8.partners())):
-                    g8._ck(g8.lib.cfdp_gpu_ipc_connect_loopback(g8.h, s_))
-                g8.ipc_ready()
 
-                def lb_time(steps, reps, **kw):
-                    g8.run_steps_ipc(200, **kw)
-                    g8.sync()
+                def lb_time(run, sync, steps, reps, **kw):
+                    run(200 if steps >= 200 else 3 * steps, **kw)
+                    sync()
                     best = float("inf")
                     for _ in range(reps):
                         t_ = time.perf_counter()
-                        g8.run_steps_ipc(steps, **kw)
-                        g8.sync()
+                        run(steps, **kw)
+                        sync()
                         best = min(best, (time.perf_counter() - t_) / steps)
                     return best * 1e6
-                free = lb_time(1000, 3, with_exchange=False, overlap=True)
-                exch = lb_time(1000, 3, with_exchange=True, overlap=True)
-                free20 = lb_time(20, 5, with_exchange=False, overlap=True)
-                exch20 = lb_time(20, 5, with_exchange=True, overlap=True)
-                lb[name] = {"partition": f"rank 0 of 8: {parts8[0].nown} points, {len(g8.partners())} partners, "
-                                         f"{g8.stats['nbtiles']} boundary tiles of {g8.stats['ntiles']}",
-                            "us_per_iteration_comm_free": free, "us_per_iteration_with_exchange": exch,
-                            "efficiency_bound": free / exch, "steps20_comm_free": free20, "steps20_with_exchange": exch20,
-                            "steps20_ratio": free20 / exch20, "wait_timeouts": int(g8.ipc_error() != 0),
-                            "protocol": g8.ipc_mode()}
-                g8.ipc_disconnect()
-                g8.close()
+
+                def loopback(notify):
+                    """one row of the table: the memory mode the hosts try first, the given notification form"""
+                    g8 = pkg.GpuPartition(parts8[0], device=device)
+                    g8.set_fusion(True)
+                    g8.ipc_configure(memory_mode=mg.ipc_mode_attempts()[0], notify=notify)
+                    g8.ipc_export()
+                    for s_ in range(len(g8.partners())):
+                        g8._ck(g8.lib.cfdp_gpu_ipc_connect_loopback(g8.h, s_))
+                    g8.ipc_ready()
+                    run = lambda n, **kw: g8.run_steps_ipc(n, use_graph=2, **kw)
+                    free = lb_time(run, g8.sync, 1000, 3, with_exchange=False, overlap=True)
+                    exch = lb_time(run, g8.sync, 1000, 3, with_exchange=True, overlap=True)
+                    free20 = lb_time(run, g8.sync, 20, 7, with_exchange=False, overlap=True)
+                    exch20 = lb_time(run, g8.sync, 20, 7, with_exchange=True, overlap=True)
+                    row = {"partition": f"rank 0 of 8: {parts8[0].nown} points, {len(g8.partners())} partners, "
+                                        f"{g8.stats['nbtiles']} boundary tiles of {g8.stats['ntiles']}",
+                           "us_per_iteration_comm_free": free, "us_per_iteration_with_exchange": exch,
+                           "efficiency_bound": free / exch, "steps20_comm_free": free20, "steps20_with_exchange": exch20,
+                           "steps20_ratio": free20 / exch20, "wait_timeouts": int(g8.ipc_error() != 0),
+                           "graph_replay": g8.ipc_graph_stats(), "protocol": g8.ipc_mode()}
+                    g8.ipc_disconnect()
+                    g8.close()
+                    return row
+                lb[name] = loopback("counter")
+                flag = loopback("flag")
+                lb[name]["flag_notification"] = {k: flag[k] for k in ("us_per_iteration_with_exchange", "efficiency_bound",
+                                                                       "steps20_with_exchange", "steps20_ratio", "wait_timeouts")}
+                # the fall-back branch priced on the same partition: grouped ncclSend / ncclRecv issued by the C library from
+                # the streams (RCCL cannot be captured into a hipGraph in this ROCm: replay hangs), a communicator of ONE rank
+                # exchanging with itself -- pack kernel + RCCL kernel + stream launches per iteration, no link crossed
+                try:
+                    g8 = pkg.GpuPartition(parts8[0], device=device)
+                    g8.set_fusion(True)
+                    rlib = mg.RankSolver.torch_rccl_path()
+                    g8.rccl_init(pkg.GpuPartition.rccl_unique_id(rlib), 1, 0, rank_of_partner=[0] * len(g8.partners()), libpath=rlib)
+                    run = lambda n, **kw: g8.run_steps_rccl(n, **kw)
+                    rfree = lb_time(run, g8.sync, 500, 2, with_exchange=False, overlap=True)
+                    rexch = lb_time(run, g8.sync, 500, 2, with_exchange=True, overlap=True)
+                    rfree20 = lb_time(run, g8.sync, 20, 5, with_exchange=False, overlap=True)
+                    rexch20 = lb_time(run, g8.sync, 20, 5, with_exchange=True, overlap=True)
+                    lb[name]["rccl_self_sendrecv"] = {
+                        "us_per_iteration_comm_free_stream_launched": rfree, "us_per_iteration_with_exchange": rexch,
+                        "steps20_comm_free_stream_launched": rfree20, "steps20_with_exchange": rexch20,
+                        "efficiency_bound_vs_graph_replayed_comm_free": lb[name]["us_per_iteration_comm_free"] / rexch,
+                        "steps20_ratio_vs_graph_replayed_comm_free": lb[name]["steps20_comm_free"] / rexch20,
+                        "rccl_nranks": g8.rccl_nranks(),
+                        "note": "communicator of one rank, every partner mapped to itself; steps launched from the streams"}
+                    g8.close()
+                except Exception as e:
+                    lb[name]["rccl_self_sendrecv"] = {"error": repr(e)[:200]}
                 for p8 in parts8:
                     p8.free()
             lb["note"] = ("ONE GPU, every partner slot looped back to the rank's own arenas and flags: the protocol's own cost with a "
@@ -582,8 +633,6 @@ def main() -> None:
             out["exchange_protocol_loopback"] = lb
         except Exception as e:  # never costs the line
             out["exchange_protocol_loopback"] = {"error": repr(e)[:300]}
-        if mode0 is None:
-            os.environ.pop("CFDP_IPC_MODE", None)
         t_phase = lap("exchange protocol in loopback", t_lb)
     # ---- CPU baseline on rank 0's host cores, at every N: the COMPILED REFERENCE (oracle/_ref/ref_dump_raw: the
     # reference's own OpenMP path, src/solver.c:42-58 comm_free loop + flux) when the binary is there,

@@ -269,6 +269,11 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_ipc_export_flags.argtypes = [vp, vp]
     lib.cfdp_gpu_ipc_connect_flags.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.cfdp_gpu_ipc_mode.argtypes = [vp]
+    lib.cfdp_gpu_ipc_graph_stats.argtypes = [vp, P(C.c_long), P(C.c_long), P(C.c_long)]
+    lib.cfdp_gpu_ipc_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.cfdp_gpu_rccl_nranks.argtypes = [vp]
+    lib.cfdp_gpu_device.argtypes = [vp]
+    lib.cfdp_gpu_device_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     lib.cfdp_gpu_ipc_connect_loopback.argtypes = [vp, C.c_int]
     lib.cfdp_gpu_ipc_enable.argtypes = [vp, C.c_int]
     lib.cfdp_gpu_ipc_disconnect.argtypes = [vp]
@@ -568,6 +573,14 @@ def merge_scatter(part: Domain, dl: int, npoints_d: int, field: np.ndarray) -> n
     return out
 
 
+def device_bus_id(device: int) -> str:
+    """PCI bus id of a visible device: the same string in every process that sees the same physical device"""
+    buf = C.create_string_buffer(64)
+    if hip_lib().cfdp_gpu_device_bus_id(int(device), buf, len(buf)):
+        raise RuntimeError(hip_lib().cfdp_gpu_last_error().decode())
+    return buf.value.decode()
+
+
 def experiment_switches() -> list:
     """the environment variables host/experiments.c gates behind CFDP_EXPERIMENTS=1 (not the product path)"""
     return host_lib().cfdp_experiment_switches().decode().split()
@@ -769,6 +782,10 @@ class GpuPartition:
             rp = (C.c_int * len(rank_of_partner))(*rank_of_partner)
         self._ck(self.lib.cfdp_gpu_rccl_init(self.h, C.create_string_buffer(unique_id, 128), nranks, rank, rp))
 
+    def rccl_nranks(self) -> int:
+        """what ncclCommCount says about this context's communicator (0: none)"""
+        return int(self.lib.cfdp_gpu_rccl_nranks(self.h))
+
     def step_rccl(self, with_exchange=True, overlap=True, with_flux=True, flux_mode: int = FLUX_CONSISTENT) -> None:
         self._ck(self.lib.cfdp_gpu_step_rccl(self.h, int(with_exchange), int(overlap), int(with_flux), flux_mode))
 
@@ -803,7 +820,24 @@ class GpuPartition:
             return {}
         return {"push": "in the fused pass" if m & 1 else "push kernel", "wait": "in the fused pass" if m & 2 else "wait kernel",
                 "notify": "per partner" if m & 4 else "all partners by the last boundary tile",
+                "notify_by": "counters (fire-and-forget atomic adds)" if m & 8 else "flags",
                 "memory": ("coarse-grained", "fine-grained", "split: fine-grained flags, coarse-grained arenas")[(m >> 4) & 3]}
+
+    IPC_MODES = {"coarse": 0, "fine": 1, "split": 2}
+
+    def ipc_configure(self, memory_mode=None, wait_inkernel=None, notify=None) -> None:
+        """cfdp_gpu_ipc_configure: memory_mode "coarse" | "fine" | "split", wait_inkernel bool, notify "counter" | "flag";
+        None = what the environment says, else the library default.  Takes effect at the next ipc_export / ipc_ready"""
+        self._ck(self.lib.cfdp_gpu_ipc_configure(
+            self.h, -1 if memory_mode is None else self.IPC_MODES[memory_mode],
+            -1 if wait_inkernel is None else int(bool(wait_inkernel)),
+            -1 if notify is None else {"counter": 1, "flag": 0}[notify]))
+
+    def ipc_graph_stats(self) -> dict:
+        """steps of run_steps_ipc replayed from hipGraphs / launched from the streams, captures abandoned"""
+        a, b, c = C.c_long(), C.c_long(), C.c_long()
+        self._ck(self.lib.cfdp_gpu_ipc_graph_stats(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"steps_replayed": a.value, "steps_streamed": b.value, "captures_failed": c.value}
 
     def ipc_ready(self) -> None:
         self._ck(self.lib.cfdp_gpu_ipc_ready(self.h))

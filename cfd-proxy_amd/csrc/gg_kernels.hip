@@ -367,6 +367,13 @@ __device__ __forceinline__ void push_tile_rows(const gg_push_args &pa, int tile,
   }
 }
 
+// exchanges this rank has announced so far, read once at the top of a boundary tile: the word only moves past a multiple
+// (flag form: at all) when the LAST boundary tile of a launch has finished, i.e. after every tile's read here
+__device__ __forceinline__ int exchanges_so_far(const gg_push_args &pa) {
+  if (pa.need && pa.counters) return (int)((unsigned)pa.hdr[GG_IPC_TILES] / (unsigned)pa.nbtiles);
+  return pa.hdr[GG_IPC_ITER];
+}
+
 // The wait for the previous exchange, at the top of a boundary tile of the next pass (see gg_push_args::
 // wait_polls; the protocol is gg_wait_kernel's).  iter0 = hdr[GG_IPC_ITER] = exchanges this rank has announced so
 // far, read once at the top of the pass: it only changes when the LAST boundary tile of a launch has finished, i.e.
@@ -378,10 +385,15 @@ __device__ __forceinline__ void push_tile_rows(const gg_push_args &pa, int tile,
 // in their arena of the same parity (a partner raises its flag k towards this rank only when all its tiles that hold
 // send rows for -- hence may read ghost rows from -- this rank have finished pass k).
 __device__ __forceinline__ void wait_previous_exchange(const gg_push_args &pa, int tile, int tid, int iter0) {
-  if (!pa.tile_off || pa.wait_polls <= 0 || tile >= pa.nbtiles) return;  // uniform per workgroup
-  const bool mine = tid < pa.nslots && (!pa.need || ((pa.tile_mask[tile] >> tid) & 1ull));
+  if (!pa.tile_off || tile >= pa.nbtiles) return;  // uniform per workgroup
+  // (a pass whose wait has been settled by the wait kernel -- ranks sharing a device, CFDP_IPC_WAIT_INKERNEL=0 -- still
+  // owes split mode its invalidate below: the wait kernel's acquire touched its own CU and XCD only)
+  if (pa.wait_polls <= 0 && !pa.inv_after_flag) return;
+  const bool mine = pa.wait_polls > 0 && tid < pa.nslots && (!pa.need || ((pa.tile_mask[tile] >> tid) & 1ull));
   if (mine && !pa.hdr[GG_IPC_ERR]) {
-    const int need = iter0;
+    // flag notification: partner s has stored its exchange number.  Counter notification: s's boundary tiles have each
+    // added 1 for every exchange they completed for this rank, NEED_IN of them per exchange (compared wrap-safe)
+    const int need = pa.counters ? iter0 * __hip_atomic_load(&pa.hdr[GG_IPC_NEED_IN + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : iter0;
     bool ok = false;
     // RELAXED system-scope polls (global_load_dword ... sc0 sc1, past every cache): an acquire per poll is a cache
     // invalidate per poll (MI355X_MICROARCH.md: polling with acquire loads is 2-3x slower per hop and many pollers cut
@@ -389,7 +401,7 @@ __device__ __forceinline__ void wait_previous_exchange(const gg_push_args &pa, i
     // for is itself a system-scope load (glds16_sys / the generic flux kernel's atomic loads), issued after this poll
     // has returned (the loop exit depends on its value) and, for the other waves, behind the barrier below.
     for (long k = 0; k < pa.wait_polls && !ok; k++) {
-      ok = __hip_atomic_load(&pa.hdr[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= need;
+      ok = (int)((unsigned)__hip_atomic_load(&pa.hdr[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)need) >= 0;
       if (!ok) __builtin_amdgcn_s_sleep(32);
     }
     if (!ok) {  // bounded: a lost partner must not hang the device.  Leave what was seen for the post-mortem.
@@ -423,6 +435,18 @@ __device__ __forceinline__ void push_tile_done(const gg_push_args &pa, int tile,
     __syncthreads();
   }
   const int it = iter0 + 1;
+  if (pa.need && pa.counters) {
+    // counter notification: nothing comes back to the tile.  Lane s adds 1 to partner s's counter word (a no-return
+    // system-scope atomic: fire and forget), lane 0 counts the tile for this rank's own exchange count -- the next pass
+    // reads TILES / nbtiles at its top, behind the kernel boundary that completes every atomic of this one.  Takes the two
+    // dependent device-scope atomics of the flag form (2-3 us each under load) off the boundary tile's critical path; the
+    // reference's notification travels with the write as well (gaspi_write_notify, src/exchange_data_gaspi.c:134-145).
+    if (!(dbg & 0x800) && tid < pa.nslots && ((pa.tile_mask[tile] >> tid) & 1ull))
+      // (the pointer comes out of a table: say that it is global memory, or the add is a flat_ instruction)
+      (void)__hip_atomic_fetch_add((__attribute__((address_space(1))) int *)pa.rflag[tid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) (void)__hip_atomic_fetch_add(&pa.hdr[GG_IPC_TILES], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   if (pa.need) {  // lane s of wave 0 looks after partner slot s (at most GG_IPC_MAXSLOTS = 48 of them)
     if (!(dbg & 0x800) && tid < pa.nslots && ((pa.tile_mask[tile] >> tid) & 1ull)) {
       // (the flag store depends on the value the add returns: it is issued after every earlier tile's count -- and so
@@ -807,7 +831,7 @@ void gg_fused_dma_kernel(
   const cfdp_tile_desc td = tiles[t];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
-  const int iter0 = pa.tile_off && t < pa.nbtiles ? pa.hdr[GG_IPC_ITER] : 0;  // uniform: a scalar load
+  const int iter0 = pa.tile_off && t < pa.nbtiles ? exchanges_so_far(pa) : 0;  // uniform: scalar loads
   wait_previous_exchange(pa, t, tid, iter0);  // before any ghost row is requested
   unsigned long long pfirst = ~0ull;  // see gg_fused_split_kernel
   if (pa.tile_off && t < pa.nbtiles) pfirst = ld_u64_nowait(pa.pt_first + (size_t)t * pa.pt_stride + (tid >> 2));
@@ -945,7 +969,7 @@ void gg_fused_split_kernel(
   int iter0 = 0;
   unsigned long long pfirst = ~0ull;  // {partner slot or -1, row}: where this lane's point goes first (boundary tiles)
   if constexpr (PUSH) {
-    if (pa.tile_off && t < pa.nbtiles) iter0 = pa.hdr[GG_IPC_ITER];  // uniform: a scalar load
+    if (pa.tile_off && t < pa.nbtiles) iter0 = exchanges_so_far(pa);  // uniform: scalar loads
     if (!(dbg & 0x100)) wait_previous_exchange(pa, t, tid, iter0);  // before any ghost row is requested
     if (pa.tile_off && t < pa.nbtiles) pfirst = ld_u64_nowait(pa.pt_first + (size_t)t * pa.pt_stride + (tid >> 2));
   }
@@ -1092,7 +1116,16 @@ __global__ __launch_bounds__(256) void gg_push_kernel(const int *__restrict__ se
 
 // hdr: [0..GG_IPC_MAXSLOTS) arrival counters written by the partners, [GG_IPC_ITER] this rank's
 // iteration counter, [GG_IPC_ERR] set when a wait gave up
-__global__ void gg_notify_kernel(int *__restrict__ hdr, int *const *__restrict__ remote_flag, int nslots) {
+// need != nullptr: counter notification -- the whole exchange at once: need[s] tiles' worth to partner s's counter,
+// nbtiles to this rank's own count (the separate push kernel has stored every row before this kernel starts)
+__global__ void gg_notify_kernel(int *__restrict__ hdr, int *const *__restrict__ remote_flag, int nslots,
+                                 const int *__restrict__ need, int nbtiles) {
+  if (need) {
+    if ((int)threadIdx.x < nslots)
+      (void)__hip_atomic_fetch_add(remote_flag[threadIdx.x], need[threadIdx.x], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&hdr[GG_IPC_TILES], nbtiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   const int it = hdr[GG_IPC_ITER] + 1;
   __syncthreads();
   if ((int)threadIdx.x < nslots)
@@ -1100,12 +1133,14 @@ __global__ void gg_notify_kernel(int *__restrict__ hdr, int *const *__restrict__
   if (threadIdx.x == 0) hdr[GG_IPC_ITER] = it;
 }
 
-__global__ void gg_wait_kernel(int *__restrict__ hdr, int nslots, long max_polls) {
+__global__ void gg_wait_kernel(int *__restrict__ hdr, int nslots, long max_polls, int nbtiles) {
   if ((int)threadIdx.x >= nslots) return;
   if (hdr[GG_IPC_ERR]) return;  // a wait has given up before: the run is void anyway, do not stall every step
-  const int need = hdr[GG_IPC_ITER];
+  const int need = nbtiles > 0 ? (int)((unsigned)hdr[GG_IPC_TILES] / (unsigned)nbtiles) *
+                                     __hip_atomic_load(&hdr[GG_IPC_NEED_IN + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                               : hdr[GG_IPC_ITER];
   for (long k = 0; k < max_polls; k++) {
-    if (__hip_atomic_load(&hdr[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= need) return;
+    if ((int)((unsigned)__hip_atomic_load(&hdr[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)need) >= 0) return;
     __builtin_amdgcn_s_sleep(32);  // ~1 us between polls: the flag line is not hammered
   }
   // bounded: a lost partner must not hang the device.  Leave what was seen for the post-mortem.
@@ -1232,12 +1267,12 @@ hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row
                      grad.a, grad.b, dst);
   return hipGetLastError();
 }
-hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, hipStream_t stream) {
-  hipLaunchKernelGGL(gg_notify_kernel, dim3(1), dim3(64), 0, stream, hdr, remote_flag, nslots);
+hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, const int *need, int nbtiles, hipStream_t stream) {
+  hipLaunchKernelGGL(gg_notify_kernel, dim3(1), dim3(64), 0, stream, hdr, remote_flag, nslots, need, nbtiles);
   return hipGetLastError();
 }
-hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, hipStream_t stream) {
-  hipLaunchKernelGGL(gg_wait_kernel, dim3(1), dim3(64), 0, stream, hdr, nslots, max_polls);
+hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, int nbtiles, hipStream_t stream) {
+  hipLaunchKernelGGL(gg_wait_kernel, dim3(1), dim3(64), 0, stream, hdr, nslots, max_polls, nbtiles);
   return hipGetLastError();
 }
 

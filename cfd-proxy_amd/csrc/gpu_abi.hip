@@ -38,6 +38,17 @@ int cfdp_gpu_device_count(void) {
   return n;
 }
 
+// the PCI bus id of a device ("0000:c1:00.0"): the same string in every process that sees the same physical device,
+// whatever HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES made of its ordinal -- what ranks compare to find out whether they
+// share a device
+int cfdp_gpu_device_bus_id(int device, char *buf, int len) {
+  if (!buf || len < 16) return fail("bus id buffer too small");
+  HIP_TRY(hipDeviceGetPCIBusId(buf, len, device));
+  return 0;
+}
+
+int cfdp_gpu_device(const cfdp_gpu *g) { return g ? g->device : -1; }
+
 const char *cfdp_gpu_last_error(void) { return g_err; }
 
 int cfdp_gpu_create(int device, cfdp_gpu **out) {
@@ -241,7 +252,7 @@ extern "C++" int cfdp_detail::ipc_settle(cfdp_gpu *g) {
   if (!g->ipc.on || !g->ipc.wait_pending) return 0;
   g->ipc.wait_pending = false;
   g->main_marked = false;
-  HIP_TRY(gg_launch_wait(g->ipc_hdr(), (int)g->partner.size(), ipc_max_polls(), g->s_main));
+  HIP_TRY(gg_launch_wait(g->ipc_hdr(), (int)g->partner.size(), ipc_max_polls(), g->ipc.counters ? g->nbtiles : 0, g->s_main));
   return 0;
 }
 

@@ -77,6 +77,7 @@ struct cfdp_gpu {
   bool main_marked = false;
   // one process per GPU: this rank's RCCL communicator and the communicator rank of every partner
   ncclComm_t comm = nullptr;
+  int comm_nranks = 0;  // ncclCommCount of `comm`
   std::vector<int> peer;
   // xGMI write + notify exchange (cfdp_gpu_ipc_*): this rank's IPC block [header | landing arena 0
   // | landing arena 1] -- partners write their rows and their arrival counters into it -- and the
@@ -93,6 +94,8 @@ struct cfdp_gpu {
     unsigned char my_handle[64] = {0};
     // notification: per partner (done[1 + s] / need[s] / tile_mask[t], gg_push_args) or one counter for all partners
     bool per_partner = false;
+    bool counters = false;  // notification by counters (gg_push_args::counters); needs the per-partner protocol
+    int cfg_mode = -1, cfg_wait_inkernel = -1, cfg_notify = -1;  // cfdp_gpu_ipc_configure (-1: environment / default)
     int *d_done = nullptr, *d_need = nullptr;
     unsigned long long *d_tile_mask = nullptr;
     size_t land_bytes = 0;
@@ -133,11 +136,13 @@ struct cfdp_gpu {
       hipGraphExec_t graph = nullptr, graph_rem = nullptr;  // main chunk of 50 steps; what is left after whole chunks
       hipGraph_t tmpl = nullptr, tmpl_rem = nullptr;        // what they were instantiated from (cfdp_refresh_exec)
       int graph_n = 0, graph_rem_n = 0;
-      int exch = -1, overlap = -1, flux = -1, mode = -1, xpar = -1, scaled = -1;
+      int exch = -1, overlap = -1, flux = -1, mode = -1, xpar = -1, scaled = -1, closed = -1;
+      bool closed_flips = false;  // a closed batch with an odd number of passes leaves the two grad buffers swapped
       const double *cur = nullptr;
       unsigned long used = 0;
     } gs[8];
     unsigned long gs_clock = 0;
+    long steps_replayed = 0, steps_streamed = 0, captures_failed = 0;  // cfdp_gpu_ipc_graph_stats
     void drop_graph_sets() {
       bool any = false;
       for (auto &x : gs) any = any || x.graph || x.graph_rem;

@@ -105,6 +105,7 @@ struct rccl_api {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -126,6 +127,9 @@ int enqueue_exchange(cfdp_gpu *g) {
   for (size_t s = 0; s < g->partner.size(); s++) {
     size_t sb = 0, rb = 0;
     void *sp = cfdp_gpu_send_ptr(g, (int)s, &sb), *rp = cfdp_gpu_recv_ptr(g, (int)s, &rb);
+    // MEASUREMENT ONLY: a communicator of ONE rank exchanges with itself (the fall-back transport priced on one GPU,
+    // bench.py's loopback table; the plumbing test): a send must then meet a receive of its own length
+    if (g->comm_nranks == 1) sb = rb = sb < rb ? sb : rb;
     if (sb) RCCL_TRY(rccl.Send(sp, sb / sizeof(double), ncclDouble, g->peer[s], g->comm, g->s_comm));
     if (rb) RCCL_TRY(rccl.Recv(rp, rb / sizeof(double), ncclDouble, g->peer[s], g->comm, g->s_comm));
   }
@@ -157,6 +161,7 @@ int cfdp_rccl_load(const char *libpath) {
   RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
   RCCL_SYM(CommInitRank, "ncclCommInitRank");
   RCCL_SYM(CommDestroy, "ncclCommDestroy");
+  RCCL_SYM(CommCount, "ncclCommCount");
   RCCL_SYM(GroupStart, "ncclGroupStart");
   RCCL_SYM(GroupEnd, "ncclGroupEnd");
   RCCL_SYM(Send, "ncclSend");
@@ -188,8 +193,15 @@ int cfdp_gpu_rccl_init(cfdp_gpu *g, const void *id128, int nranks, int rank, con
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
   RCCL_TRY(rccl.CommInitRank(&g->comm, nranks, id, rank));
+  // what the communicator itself says: a bench line reports THIS (config.rccl_nranks), not the world size it asked for
+  int cnt = 0;
+  RCCL_TRY(rccl.CommCount(g->comm, &cnt));
+  g->comm_nranks = cnt;
   return 0;
 }
+
+// ranks in this context's RCCL communicator as ncclCommCount reports it; 0 without a communicator
+int cfdp_gpu_rccl_nranks(const cfdp_gpu *g) { return g && g->comm ? g->comm_nranks : 0; }
 
 int cfdp_gpu_rccl_finalize(cfdp_gpu *g) {
   if (!g) return fail("null context");
@@ -198,6 +210,7 @@ int cfdp_gpu_rccl_finalize(cfdp_gpu *g) {
     HIP_TRY(hipDeviceSynchronize());
     RCCL_TRY(rccl.CommDestroy(g->comm));
     g->comm = nullptr;
+    g->comm_nranks = 0;
   }
   return 0;
 }
@@ -264,7 +277,7 @@ extern "C++" void cfdp_detail::ipc_release(cfdp_gpu *g) {
   I.d_slot_of_row = I.d_send_off = I.d_tile_off = I.d_ent = I.d_ent_row = nullptr;
   I.inkernel = false;
   (void)hipFree(I.d_done); (void)hipFree(I.d_need); (void)hipFree(I.d_tile_mask);
-  I.d_done = I.d_need = nullptr; I.d_tile_mask = nullptr; I.per_partner = false;
+  I.d_done = I.d_need = nullptr; I.d_tile_mask = nullptr; I.per_partner = false; I.counters = false;
   (void)hipFree(I.flags); I.flags = nullptr;
   (void)hipFree(I.block); I.block = nullptr;
   I.on = false; I.xiter = 0;
@@ -305,6 +318,7 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
       pa.pt_first = I.d_pt_first; pa.pt_stride = I.pt_stride; pa.tile_xoff = I.d_tile_xoff;
       pa.nbtiles = g->nbtiles; pa.nslots = nslots;
       pa.inv_after_flag = I.mode == 2 ? 1 : 0;
+      pa.counters = I.counters ? 1 : 0;
       pa.wait_polls = I.wait_pending && I.wait_inkernel && !I.fault_skip_wait ? (long)ipc_max_polls() : 0;
       const int rc = launch_fused(g, CFDP_TILES_ALL, g->s_main, &pa);
       if (rc == 1) return 1;
@@ -319,14 +333,14 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
       if (fork_comm(g)) return 1;  // the comm stream forks off the main stream here
       if (grad_tiles(CFDP_TILES_BOUNDARY, g->s_comm)) return 1;
       HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_comm));
-      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, g->s_comm));
+      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, I.counters ? I.d_need : nullptr, g->nbtiles, g->s_comm));
       HIP_TRY(hipEventRecord(g->ev_senddone, g->s_comm));
       if (grad_tiles(CFDP_TILES_INTERIOR, g->s_main)) return 1;
       HIP_TRY(hipStreamWaitEvent(g->s_main, g->ev_senddone, 0));
     } else {
       if (grad_tiles(CFDP_TILES_ALL, g->s_main)) return 1;
       HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_main));
-      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, g->s_main));
+      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, I.counters ? I.d_need : nullptr, g->nbtiles, g->s_main));
     }
     if (fused) fused_done(g);
     I.xiter++;  // from here on the ghost block is the arena this exchange lands in
@@ -388,6 +402,23 @@ static int ipc_open(cfdp_gpu *g, const void *handle64, unsigned char **base_out)
   return 0;
 }
 
+// how the next cfdp_gpu_ipc_export / _ready set the exchange up, per context and by argument instead of through the
+// process environment (-1 = as the environment says, else the library default):
+//   memory_mode    0 coarse, 1 fine, 2 split                        (CFDP_IPC_MODE)
+//   wait_inkernel  1 the boundary tiles wait themselves, 0 wait kernel (CFDP_IPC_WAIT_INKERNEL; ranks sharing a device: 0)
+//   notify         1 counters (fire-and-forget atomic adds), 0 flags   (CFDP_IPC_NOTIFY=counter|flag)
+int cfdp_gpu_ipc_configure(cfdp_gpu *g, int memory_mode, int wait_inkernel, int notify) {
+  if (!g) return fail("null context");
+  if (memory_mode < -1 || memory_mode > 2 || wait_inkernel < -1 || wait_inkernel > 1 || notify < -1 || notify > 1)
+    return fail("cfdp_gpu_ipc_configure(%d, %d, %d): out of range", memory_mode, wait_inkernel, notify);
+  g->ipc.cfg_mode = memory_mode;
+  g->ipc.cfg_wait_inkernel = wait_inkernel;
+  g->ipc.cfg_notify = notify;
+  return 0;
+}
+
+int cfdp_gpu_ipc_header_bytes(void) { return GG_IPC_HDR_BYTES; }
+
 int cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes) {
   NEED_UPLOAD(g);
   if (!handle64) return fail("null argument");
@@ -404,7 +435,7 @@ int cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes) {
   auto &I = g->ipc;
   I.land_bytes = (((size_t)(g->nall - g->nown) * 21 * sizeof(double)) + 255) & ~(size_t)255;
   const size_t bytes = GG_IPC_HDR_BYTES + 2 * I.land_bytes;
-  I.mode = ipc_mode_from_env();
+  I.mode = I.cfg_mode >= 0 ? I.cfg_mode : ipc_mode_from_env();
   if (I.mode == 1) HIP_TRY(hipExtMallocWithFlags((void **)&I.block, bytes, hipDeviceMallocFinegrained));
   else HIP_TRY(hipMalloc(&I.block, bytes));
   HIP_TRY(cfdp_memset_sync(I.block, 0, bytes));
@@ -481,12 +512,12 @@ int cfdp_gpu_ipc_connect_loopback(cfdp_gpu *g, int slot) {
 }
 
 // what the exchange set up by cfdp_gpu_ipc_ready does: bit 0 the fused pass pushes and notifies itself, bit 1 its
-// boundary tiles wait themselves, bit 2 per-partner notification and wait masks, bits 4-5 the memory mode
-// (0 coarse, 1 fine, 2 split)
+// boundary tiles wait themselves, bit 2 per-partner notification and wait masks, bit 3 notification by counters
+// (fire-and-forget atomic adds), bits 4-5 the memory mode (0 coarse, 1 fine, 2 split)
 int cfdp_gpu_ipc_mode(const cfdp_gpu *g) {
   if (!g || !g->ipc.block) return -1;
   const auto &I = g->ipc;
-  return (I.inkernel ? 1 : 0) | (I.inkernel && I.wait_inkernel ? 2 : 0) | (I.per_partner ? 4 : 0) | (I.mode << 4);
+  return (I.inkernel ? 1 : 0) | (I.inkernel && I.wait_inkernel ? 2 : 0) | (I.per_partner ? 4 : 0) | (I.counters ? 8 : 0) | (I.mode << 4);
 }
 
 int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
@@ -568,7 +599,7 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       // exchange_dbl_copy_in, src/threads.c:791-813): such partitions keep the separate push kernel
       I.inkernel = g->nbtiles > 0 && !g->faceless_send && !(e && atoi(e) == 0);
       const char *w = getenv("CFDP_IPC_WAIT_INKERNEL");  // 0: always a separate wait kernel (A/B timing)
-      I.wait_inkernel = !(w && atoi(w) == 0);
+      I.wait_inkernel = I.cfg_wait_inkernel >= 0 ? I.cfg_wait_inkernel != 0 : !(w && atoi(w) == 0);
       // per-partner notification needs: every boundary tile reads ghost rows only of partners it sends to (then the
       // flags a tile waits for also cover the rows it is about to overwrite at those partners, see gg_kernels.hip)
       std::vector<unsigned long long> smask((size_t)g->nbtiles, 0ull);
@@ -583,8 +614,19 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       for (int s2 = 0; s2 < nslots; s2++) pp = pp && need[(size_t)s2] > 0;
       const char *ppe = getenv("CFDP_IPC_PER_PARTNER");  // 0: one counter, all flags raised by the last boundary tile (A/B)
       I.per_partner = pp && !(ppe && atoi(ppe) == 0);
+      // notification: counters raised by fire-and-forget atomic adds (default wherever the per-partner protocol holds),
+      // or flags raised by the tile that completes a partner's rows (CFDP_IPC_NOTIFY=flag; cfdp_gpu_ipc_configure)
+      const char *ne = getenv("CFDP_IPC_NOTIFY");
+      const int want_counters = I.cfg_notify >= 0 ? I.cfg_notify : !(ne && !strcmp(ne, "flag"));
+      I.counters = I.per_partner && want_counters;
       HIP_TRY(hipMalloc(&I.d_need, sizeof(int) * need.size()));
       HIP_TRY(hipMemcpy(I.d_need, need.data(), sizeof(int) * need.size(), hipMemcpyHostToDevice));
+      // ... and every partner learns how many of this rank's boundary tiles count per exchange towards it: word
+      // NEED_IN + (this rank's slot there) of ITS header, next to the counter word itself.  Written once, here; read by the
+      // partner's waits from its first exchanging step on -- the hosts meet between _ready and that step (every set-up in
+      // this repo validates collectively first; cfdproxy_hip.h says so for other hosts)
+      for (int s2 = 0; s2 < nslots; s2++)
+        HIP_TRY(hipMemcpy(I.rflag[(size_t)s2] + GG_IPC_NEED_IN, &need[(size_t)s2], sizeof(int), hipMemcpyHostToDevice));
       HIP_TRY(hipMalloc(&I.d_tile_mask, sizeof(unsigned long long) * (smask.size() + 1)));
       if (!smask.empty())
         HIP_TRY(hipMemcpy(I.d_tile_mask, smask.data(), sizeof(unsigned long long) * smask.size(), hipMemcpyHostToDevice));
@@ -653,9 +695,9 @@ int cfdp_gpu_ipc_error(cfdp_gpu *g) {
   if (hipMemcpy(h, g->ipc_hdr(), sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -1;
   const int *e = h + GG_IPC_ERR;
   if (getenv("CFDP_DEBUG_TRACE"))
-    fprintf(stderr, "[cfdp] ipc state: host xiter %ld, device iteration counter %d, arrival counter of slot 0: %d; "
-                    "%d waits gave up (last: slot %d, waiting for %d, saw %d)\n",
-            g->ipc.xiter, h[GG_IPC_ITER], h[0], e[4], e[1], e[2], e[3]);
+    fprintf(stderr, "[cfdp] ipc state: host xiter %ld, device iteration counter %d (boundary tiles counted: %d), arrival "
+                    "word of slot 0: %d; %d waits gave up (last: slot %d, waiting for %d, saw %d)\n",
+            g->ipc.xiter, h[GG_IPC_ITER], h[GG_IPC_TILES], h[0], e[4], e[1], e[2], e[3]);
   return e[0] != 0;
 }
 
@@ -684,6 +726,9 @@ int cfdp_gpu_step_ipc(cfdp_gpu *g, int with_exchange, int overlap, int with_flux
 // included: whole chunks of 50 from one graph, the even part of the remainder from a second one (an
 // even count restores the parity of the landing arenas and of the two grad buffers, which the kernels'
 // arguments bake in), at most one step launched from the streams -- so short runs replay as well.
+// use_graph = 2: a batch of 4..64 fused steps is ONE graph from its first pass to the flux of its last iteration and the
+// wait for its last exchange ("closed": the state the caller's cfdp_gpu_sync would establish anyway, without the two
+// stream launches behind the graph that a short batch pays on few steps); longer batches as with use_graph = 1.
 int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overlap, int with_flux,
                            int flux_mode, int use_graph) {
   NEED_UPLOAD(g);
@@ -704,23 +749,39 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       g->flux_pending = flux_mode;
     // lead-in steps from the streams until the state every captured chunk starts and ends in is reached: a flux pending
     // (fused schedule), the arena parity even
-    for (const int lead = g->flux_pending >= 0 ? 0 : 2; done < lead; done++)
+    for (const int lead = g->flux_pending >= 0 ? 0 : 2; done < lead; done++) {
       if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
-    if (I.xiter & 1) {  // a graph is tied to the arena parity it was captured at: even
+      I.steps_streamed++;
+    }
+    // closed: the whole batch is one graph, its last flux and the wait for its last exchange included (its graph set is
+    // keyed by the arena parity and the grad buffer it starts from: no parity step, any count)
+    const bool closed = use_graph == 2 && done == 0 && steps <= 64 && g->flux_pending >= 0 && g->fusion && g->d_grad_alt && with_flux;
+    if (!closed && (I.xiter & 1)) {  // a graph is tied to the arena parity it was captured at: even
       if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
+      I.steps_streamed++;
       done++;
     }
-    // A captured chunk starts and ends with the wait for its last exchange PENDING (its first pass waits in the kernel, or
-    // behind a wait kernel): a chunk captured that way is right whatever the state at replay -- a wait for flags that have
-    // arrived long ago returns at once -- whereas a chunk captured with nothing pending (right behind a sync, which
-    // settles the wait) would skip the wait of its first pass and could not close in the state it started in.
-    if (with_exchange && !g->partner.empty()) I.wait_pending = true;
+    // The state a captured chunk starts AND ends in depends on who waits for an exchange.  A schedule whose fused pass
+    // absorbs the wait (in-kernel push + in-kernel wait) ends every step with the wait for its exchange PENDING: its chunks
+    // are captured with the wait pending at the start as well (the first pass waits in the kernel; a wait for flags that
+    // have arrived long ago returns at once), so a chunk is right whatever the state at replay.  Every other schedule --
+    // the wait kernel (ranks sharing a device, CFDP_IPC_WAIT_INKERNEL=0), push / notify kernels of their own, un-fused
+    // steps, steps without exchange -- settles the wait at the end of every step: its chunks start settled (a pending wait
+    // is settled HERE, in front of the capture) and end settled.  (Round 4 forced "pending" for all of them: their captures
+    // could never close in the state they started in, were abandoned, and every step ran from the streams -- unreported.)
+    const bool comm = with_exchange && !g->partner.empty();
+    bool absorbs = comm && with_flux && g->fusion && g->d_grad_alt && I.inkernel && I.wait_inkernel;
+    auto chunk_start_state = [&]() -> int {
+      if (absorbs) { I.wait_pending = true; return 0; }
+      return ipc_settle(g);
+    };
+    if (chunk_start_state()) return 1;
     // the graph set of this configuration (the arena the ghost rows are read from and the current grad buffer are baked
     // into the kernels' arguments too), or the least recently used one to capture into
     cfdp_gpu::ipc_state::graph_set *S = nullptr;
     for (auto &x : I.gs)
       if (x.exch == with_exchange && x.overlap == overlap && x.flux == with_flux && x.mode == flux_mode && x.cur == g->d_grad &&
-          x.xpar == (int)(I.xiter & 1) && x.scaled == (int)g->sc.on)
+          x.xpar == (int)(I.xiter & 1) && x.scaled == (int)g->sc.on && x.closed == (int)closed)
         S = &x;
     if (!S) {
       S = &I.gs[0];
@@ -733,10 +794,10 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       if (S->tmpl_rem) (void)hipGraphDestroy(S->tmpl_rem);
       *S = cfdp_gpu::ipc_state::graph_set();
       S->exch = with_exchange; S->overlap = overlap; S->flux = with_flux; S->mode = flux_mode; S->cur = g->d_grad;
-      S->xpar = (int)(I.xiter & 1); S->scaled = (int)g->sc.on;
+      S->xpar = (int)(I.xiter & 1); S->scaled = (int)g->sc.on; S->closed = (int)closed;
     }
     S->used = ++I.gs_clock;
-    auto capture = [&](hipGraphExec_t &slot, int &slot_n, int n) -> bool {  // false: run from the streams instead
+    auto capture_once = [&](hipGraphExec_t &slot, int &slot_n, int n) -> bool {  // false: run from the streams instead
       hipGraph_t &tmpl = &slot == &S->graph ? S->tmpl : S->tmpl_rem;
       if (slot && slot_n == n) return true;
       if (slot) {  // another length wanted: the old one may still be replaying
@@ -756,11 +817,22 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       g->main_marked = false;  // the first captured step must fork off a record made INSIDE the capture
       int rc = 0;
       for (int i = 0; i < n && !rc; i++) rc = one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode);
+      if (closed && !rc) rc = flush_flux(g, false);  // the wait kernel if a wait is pending, the last iteration's flux
       hipError_t ec = hipStreamEndCapture(g->s_main, &gr);
       (void)hipEventRecord(g->ev_fork, g->s_main);      // events last recorded inside a capture may not
       (void)hipEventRecord(g->ev_senddone, g->s_comm);  // be waited for outside it: re-arm them
       (void)mark_main(g);
-      const bool ok = !rc && ec == hipSuccess && gr && g->d_grad == cur0 && g->flux_pending == pend0 && I.wait_pending == wait0;
+      // an open chunk ends in the state it started in; a closed batch ends settled, its flux computed, and may leave the
+      // two grad buffers swapped (an odd number of passes)
+      const bool flipped = g->d_grad != cur0;
+      const bool ok = !rc && ec == hipSuccess && gr &&
+                      (closed ? g->flux_pending < 0 && !I.wait_pending
+                              : !flipped && g->flux_pending == pend0 && I.wait_pending == wait0);
+      if (closed && ok) {  // nothing of the capture has run: back to the start state (replay() establishes the end state)
+        if (flipped) { std::swap(g->d_grad, g->d_grad_alt); std::swap(g->own_grad, g->own_grad_alt); }
+        g->flux_pending = pend0;
+        S->closed_flips = flipped;
+      }
       if (ok && hipGraphInstantiate(&slot, gr, nullptr, nullptr, 0) != hipSuccess) slot = nullptr;
       if (ok && slot) tmpl = gr;  // kept: cfdp_gpu_refresh_graphs instantiates from it again
       else if (gr) (void)hipGraphDestroy(gr);
@@ -772,10 +844,20 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
         if (g->d_grad != cur0) { std::swap(g->d_grad, g->d_grad_alt); std::swap(g->own_grad, g->own_grad_alt); }
         g->flux_pending = pend0;
         (void)hipGetLastError();
+        I.captures_failed++;
         return false;
       }
       slot_n = n;
       return true;
+    };
+    auto capture = [&](hipGraphExec_t &slot, int &slot_n, int n) -> bool {
+      if (capture_once(slot, slot_n, n)) return true;
+      // the pass did not absorb the wait after all (no fused kernel fits these tiles: the separate kernels ran and
+      // settled it): the chunk is one that starts and ends settled
+      if (!absorbs) return false;
+      absorbs = false;
+      if (chunk_start_state()) return false;
+      return capture_once(slot, slot_n, n);
     };
     auto replay = [&](hipGraphExec_t ge, int n) -> int {
       HIP_TRY(hipGraphLaunch(ge, g->s_main));
@@ -785,16 +867,40 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
       g->iter += n;
       if (with_exchange && !g->partner.empty()) I.xiter += n;
       done += n;
+      I.steps_replayed += n;
+      if (closed) {
+        if (S->closed_flips) { std::swap(g->d_grad, g->d_grad_alt); std::swap(g->own_grad, g->own_grad_alt); }
+        g->flux_pending = -1;
+        I.wait_pending = false;
+      }
       return 0;
     };
-    if (steps - done >= full && capture(S->graph, S->graph_n, full))
-      while (steps - done >= full)
-        if (replay(S->graph, full)) return 1;
-    const int rem = (steps - done) & ~1;
-    if (rem >= 2 && rem < full && capture(S->graph_rem, S->graph_rem_n, rem) && replay(S->graph_rem, rem)) return 1;
+    if (closed) {
+      if (capture(S->graph_rem, S->graph_rem_n, steps)) return replay(S->graph_rem, steps);
+      // (not capturable: every step from the streams, below)
+    } else {
+      if (steps - done >= full && capture(S->graph, S->graph_n, full))
+        while (steps - done >= full)
+          if (replay(S->graph, full)) return 1;
+      const int rem = (steps - done) & ~1;
+      if (rem >= 2 && rem < full && capture(S->graph_rem, S->graph_rem_n, rem) && replay(S->graph_rem, rem)) return 1;
+    }
   }
-  for (; done < steps; done++)
+  for (; done < steps; done++) {
     if (one_step_ipc(g, with_exchange, overlap, with_flux, flux_mode)) return 1;
+    I.steps_streamed++;
+  }
+  return 0;
+}
+
+// how the steps of cfdp_gpu_run_steps_ipc have run on this context so far: replayed from hipGraphs, launched from the
+// streams (lead-in steps, odd remainders, runs of fewer than 4 steps, use_graph = 0 -- or every step when a capture
+// failed), and how many captures were abandoned (0 in every schedule the library selects by itself)
+int cfdp_gpu_ipc_graph_stats(cfdp_gpu *g, long *steps_replayed, long *steps_streamed, long *captures_failed) {
+  if (!g) return fail("null context");
+  if (steps_replayed) *steps_replayed = g->ipc.steps_replayed;
+  if (steps_streamed) *steps_streamed = g->ipc.steps_streamed;
+  if (captures_failed) *captures_failed = g->ipc.captures_failed;
   return 0;
 }
 

@@ -33,7 +33,7 @@
 
 static int g_own_init = 0;   /* MPI_Init_thread was called here: finalize here too */
 static int g_use_ipc = 0;    /* data path chosen by attach(): 1 = xGMI write + notify, 0 = RCCL (or none) */
-static char g_path[160] = "none (one rank)";
+static char g_path[256] = "none (one rank)";
 
 const char *cfdp_mpi_exchange_path(void) { return g_path; }
 
@@ -111,7 +111,7 @@ static int ipc_setup(cfdp_gpu *gpu, int r, int G) {
     int t = -1;
     for (int i = 0; i < pi->np; i++)
       if (pi->partner[i] == r) t = i;
-    const size_t base = 256 + (size_t)pi->recv_off[t < 0 ? 0 : t] * NGRAD * 3 * sizeof(double);
+    const size_t base = CFDP_IPC_HEADER_BYTES + (size_t)pi->recv_off[t < 0 ? 0 : t] * NGRAD * 3 * sizeof(double);
     ok = t >= 0 && cfdp_gpu_ipc_connect(gpu, s, pi->handle, base, base + (size_t)pi->land, 4 * (size_t)t) == 0 &&
          cfdp_gpu_ipc_connect_flags(gpu, s, pi->fhandle, 4 * (size_t)t) == 0; /* (a block of its own in "split" mode) */
   }
@@ -218,26 +218,50 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
     int all_one_node = nsize == G, agreed = 0;
     MPI_Allreduce(&all_one_node, &agreed, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
     try_ipc = agreed;
-    /* ranks that SHARE a device must not wait inside the fused pass: the boundary tiles of every rank would sit in the
-     * device's workgroup slots, spinning, while the pass whose flags they wait for cannot get a slot (measured: 4 ranks
-     * at 128^3 on one MI355X starve each other until the bounded waits give up).  One waiting workgroup per rank (the
-     * wait kernel) cannot exhaust the device. */
-    if (nsize > cfdp_gpu_device_count()) setenv("CFDP_IPC_WAIT_INKERNEL", "0", 0);
+  }
+  /* ranks that SHARE a device must not wait inside the fused pass: the boundary tiles of every rank would sit in the
+   * device's workgroup slots, spinning, while the pass whose flags they wait for cannot get a slot (measured: 4 ranks
+   * at 128^3 on one MI355X starve each other until the bounded waits give up).  One waiting workgroup per rank (the
+   * wait kernel) cannot exhaust the device.  Sharing is found by comparing the PCI bus ids of the ranks' devices -- not
+   * ordinals or device counts: a launcher that shows every rank ONE device (ROCR_VISIBLE_DEVICES per rank) makes every
+   * count 1 and every ordinal 0.  A CFDP_IPC_WAIT_INKERNEL in the environment wins. */
+  int wait_inkernel = -1, per_device = 1;
+  {
+    char mine[64], *all = cfdp_malloc((size_t)G * 64);
+    memset(mine, 0, sizeof mine);
+    if (cfdp_gpu_device_bus_id(cfdp_gpu_device(gpu), mine, (int)sizeof mine)) snprintf(mine, sizeof mine, "rank%d", r);
+    MPI_Allgather(mine, 64, MPI_BYTE, all, 64, MPI_BYTE, MPI_COMM_WORLD);
+    for (int a = 0; a < G; a++) {
+      int n = 0;
+      for (int b = 0; b < G; b++) n += !strncmp(all + (size_t)a * 64, all + (size_t)b * 64, 64);
+      if (n > per_device) per_device = n;
+    }
+    free(all);
+    if (per_device > 1 && !getenv("CFDP_IPC_WAIT_INKERNEL")) wait_inkernel = 0;
+    if (r == 0 && try_ipc)
+      printf("exchange: %d ranks, at most %d per device: the wait for an exchange runs %s\n", G, per_device,
+             wait_inkernel == 0 ? "as a kernel of its own (ranks share a device)" : "inside the fused pass (or as the environment says)");
   }
   /* the memory modes of the landing block (cfdproxy_hip.h, CFDP_IPC_MODE), in the order they are tried; a mode the
    * environment names is the only one tried */
   static const char *const modes[3] = {"fine", "coarse", "split"}; /* fine first: coherent by definition, and no slower in loopback */
   static const char *const labels[3] = {"fine-grained landing block", "coarse-grained landing block",
                                         "fine-grained flags, coarse-grained arenas, explicit invalidate"};
+  static const int mode_id[3] = {1, 0, 2}; /* cfdp_gpu_ipc_configure: 0 coarse, 1 fine, 2 split */
   const char *preset = getenv("CFDP_IPC_MODE");
   const char *fg0 = getenv("CFDP_IPC_FINEGRAINED");
   if (!(preset && *preset) && fg0 && atoi(fg0) != 0) preset = "fine";
-  char preset_copy[16] = "";
-  if (preset && *preset) snprintf(preset_copy, sizeof preset_copy, "%s", preset); /* (setenv below may move the string) */
-  for (int attempt = 0; try_ipc && attempt < 3; attempt++) {
-    if (preset_copy[0] && strcmp(preset_copy, modes[attempt])) continue;
-    setenv("CFDP_IPC_MODE", modes[attempt], 1);
-    const char *what = labels[attempt];
+  /* per memory mode: notification by counters (fire-and-forget atomic adds), then by flags; CFDP_IPC_NOTIFY names one.
+   * Every attempt is configured by argument -- the process environment stays as the user left it, so the attach of a
+   * further multigrid level or solver starts from the user's presets, not from the last rung tried here */
+  const char *npre = getenv("CFDP_IPC_NOTIFY");
+  for (int attempt = 0; try_ipc && attempt < 6; attempt++) {
+    const int mi = attempt / 2, counters = attempt % 2 == 0;
+    if (preset && *preset && strcmp(preset, modes[mi])) continue;
+    if (npre && *npre && strcmp(npre, counters ? "counter" : "flag")) continue;
+    (void)cfdp_gpu_ipc_configure(gpu, mode_id[mi], wait_inkernel, counters);
+    char what[160];
+    snprintf(what, sizeof what, "%s, %s notification", labels[mi], counters ? "counter" : "flag");
     if (!ipc_setup(gpu, r, G)) {
       if (r == 0) printf("exchange: HIP IPC setup failed (%s): %s\n", what, cfdp_gpu_last_error());
       ipc_teardown(gpu);

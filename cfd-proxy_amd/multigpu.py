@@ -124,6 +124,7 @@ def bench_config(name: str, n_ranks: int) -> dict:
 
 IPC_MODE_LABEL = {"coarse": "coarse-grained block", "split": "fine-grained flags, coarse-grained arenas, explicit invalidate",
                   "fine": "fine-grained block"}
+IPC_NOTIFY_LABEL = {"counter": "counter notification", "flag": "flag notification"}
 
 
 # what the environment asked for when the process started (RankSolver sets CFDP_IPC_MODE itself while it tries the modes)
@@ -139,6 +140,35 @@ def ipc_mode_attempts() -> List[str]:
     if _IPC_MODE_PRESET:
         return [x for x in _IPC_MODE_PRESET.split(",") if x in IPC_MODE_LABEL] or ["fine"]
     return ["fine", "coarse", "split"]
+
+
+_IPC_NOTIFY_PRESET = os.environ.get("CFDP_IPC_NOTIFY", "")
+
+
+def ipc_notify_attempts() -> List[str]:
+    """notification forms in the order the set-up tries them (cfdproxy_hip.h, CFDP_IPC_NOTIFY): counters raised by
+    fire-and-forget atomic adds first (nothing on the boundary tile's critical path; relies on atomics to a peer's memory
+    over xGMI, which only a validation on the machine itself can confirm), then flags stored by the tile that completes a
+    partner's rows.  A form named in the environment is the only one tried"""
+    if _IPC_NOTIFY_PRESET in IPC_NOTIFY_LABEL:
+        return [_IPC_NOTIFY_PRESET]
+    return ["counter", "flag"]
+
+
+def device_census(device: int, rank: int, world: int, dist=None) -> dict:
+    """collective: which PHYSICAL device every rank runs on (PCI bus ids, gathered) -- ordinals say nothing under a
+    launcher that shows every rank one device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank)"""
+    from . import device_bus_id
+    mine = device_bus_id(device)
+    ids: List[str] = [mine]
+    if dist is not None and world > 1:
+        ids = [None] * world  # type: ignore[list-item]
+        dist.all_gather_object(ids, mine)
+    per: Dict[str, int] = {}
+    for b in ids:
+        per[b] = per.get(b, 0) + 1
+    return {"device_of_rank": list(ids), "distinct_devices": len(per), "ranks_per_device": max(per.values()),
+            "shared_gpu": max(per.values()) > 1}
 
 
 def exchange_requests(part: Domain, rank: int, world: int, dist=None, all_requests=None) -> None:
@@ -241,26 +271,43 @@ class RankSolver:
         # {"ipc / as configured": {"ok": False, "failed": "stale rows", "wait_timeouts": 0, "worst_mismatch": 0.31}, ...}
         # -- the datum that says WHICH check a transport failed on a machine nobody could test on before
         self.validation: Dict[str, dict] = {}
+        # which physical device every rank runs on (PCI bus ids): ranks that SHARE a device -- found by comparing the ids,
+        # not ordinals or device counts, which say nothing when a launcher shows every rank one device -- or
+        # CFDP_SHARED_GPU=1 as the explicit override
+        self.census = device_census(device, rank, world, dist)
+        self.shared_gpu = self.census["shared_gpu"] or os.environ.get("CFDP_SHARED_GPU") == "1"
         if transport in ("ipc", "auto") and world > 1:
             import sys
-            if os.environ.get("CFDP_SHARED_GPU") == "1" or world > max(torch.cuda.device_count(), 1):
-                # ranks that SHARE a device must not wait inside the fused pass: the boundary tiles of every rank would
-                # sit in the device's workgroup slots, spinning, while the pass whose flags they wait for cannot get a
-                # slot (measured: 4 ranks at 128^3 on one MI355X starve each other until the bounded waits give up).
-                # One waiting workgroup per rank (the wait kernel) cannot exhaust the device
-                os.environ.setdefault("CFDP_IPC_WAIT_INKERNEL", "0")
-            # the memory modes of the landing block, in the order they are tried (every rank fails or passes alike:
-            # _init_ipc raises from all-reduced evidence only); a mode set in the environment is the only one tried
+            # ranks that SHARE a device must not wait inside the fused pass: the boundary tiles of every rank would sit in
+            # the device's workgroup slots, spinning, while the pass whose flags they wait for cannot get a slot (measured:
+            # 4 ranks at 128^3 on one MI355X starve each other until the bounded waits give up).  One waiting workgroup
+            # per rank (the wait kernel) cannot exhaust the device.  (A CFDP_IPC_WAIT_INKERNEL in the environment wins.)
+            wait_in = None if "CFDP_IPC_WAIT_INKERNEL" in os.environ else (False if self.shared_gpu else None)
+            if rank == 0:
+                print(f"[cfdp] {world} ranks on {self.census['distinct_devices']} device(s), at most "
+                      f"{self.census['ranks_per_device']} per device: the wait for an exchange runs "
+                      + ("as a kernel of its own (ranks share a device)" if wait_in is False else
+                         "inside the fused pass" if wait_in is None else "as the environment says"), file=sys.stderr)
+            # the rungs of the exchange, in the order they are tried (every rank fails or passes alike: _init_ipc raises
+            # from all-reduced evidence only): memory modes of the landing block, and per mode the notification forms.
+            # Each attempt is configured BY ARGUMENT (cfdp_gpu_ipc_configure): the process environment is left alone, so
+            # a later solver of this process starts from the user's presets again, not from the last rung tried here
+            done = False
             for mode in ipc_mode_attempts():
-                os.environ["CFDP_IPC_MODE"] = mode
-                self._validating = f"ipc / {IPC_MODE_LABEL[mode]}"
-                try:
-                    self._init_ipc()
-                    self.available.append("ipc")
+                for notify in ipc_notify_attempts():
+                    self.gpu.ipc_configure(memory_mode=mode, wait_inkernel=wait_in, notify=notify)
+                    self._ipc_mode_now = mode
+                    self._validating = f"ipc / {IPC_MODE_LABEL[mode]}, {IPC_NOTIFY_LABEL[notify]}"
+                    try:
+                        self._init_ipc()
+                        self.available.append("ipc")
+                        done = True
+                        break
+                    except Exception as e:
+                        self.validation.setdefault(self._validating, {"ok": False, "failed": f"setup: {e}"[:160]})
+                        print(f"[rank {rank}] xGMI write+notify setup failed ({self._validating}: {e})", file=sys.stderr)
+                if done:
                     break
-                except Exception as e:
-                    self.validation.setdefault(self._validating, {"ok": False, "failed": f"setup: {e}"[:160]})
-                    print(f"[rank {rank}] xGMI write+notify setup failed ({IPC_MODE_LABEL[mode]}: {e})", file=sys.stderr)
             if "ipc" not in self.available and transport == "ipc":
                 transport = "rccl"
         elif transport in ("ipc", "auto"):
@@ -322,7 +369,7 @@ class RankSolver:
             for s, p in enumerate(self.partners):
                 pi = gathered[p]
                 t = pi["partners"].index(self.rank)
-                base = 256 + pi["recv_off"][t] * 8 * ROWLEN
+                base = self.gpu.lib.cfdp_gpu_ipc_header_bytes() + pi["recv_off"][t] * 8 * ROWLEN
                 self.gpu.ipc_connect(s, pi["handle"], base, base + pi["land"], 4 * t)
                 self.gpu.ipc_connect_flags(s, pi["fhandle"], 4 * t)  # (a block of its own in "split" mode)
             self.gpu.ipc_ready()
@@ -504,7 +551,7 @@ class RankSolver:
         # a broken mapping must not cost half a minute per iteration here; ranks that time-slice ONE device (rehearsals)
         # wait for each other's turn on it, which takes seconds with 6 of them
         lib.cfdp_ipc_set_wait_seconds(float(os.environ.get("CFDP_IPC_VALIDATE_WAIT_SECONDS") or
-                                            (20.0 if os.environ.get("CFDP_SHARED_GPU") == "1" else 2.0)))
+                                            (20.0 if getattr(self, "shared_gpu", False) else 2.0)))
         try:
             ev = self.stale_read_check()
             g = self.grad_host()
@@ -610,7 +657,9 @@ class RankSolver:
         """`steps` iterations (one library call with the library's own communicator)"""
         comm = with_exchange and self.world > 1 and bool(self.partners)
         if self.transport == "ipc":
-            self.gpu.run_steps_ipc(steps, comm, overlap, with_flux, flux_mode, use_graph=True)
+            # use_graph = 2: a batch of up to 64 steps is ONE graph, the flux of its last iteration and the wait for its last
+            # exchange included (what the caller's synchronize() would enqueue behind it anyway)
+            self.gpu.run_steps_ipc(steps, comm, overlap, with_flux, flux_mode, use_graph=2)
             return
         if self.transport == "rccl":
             self.gpu.run_steps_rccl(steps, comm, overlap, with_flux, flux_mode)

@@ -48,6 +48,10 @@ enum {
 enum { CFDP_GRAD_DEFAULT = 0, CFDP_GRAD_L1 = 1, CFDP_GRAD_L2 = 2, CFDP_GRAD_L4 = 4, CFDP_GRAD_L8 = 8 };
 
 int  cfdp_gpu_device_count(void);
+/* PCI bus id of a device ("0000:c1:00.0", len >= 16): equal in every process that sees the same physical device whatever
+ * its ordinal there -- ranks compare it to find out whether they share a device                                       */
+int  cfdp_gpu_device_bus_id(int device, char *buf, int len);
+int  cfdp_gpu_device(const cfdp_gpu *g); /* the ordinal the context was created on; -1 for a null context */
 const char *cfdp_gpu_last_error(void);
 
 int  cfdp_gpu_create(int device, cfdp_gpu **out);
@@ -154,6 +158,7 @@ int  cfdp_rccl_load(const char *libpath);
 int  cfdp_rccl_unique_id(void *id128);
 int  cfdp_gpu_rccl_init(cfdp_gpu *g, const void *id128, int nranks, int rank, const int *rank_of_partner);
 int  cfdp_gpu_rccl_finalize(cfdp_gpu *g);
+int  cfdp_gpu_rccl_nranks(const cfdp_gpu *g); /* ncclCommCount of the context's communicator; 0 without one */
 int  cfdp_gpu_exchange_rccl(cfdp_gpu *g);   /* between cfdp_gpu_step_pre and cfdp_gpu_step_post */
 int  cfdp_gpu_step_rccl(cfdp_gpu *g, int with_exchange, int overlap, int with_flux, int flux_mode);
 /* drop-in layer, one rank per process (e.g. MPI-launched, bin/hybrid.f6.hip.mpi): the context
@@ -201,13 +206,31 @@ int  cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int over
  * tile reads ghost rows only of partners it holds send points for (checked at _ready; else, or with
  * CFDP_IPC_PER_PARTNER=0, the last boundary tile raises all flags and every tile waits for all).
  *   cfdp_gpu_ipc_mode     bit 0 the fused pass pushes / notifies, bit 1 its tiles wait themselves, bit 2 per-partner
- *                         notification, bits 4-5 memory mode (0 coarse, 1 fine, 2 split); -1 without a block          */
+ *                         notification, bit 3 notification by counters, bits 4-5 memory mode (0 coarse, 1 fine,
+ *                         2 split); -1 without a block                                                                */
+/* A rank's block starts with CFDP_IPC_HEADER_BYTES of flag / counter words; landing arena 0 follows, then arena 1.
+ * Notification (CFDP_IPC_NOTIFY, cfdp_gpu_ipc_configure): "counter" (default where the per-partner protocol holds) -- a
+ * partner's word counts the boundary tiles that have completed their rows for it, raised by fire-and-forget system-scope
+ * atomic adds (nothing returns to the tile; the reference's notification travels with the write as well,
+ * src/exchange_data_gaspi.c:134-145), a waiter compares it with tiles-per-exchange x exchanges; "flag" -- the tile that
+ * completes a partner's rows stores the exchange number (two dependent device-scope atomics decide which tile that is).
+ * cfdp_gpu_ipc_ready writes into every partner's header how many of this rank's tiles count per exchange: the hosts must
+ * meet (a barrier, a collective) between _ready on every rank and the first exchanging step.
+ *   cfdp_gpu_ipc_configure  per context, by argument instead of through the environment (-1 = environment / default):
+ *                           memory_mode 0 coarse | 1 fine | 2 split; wait_inkernel 1 | 0 (ranks sharing a device: 0);
+ *                           notify 1 counters | 0 flags.  Takes effect at the next _export / _ready.                   */
+#define CFDP_IPC_HEADER_BYTES 512
+int  cfdp_gpu_ipc_header_bytes(void);
+int  cfdp_gpu_ipc_configure(cfdp_gpu *g, int memory_mode, int wait_inkernel, int notify);
 int  cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes);
 int  cfdp_gpu_ipc_connect(cfdp_gpu *g, int slot, const void *partner_handle64, size_t land_off0,
                           size_t land_off1, size_t flag_off);
 int  cfdp_gpu_ipc_export_flags(cfdp_gpu *g, void *handle64);
 int  cfdp_gpu_ipc_connect_flags(cfdp_gpu *g, int slot, const void *partner_flags_handle64, size_t flag_off);
 int  cfdp_gpu_ipc_mode(const cfdp_gpu *g);
+/* how the steps of cfdp_gpu_run_steps_ipc have run on this context: replayed from hipGraphs / launched from the streams
+ * (lead-in steps, odd remainders, short runs) / captures that were abandoned (0 in every schedule the library selects) */
+int  cfdp_gpu_ipc_graph_stats(cfdp_gpu *g, long *steps_replayed, long *steps_streamed, long *captures_failed);
 /* measurement only: partner slot `slot` is this rank itself (its own arenas, its own flag word): the cost of the protocol
  * with a partner that is never late; the ghost rows then hold this rank's own send rows                              */
 int  cfdp_gpu_ipc_connect_loopback(cfdp_gpu *g, int slot);

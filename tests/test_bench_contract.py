@@ -42,7 +42,17 @@ def test_bench_line(gpu):
         e = lb[name]
         assert e["wait_timeouts"] == 0 and 0.5 < e["efficiency_bound"] <= 1.05 and e["protocol"]["notify"] == "per partner", e
         assert e["us_per_iteration_with_exchange"] >= 0.95 * e["us_per_iteration_comm_free"], e
-    assert "wall_s" in out and out["wall_s"]["exchange protocol in loopback"] < 60
+    assert "wall_s" in out and out["wall_s"]["exchange protocol in loopback"] < 90
+    # notification by counters (the default) beside the flag form and the RCCL fall-back, same partitions, same table
+    for name in ("dualgrid.384", "dualgrid.192"):
+        e = lb[name]
+        assert e["protocol"]["notify_by"].startswith("counters") and e["graph_replay"]["captures_failed"] == 0, e
+        assert e["flag_notification"]["wait_timeouts"] == 0 and 0.5 < e["flag_notification"]["steps20_ratio"] <= 1.05, e
+        r_ = e["rccl_self_sendrecv"]
+        assert "error" in r_ or (r_["rccl_nranks"] == 1 and r_["steps20_with_exchange"] > 0), r_
+    # one rank, one device, nothing shared; the CFDP_* variables the run saw are in the line
+    assert out["shared_gpu"] is False and out["config"]["distinct_devices"] == 1 and len(out["config"]["device_of_rank"]) == 1
+    assert isinstance(out["config"]["env"], dict) and all(k.startswith("CFDP_") for k in out["config"]["env"])
 
 
 def test_bench_configs_name_the_baseline_workloads(pkg):
@@ -65,6 +75,11 @@ def test_bench_configs_name_the_baseline_workloads(pkg):
         mg.bench_config("dualgrid.12", 8)  # 12 domains do not divide over 8 GPUs
     with pytest.raises(ValueError):
         mg.bench_config("dualgrid.13", 1)
+
+
+def _visible_devices():
+    import torch
+    return max(torch.cuda.device_count(), 1)
 
 
 def _bench_two_ranks(transport, extra_env=None, expect=None, weak=False):
@@ -265,6 +280,17 @@ def test_bench_eight_gpu_code_path_rehearsed_by_four_ranks_on_a_tiny_mesh(gpu):
     val = out["config"]["transport_probe_validation"]
     assert any(k.startswith("ipc") and v["ok"] for k, v in val.items()), val
     assert out["config"]["exchange_protocol"]["notify"] == "per partner", out["config"]["exchange_protocol"]
+    assert out["config"]["exchange_protocol"]["notify_by"].startswith("counters"), out["config"]["exchange_protocol"]
+    # the line says WHICH hardware it ran on: four ranks on however many devices this box has -- with one device a
+    # rehearsal that can never be read as a scaling point
+    c = out["config"]
+    ndev = _visible_devices()
+    assert len(c["device_of_rank"]) == 4 and all(isinstance(b, str) and b for b in c["device_of_rank"]), c["device_of_rank"]
+    assert c["distinct_devices"] == len(set(c["device_of_rank"])) == min(ndev, 4) and c["ranks_per_device"] == -(-4 // min(ndev, 4))
+    assert out["shared_gpu"] == (c["ranks_per_device"] > 1) and st["shared_gpu"] == out["shared_gpu"]
+    assert ("shared_gpu_note" in out) == out["shared_gpu"]
+    assert c["rccl_nranks"] is None and c["process_group"] == {"backend": "gloo", "world_size": 4}  # (CFDP_SHARED_GPU=1: gloo)
+    assert c["device_of_rank"][0] in c["peer_access_of_rank0"] and c["env"]["CFDP_BENCH_AS_GPUS"] == "8"
     assert wall < 240, wall
 
 

@@ -93,12 +93,15 @@ def test_multirank_xgmi_write_notify_under_random_skew(gpu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"CFDP_IPC_MODE": "split"}, {"CFDP_IPC_MODE": "fine"}, {"CFDP_IPC_PER_PARTNER": "0"},
-                                 {"CFDP_IPC_WAIT_INKERNEL": "0"}, {"CFDP_IPC_INKERNEL": "0"}])
+                                 {"CFDP_IPC_WAIT_INKERNEL": "0"}, {"CFDP_IPC_INKERNEL": "0"}, {"CFDP_IPC_NOTIFY": "flag"},
+                                 {"CFDP_IPC_NOTIFY": "flag", "CFDP_IPC_WAIT_INKERNEL": "0"},
+                                 {"CFDP_IPC_NOTIFY": "counter", "CFDP_IPC_INKERNEL": "0"}])
 def test_multirank_xgmi_write_notify_other_rungs(gpu, env):
     """the same value checks (and the scaled-field check of every schedule) on the other rungs of the exchange: flags in a
     fine-grained block of their own with the arenas coarse-grained and an explicit invalidate ("split"), everything
     fine-grained, one completion counter for all partners instead of one per partner, the wait as a kernel of its own,
-    push / notify as kernels of their own"""
+    push / notify as kernels of their own, notification by flags instead of counters (with either wait), counters raised
+    by the notify kernel"""
     _launch(3, ["--gpu", "--transport", "ipc", "--files"], extra_env=dict({"CFDP_IPC_WAIT_INKERNEL": "1"}, **env))
 
 
@@ -118,8 +121,10 @@ def test_scaled_field_check_sees_a_ghost_row_read_one_exchange_early(gpu, world,
 
 @pytest.mark.gpu
 def test_write_notify_setup_is_retried_with_a_fine_grained_block(gpu):
-    """a failed exchange validation tears the IPC mappings down on every rank and the set-up is retried with the
-    next memory mode of the landing block (fine -> coarse -> split, CFDP_IPC_MODE) before any other transport is tried"""
+    """a failed exchange validation tears the IPC mappings down on every rank and the set-up is retried on the next rung
+    -- per memory mode of the landing block (fine -> coarse -> split, CFDP_IPC_MODE) the notification by counters, then by
+    flags (CFDP_IPC_NOTIFY) -- before any other transport is tried; the rungs are configured by argument, the process
+    environment stays as the user left it"""
     _launch(2, ["--gpu", "--fail-first-validation"])
 
 

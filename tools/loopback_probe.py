@@ -10,7 +10,7 @@ pkg = load_package()
 from cfd_proxy_amd import multigpu as mg
 
 def timed(g, steps, **kw):
-    g.run_steps_ipc(200, **kw); g.sync()
+    g.run_steps_ipc(200, **kw); g.sync()  # (open chunks of 50: the steady state)
     best = 1e9
     for _ in range(3):
         t = time.perf_counter(); g.run_steps_ipc(steps, **kw); g.sync(); best = min(best, (time.perf_counter() - t) / steps)
@@ -23,13 +23,17 @@ for name, world in (("dualgrid.24", 2), ("dualgrid.48", 4), ("dualgrid.192", 8),
     reqs = [{int(k): (v[0], v[1]) for k, v in pkg.merge_requests(p).items()} for p in parts]
     mg.exchange_requests(parts[0], 0, world, None, all_requests=reqs)
     part = parts[0]
-    for variant, env in (("per-partner flags, wait in the pass", {}), ("one counter, wait in the pass", {"CFDP_IPC_PER_PARTNER": "0"}),
-                         ("per-partner flags, wait kernel", {"CFDP_IPC_WAIT_INKERNEL": "0"}), ("push + notify + wait kernels", {"CFDP_IPC_INKERNEL": "0"})):
+    for variant, env, notify in (("per-partner counters, wait in the pass", {}, "counter"),
+                                 ("per-partner flags, wait in the pass", {}, "flag"),
+                                 ("one completion counter + flags, wait in the pass", {"CFDP_IPC_PER_PARTNER": "0"}, "flag"),
+                                 ("per-partner counters, wait kernel", {"CFDP_IPC_WAIT_INKERNEL": "0"}, "counter"),
+                                 ("push + notify + wait kernels", {"CFDP_IPC_INKERNEL": "0"}, "counter")):
         for k in ("CFDP_IPC_PER_PARTNER", "CFDP_IPC_WAIT_INKERNEL", "CFDP_IPC_INKERNEL"):
             os.environ.pop(k, None)
         os.environ.update(env)
         g = pkg.GpuPartition(part)
         g.set_fusion(True)
+        g.ipc_configure(notify=notify)
         g.ipc_export()
         try:
             for s in range(len(g.partners())):
@@ -41,13 +45,15 @@ for name, world in (("dualgrid.24", 2), ("dualgrid.48", 4), ("dualgrid.192", 8),
         exch = timed(g, 2000, with_exchange=True, overlap=True)
         assert g.ipc_error() == 0
         if not env:  # the driver's flags: K = 20 steps between two syncs (what a bench line records at N > 1)
-            def short(**kw):
+            def short(ug, **kw):
                 best = 1e9
-                for _ in range(5):
-                    g.sync(); t = time.perf_counter(); g.run_steps_ipc(20, **kw); g.sync(); best = min(best, (time.perf_counter() - t) / 20)
+                for _ in range(7):
+                    g.sync(); t = time.perf_counter(); g.run_steps_ipc(20, use_graph=ug, **kw); g.sync(); best = min(best, (time.perf_counter() - t) / 20)
                 return best * 1e6
-            f20, e20 = short(with_exchange=False, overlap=True), short(with_exchange=True, overlap=True)
-            print(f"{name:13s} rank 0 of {world}: K = 20 between syncs: comm_free {f20:6.2f} us/step, with exchange {e20:6.2f} us/step  -> {f20 / e20:5.3f}", flush=True)
+            for ug, what in ((1, "open graph + the sync's flux and wait from the streams"), (2, "ONE closed graph")):
+                f20, e20 = short(ug, with_exchange=False, overlap=True), short(ug, with_exchange=True, overlap=True)
+                print(f"{name:13s} rank 0 of {world}: K = 20 between syncs, {what}: comm_free {f20:6.2f} us/step, with exchange {e20:6.2f} us/step  -> {f20 / e20:5.3f}", flush=True)
+            print(f"{name:13s} graph replay: {g.ipc_graph_stats()}", flush=True)
         print(f"{name:13s} rank 0 of {world} ({part.nown} points, {len(g.partners())} partners, {g.stats['nbtiles']} boundary tiles of {g.stats['ntiles']}): "
               f"{variant:38s} comm_free {free:6.2f} us, with exchange {exch:6.2f} us  -> efficiency bound {free / exch:5.3f}", flush=True)
         g.ipc_disconnect()
