@@ -272,6 +272,8 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_ipc_graph_stats.argtypes = [vp, P(C.c_long), P(C.c_long), P(C.c_long)]
     lib.cfdp_gpu_ipc_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_rccl_nranks.argtypes = [vp]
+    lib.cfdp_gpu_ipc_flag_offset.argtypes = [C.c_int]
+    lib.cfdp_gpu_ipc_flag_offset.restype = C.c_size_t
     lib.cfdp_gpu_device.argtypes = [vp]
     lib.cfdp_gpu_device_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     lib.cfdp_gpu_ipc_connect_loopback.argtypes = [vp, C.c_int]

@@ -48,8 +48,11 @@ struct gg_push_args {
   int inv_after_flag;  // explicit buffer_inv sc0 sc1 once a tile has seen its partners' flags
   // counter notification (per-partner protocol only): a partner's flag word is a COUNTER of the boundary tiles that have
   // completed their rows for it -- raised by a fire-and-forget system-scope atomic add, nothing returns to the tile --
-  // and a waiting tile compares it with hdr[GG_IPC_NEED_IN + slot] x exchanges so far
+  // and a waiting tile compares it with (tiles of that partner per exchange) x (exchanges so far).  tile_iter[t] = the
+  // exchanges boundary tile t has taken part in: read by tile t at its top, stored by tile t at its end -- nobody else
+  // touches it, so the count needs no atomic and no "last tile" election
   int counters;
+  int *tile_iter;
   // > 0: the boundary tiles (the only ones that read ghost rows) first wait -- bounded -- until every partner's
   // rows of the PREVIOUS exchange have arrived: the job of gg_wait_kernel done at the top of the next pass, so
   // that an iteration is ONE launch (no wait kernel, no kernel boundary behind it)
@@ -94,19 +97,20 @@ hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view
 // xGMI write + notify exchange (see gg_kernels.hip): header words of a rank's IPC block
 enum { GG_ROW_STRIDE = 208 };  // >= 1024 / 5 + 1 rows: every piece index of the 256-thread fused pass
 enum { GG_DONE_STRIDE = 32 };  // the completion counters of push_tile_done sit on cache lines of their own (atomics of hundreds of tiles)
-// hdr: [0, MAXSLOTS) arrival flags / counters written by the partners; [ITER] this rank's exchanges so far (flag
-// notification); [ERR .. ERR + 4] a wait gave up; [TILES] boundary tiles counted so far (counter notification: exchanges
-// so far = TILES / boundary tiles); [NEED_IN + s] how many of partner s's boundary tiles count per exchange (written once
-// by the partner's host at set-up)
-enum { GG_IPC_MAXSLOTS = 48, GG_IPC_ITER = 48, GG_IPC_ERR = 49, GG_IPC_TILES = 54, GG_IPC_NEED_IN = 64, GG_IPC_HDR_BYTES = 512 };
+// hdr (ints): partner slot s owns the cache line [s * SLOT_STRIDE, (s + 1) * SLOT_STRIDE): word 0 its arrival flag /
+// counter (written by partner s only -- seven devices never store to one line), word GG_IPC_NEED_IN how many of its
+// boundary tiles count per exchange (written once by the partner's host at set-up); behind the slot lines [ITER] this
+// rank's exchanges so far (flag notification) and [ERR .. ERR + 4] a wait gave up
+enum { GG_IPC_MAXSLOTS = 48, GG_IPC_SLOT_STRIDE = 32, GG_IPC_NEED_IN = 1, GG_IPC_ITER = GG_IPC_MAXSLOTS * GG_IPC_SLOT_STRIDE,
+       GG_IPC_ERR = GG_IPC_ITER + 1, GG_IPC_HDR_BYTES = 8192 };
 static_assert(GG_IPC_HDR_BYTES == CFDP_IPC_HEADER_BYTES, "cfdproxy_hip.h");
-static_assert((GG_IPC_NEED_IN + GG_IPC_MAXSLOTS) * 4 <= GG_IPC_HDR_BYTES, "header layout");
+static_assert((GG_IPC_ERR + 5) * 4 <= GG_IPC_HDR_BYTES, "header layout");
 hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row, const int *send_off,
                           const gg_grad_view &grad, double *const *dst, hipStream_t stream);
-// need != nullptr: counter notification (every partner's counter += need[s], hdr[GG_IPC_TILES] += nbtiles)
-hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, const int *need, int nbtiles, hipStream_t stream);
-// nbtiles > 0: counter notification (wait for counter >= hdr[GG_IPC_NEED_IN + s] x (hdr[GG_IPC_TILES] / nbtiles))
-hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, int nbtiles, hipStream_t stream);
+// need != nullptr: counter notification (every partner's counter += need[s], every boundary tile's exchange count += 1)
+hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, const int *need, int *tile_iter, int nbtiles, hipStream_t stream);
+// tile_iter != nullptr: counter notification (wait for counter >= NEED_IN of the slot x tile_iter[0])
+hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, const int *tile_iter, hipStream_t stream);
 hipError_t gg_launch_jitter(unsigned *rng, int max_us, hipStream_t stream);  // tests: a pseudo-random idle time in front of a step
 // scaled-field validation of an exchange (gg_validate_kernel): words of its device-side state block (16 ints, 8-byte
 // aligned): gradient launches so far, flux fields compared, mismatching values (64 bit), first mismatch (claimed,

@@ -367,10 +367,10 @@ __device__ __forceinline__ void push_tile_rows(const gg_push_args &pa, int tile,
   }
 }
 
-// exchanges this rank has announced so far, read once at the top of a boundary tile: the word only moves past a multiple
-// (flag form: at all) when the LAST boundary tile of a launch has finished, i.e. after every tile's read here
-__device__ __forceinline__ int exchanges_so_far(const gg_push_args &pa) {
-  if (pa.need && pa.counters) return (int)((unsigned)pa.hdr[GG_IPC_TILES] / (unsigned)pa.nbtiles);
+// exchanges this rank has announced so far, read once at the top of a boundary tile (flag form: the word only moves when
+// the LAST boundary tile of a launch has finished, i.e. after every tile's read here)
+__device__ __forceinline__ int exchanges_so_far(const gg_push_args &pa, int tile) {
+  if (pa.need && pa.counters) return pa.tile_iter[tile];  // this tile's own word: it stores it at its end, nobody else does
   return pa.hdr[GG_IPC_ITER];
 }
 
@@ -393,7 +393,8 @@ __device__ __forceinline__ void wait_previous_exchange(const gg_push_args &pa, i
   if (mine && !pa.hdr[GG_IPC_ERR]) {
     // flag notification: partner s has stored its exchange number.  Counter notification: s's boundary tiles have each
     // added 1 for every exchange they completed for this rank, NEED_IN of them per exchange (compared wrap-safe)
-    const int need = pa.counters ? iter0 * __hip_atomic_load(&pa.hdr[GG_IPC_NEED_IN + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : iter0;
+    const int *slot = pa.hdr + tid * GG_IPC_SLOT_STRIDE;
+    const int need = pa.counters ? iter0 * __hip_atomic_load(&slot[GG_IPC_NEED_IN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : iter0;
     bool ok = false;
     // RELAXED system-scope polls (global_load_dword ... sc0 sc1, past every cache): an acquire per poll is a cache
     // invalidate per poll (MI355X_MICROARCH.md: polling with acquire loads is 2-3x slower per hop and many pollers cut
@@ -401,14 +402,14 @@ __device__ __forceinline__ void wait_previous_exchange(const gg_push_args &pa, i
     // for is itself a system-scope load (glds16_sys / the generic flux kernel's atomic loads), issued after this poll
     // has returned (the loop exit depends on its value) and, for the other waves, behind the barrier below.
     for (long k = 0; k < pa.wait_polls && !ok; k++) {
-      ok = (int)((unsigned)__hip_atomic_load(&pa.hdr[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)need) >= 0;
+      ok = (int)((unsigned)__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)need) >= 0;
       if (!ok) __builtin_amdgcn_s_sleep(32);
     }
     if (!ok) {  // bounded: a lost partner must not hang the device.  Leave what was seen for the post-mortem.
       pa.hdr[GG_IPC_ERR] = 1;
       pa.hdr[GG_IPC_ERR + 1] = tid;
       pa.hdr[GG_IPC_ERR + 2] = need;
-      pa.hdr[GG_IPC_ERR + 3] = __hip_atomic_load(&pa.hdr[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      pa.hdr[GG_IPC_ERR + 3] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       atomicAdd(&pa.hdr[GG_IPC_ERR + 4], 1);
     }
   }
@@ -437,14 +438,14 @@ __device__ __forceinline__ void push_tile_done(const gg_push_args &pa, int tile,
   const int it = iter0 + 1;
   if (pa.need && pa.counters) {
     // counter notification: nothing comes back to the tile.  Lane s adds 1 to partner s's counter word (a no-return
-    // system-scope atomic: fire and forget), lane 0 counts the tile for this rank's own exchange count -- the next pass
-    // reads TILES / nbtiles at its top, behind the kernel boundary that completes every atomic of this one.  Takes the two
-    // dependent device-scope atomics of the flag form (2-3 us each under load) off the boundary tile's critical path; the
-    // reference's notification travels with the write as well (gaspi_write_notify, src/exchange_data_gaspi.c:134-145).
+    // system-scope atomic: fire and forget), lane 0 stores the tile's own exchange count -- its next pass reads it at its
+    // top, behind the kernel boundary.  Takes the two dependent device-scope atomics of the flag form (2-3 us each under
+    // load) off the boundary tile's critical path; the reference's notification travels with the write as well
+    // (gaspi_write_notify, src/exchange_data_gaspi.c:134-145).
     if (!(dbg & 0x800) && tid < pa.nslots && ((pa.tile_mask[tile] >> tid) & 1ull))
       // (the pointer comes out of a table: say that it is global memory, or the add is a flat_ instruction)
       (void)__hip_atomic_fetch_add((__attribute__((address_space(1))) int *)pa.rflag[tid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (tid == 0) (void)__hip_atomic_fetch_add(&pa.hdr[GG_IPC_TILES], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) pa.tile_iter[tile] = it;
     return;
   }
   if (pa.need) {  // lane s of wave 0 looks after partner slot s (at most GG_IPC_MAXSLOTS = 48 of them)
@@ -831,7 +832,7 @@ void gg_fused_dma_kernel(
   const cfdp_tile_desc td = tiles[t];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
-  const int iter0 = pa.tile_off && t < pa.nbtiles ? exchanges_so_far(pa) : 0;  // uniform: scalar loads
+  const int iter0 = pa.tile_off && t < pa.nbtiles ? exchanges_so_far(pa, t) : 0;  // uniform: scalar loads
   wait_previous_exchange(pa, t, tid, iter0);  // before any ghost row is requested
   unsigned long long pfirst = ~0ull;  // see gg_fused_split_kernel
   if (pa.tile_off && t < pa.nbtiles) pfirst = ld_u64_nowait(pa.pt_first + (size_t)t * pa.pt_stride + (tid >> 2));
@@ -969,7 +970,7 @@ void gg_fused_split_kernel(
   int iter0 = 0;
   unsigned long long pfirst = ~0ull;  // {partner slot or -1, row}: where this lane's point goes first (boundary tiles)
   if constexpr (PUSH) {
-    if (pa.tile_off && t < pa.nbtiles) iter0 = exchanges_so_far(pa);  // uniform: scalar loads
+    if (pa.tile_off && t < pa.nbtiles) iter0 = exchanges_so_far(pa, t);  // uniform: scalar loads
     if (!(dbg & 0x100)) wait_previous_exchange(pa, t, tid, iter0);  // before any ghost row is requested
     if (pa.tile_off && t < pa.nbtiles) pfirst = ld_u64_nowait(pa.pt_first + (size_t)t * pa.pt_stride + (tid >> 2));
   }
@@ -1114,16 +1115,15 @@ __global__ __launch_bounds__(256) void gg_push_kernel(const int *__restrict__ se
   }
 }
 
-// hdr: [0..GG_IPC_MAXSLOTS) arrival counters written by the partners, [GG_IPC_ITER] this rank's
-// iteration counter, [GG_IPC_ERR] set when a wait gave up
+// hdr: the layout of gg_kernels.h (one cache line per partner slot, then [GG_IPC_ITER], [GG_IPC_ERR ..])
 // need != nullptr: counter notification -- the whole exchange at once: need[s] tiles' worth to partner s's counter,
-// nbtiles to this rank's own count (the separate push kernel has stored every row before this kernel starts)
+// one exchange more for every boundary tile (the separate push kernel has stored every row before this kernel starts)
 __global__ void gg_notify_kernel(int *__restrict__ hdr, int *const *__restrict__ remote_flag, int nslots,
-                                 const int *__restrict__ need, int nbtiles) {
+                                 const int *__restrict__ need, int *__restrict__ tile_iter, int nbtiles) {
   if (need) {
     if ((int)threadIdx.x < nslots)
       (void)__hip_atomic_fetch_add(remote_flag[threadIdx.x], need[threadIdx.x], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&hdr[GG_IPC_TILES], nbtiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int t = threadIdx.x; t < nbtiles; t += blockDim.x) tile_iter[t] += 1;
     return;
   }
   const int it = hdr[GG_IPC_ITER] + 1;
@@ -1133,21 +1133,21 @@ __global__ void gg_notify_kernel(int *__restrict__ hdr, int *const *__restrict__
   if (threadIdx.x == 0) hdr[GG_IPC_ITER] = it;
 }
 
-__global__ void gg_wait_kernel(int *__restrict__ hdr, int nslots, long max_polls, int nbtiles) {
+__global__ void gg_wait_kernel(int *__restrict__ hdr, int nslots, long max_polls, const int *__restrict__ tile_iter) {
   if ((int)threadIdx.x >= nslots) return;
   if (hdr[GG_IPC_ERR]) return;  // a wait has given up before: the run is void anyway, do not stall every step
-  const int need = nbtiles > 0 ? (int)((unsigned)hdr[GG_IPC_TILES] / (unsigned)nbtiles) *
-                                     __hip_atomic_load(&hdr[GG_IPC_NEED_IN + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                               : hdr[GG_IPC_ITER];
+  int *slot = hdr + threadIdx.x * GG_IPC_SLOT_STRIDE;
+  const int need = tile_iter ? tile_iter[0] * __hip_atomic_load(&slot[GG_IPC_NEED_IN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                             : hdr[GG_IPC_ITER];
   for (long k = 0; k < max_polls; k++) {
-    if ((int)((unsigned)__hip_atomic_load(&hdr[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)need) >= 0) return;
+    if ((int)((unsigned)__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)need) >= 0) return;
     __builtin_amdgcn_s_sleep(32);  // ~1 us between polls: the flag line is not hammered
   }
   // bounded: a lost partner must not hang the device.  Leave what was seen for the post-mortem.
   hdr[GG_IPC_ERR] = 1;
   hdr[GG_IPC_ERR + 1] = (int)threadIdx.x;
   hdr[GG_IPC_ERR + 2] = need;
-  hdr[GG_IPC_ERR + 3] = __hip_atomic_load(&hdr[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+  hdr[GG_IPC_ERR + 3] = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
   atomicAdd(&hdr[GG_IPC_ERR + 4], 1);
 }
 
@@ -1267,12 +1267,12 @@ hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row
                      grad.a, grad.b, dst);
   return hipGetLastError();
 }
-hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, const int *need, int nbtiles, hipStream_t stream) {
-  hipLaunchKernelGGL(gg_notify_kernel, dim3(1), dim3(64), 0, stream, hdr, remote_flag, nslots, need, nbtiles);
+hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, const int *need, int *tile_iter, int nbtiles, hipStream_t stream) {
+  hipLaunchKernelGGL(gg_notify_kernel, dim3(1), dim3(64), 0, stream, hdr, remote_flag, nslots, need, tile_iter, nbtiles);
   return hipGetLastError();
 }
-hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, int nbtiles, hipStream_t stream) {
-  hipLaunchKernelGGL(gg_wait_kernel, dim3(1), dim3(64), 0, stream, hdr, nslots, max_polls, nbtiles);
+hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, const int *tile_iter, hipStream_t stream) {
+  hipLaunchKernelGGL(gg_wait_kernel, dim3(1), dim3(64), 0, stream, hdr, nslots, max_polls, tile_iter);
   return hipGetLastError();
 }
 

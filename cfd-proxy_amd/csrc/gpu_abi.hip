@@ -252,7 +252,7 @@ extern "C++" int cfdp_detail::ipc_settle(cfdp_gpu *g) {
   if (!g->ipc.on || !g->ipc.wait_pending) return 0;
   g->ipc.wait_pending = false;
   g->main_marked = false;
-  HIP_TRY(gg_launch_wait(g->ipc_hdr(), (int)g->partner.size(), ipc_max_polls(), g->ipc.counters ? g->nbtiles : 0, g->s_main));
+  HIP_TRY(gg_launch_wait(g->ipc_hdr(), (int)g->partner.size(), ipc_max_polls(), g->ipc.counters ? g->ipc.d_tile_iter : nullptr, g->s_main));
   return 0;
 }
 

@@ -276,8 +276,8 @@ extern "C++" void cfdp_detail::ipc_release(cfdp_gpu *g) {
   I.d_pt_first = nullptr; I.d_tile_xoff = nullptr;
   I.d_slot_of_row = I.d_send_off = I.d_tile_off = I.d_ent = I.d_ent_row = nullptr;
   I.inkernel = false;
-  (void)hipFree(I.d_done); (void)hipFree(I.d_need); (void)hipFree(I.d_tile_mask);
-  I.d_done = I.d_need = nullptr; I.d_tile_mask = nullptr; I.per_partner = false; I.counters = false;
+  (void)hipFree(I.d_done); (void)hipFree(I.d_need); (void)hipFree(I.d_tile_mask); (void)hipFree(I.d_tile_iter);
+  I.d_done = I.d_need = I.d_tile_iter = nullptr; I.d_tile_mask = nullptr; I.per_partner = false; I.counters = false;
   (void)hipFree(I.flags); I.flags = nullptr;
   (void)hipFree(I.block); I.block = nullptr;
   I.on = false; I.xiter = 0;
@@ -319,6 +319,7 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
       pa.nbtiles = g->nbtiles; pa.nslots = nslots;
       pa.inv_after_flag = I.mode == 2 ? 1 : 0;
       pa.counters = I.counters ? 1 : 0;
+      pa.tile_iter = I.d_tile_iter;
       pa.wait_polls = I.wait_pending && I.wait_inkernel && !I.fault_skip_wait ? (long)ipc_max_polls() : 0;
       const int rc = launch_fused(g, CFDP_TILES_ALL, g->s_main, &pa);
       if (rc == 1) return 1;
@@ -333,14 +334,14 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
       if (fork_comm(g)) return 1;  // the comm stream forks off the main stream here
       if (grad_tiles(CFDP_TILES_BOUNDARY, g->s_comm)) return 1;
       HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_comm));
-      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, I.counters ? I.d_need : nullptr, g->nbtiles, g->s_comm));
+      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, I.counters ? I.d_need : nullptr, I.d_tile_iter, g->nbtiles, g->s_comm));
       HIP_TRY(hipEventRecord(g->ev_senddone, g->s_comm));
       if (grad_tiles(CFDP_TILES_INTERIOR, g->s_main)) return 1;
       HIP_TRY(hipStreamWaitEvent(g->s_main, g->ev_senddone, 0));
     } else {
       if (grad_tiles(CFDP_TILES_ALL, g->s_main)) return 1;
       HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_main));
-      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, I.counters ? I.d_need : nullptr, g->nbtiles, g->s_main));
+      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, I.counters ? I.d_need : nullptr, I.d_tile_iter, g->nbtiles, g->s_main));
     }
     if (fused) fused_done(g);
     I.xiter++;  // from here on the ghost block is the arena this exchange lands in
@@ -418,6 +419,8 @@ int cfdp_gpu_ipc_configure(cfdp_gpu *g, int memory_mode, int wait_inkernel, int 
 }
 
 int cfdp_gpu_ipc_header_bytes(void) { return GG_IPC_HDR_BYTES; }
+// where, in a rank's block (or flag block), the word of partner slot `slot` lives: a cache line of its own
+size_t cfdp_gpu_ipc_flag_offset(int slot) { return (size_t)slot * GG_IPC_SLOT_STRIDE * sizeof(int); }
 
 int cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes) {
   NEED_UPLOAD(g);
@@ -507,7 +510,7 @@ int cfdp_gpu_ipc_connect_loopback(cfdp_gpu *g, int slot) {
   const size_t base = GG_IPC_HDR_BYTES + (size_t)g->recv_off[slot] * 21 * sizeof(double);
   I.dst[0][slot] = reinterpret_cast<double *>(I.block + base);
   I.dst[1][slot] = reinterpret_cast<double *>(I.block + base + I.land_bytes);
-  I.rflag[slot] = g->ipc_hdr() + slot;
+  I.rflag[slot] = g->ipc_hdr() + slot * GG_IPC_SLOT_STRIDE;
   return 0;
 }
 
@@ -646,6 +649,8 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
   }
   HIP_TRY(hipMalloc(&I.d_done, sizeof(int) * (GG_IPC_MAXSLOTS + 1) * GG_DONE_STRIDE));
   HIP_TRY(cfdp_memset_sync(I.d_done, 0, sizeof(int) * (GG_IPC_MAXSLOTS + 1) * GG_DONE_STRIDE));
+  HIP_TRY(hipMalloc(&I.d_tile_iter, sizeof(int) * (size_t)(g->nbtiles > 0 ? g->nbtiles : 1)));
+  HIP_TRY(cfdp_memset_sync(I.d_tile_iter, 0, sizeof(int) * (size_t)(g->nbtiles > 0 ? g->nbtiles : 1)));
   if (flush_flux(g)) return 1;
   HIP_TRY(hipDeviceSynchronize());
   // the ghost rows move into the landing arenas
@@ -691,13 +696,14 @@ int cfdp_gpu_ipc_disconnect(cfdp_gpu *g) {
 int cfdp_gpu_ipc_error(cfdp_gpu *g) {
   if (!g || !g->ipc.block) return 0;
   if (hipSetDevice(g->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
-  int h[64];
-  if (hipMemcpy(h, g->ipc_hdr(), sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  const int *e = h + GG_IPC_ERR;
+  int h[8], slot0 = 0;  // [ITER, ERR .. ERR + 4]
+  if (hipMemcpy(h, g->ipc_hdr() + GG_IPC_ITER, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemcpy(&slot0, g->ipc_hdr(), sizeof slot0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  const int *e = h + (GG_IPC_ERR - GG_IPC_ITER);
   if (getenv("CFDP_DEBUG_TRACE"))
-    fprintf(stderr, "[cfdp] ipc state: host xiter %ld, device iteration counter %d (boundary tiles counted: %d), arrival "
-                    "word of slot 0: %d; %d waits gave up (last: slot %d, waiting for %d, saw %d)\n",
-            g->ipc.xiter, h[GG_IPC_ITER], h[GG_IPC_TILES], h[0], e[4], e[1], e[2], e[3]);
+    fprintf(stderr, "[cfdp] ipc state: host xiter %ld, device iteration counter %d (flag notification), arrival word of slot 0: "
+                    "%d; %d waits gave up (last: slot %d, waiting for %d, saw %d)\n",
+            g->ipc.xiter, h[0], slot0, e[4], e[1], e[2], e[3]);
   return e[0] != 0;
 }
 

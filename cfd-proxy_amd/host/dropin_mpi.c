@@ -112,8 +112,9 @@ static int ipc_setup(cfdp_gpu *gpu, int r, int G) {
     for (int i = 0; i < pi->np; i++)
       if (pi->partner[i] == r) t = i;
     const size_t base = CFDP_IPC_HEADER_BYTES + (size_t)pi->recv_off[t < 0 ? 0 : t] * NGRAD * 3 * sizeof(double);
-    ok = t >= 0 && cfdp_gpu_ipc_connect(gpu, s, pi->handle, base, base + (size_t)pi->land, 4 * (size_t)t) == 0 &&
-         cfdp_gpu_ipc_connect_flags(gpu, s, pi->fhandle, 4 * (size_t)t) == 0; /* (a block of its own in "split" mode) */
+    const size_t foff = cfdp_gpu_ipc_flag_offset(t < 0 ? 0 : t); /* the word of my slot there: a cache line of its own */
+    ok = t >= 0 && cfdp_gpu_ipc_connect(gpu, s, pi->handle, base, base + (size_t)pi->land, foff) == 0 &&
+         cfdp_gpu_ipc_connect_flags(gpu, s, pi->fhandle, foff) == 0; /* (a block of its own in "split" mode) */
   }
   ok = ok && cfdp_gpu_ipc_ready(gpu) == 0;
   int all_ok = 0;

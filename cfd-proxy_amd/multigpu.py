@@ -370,8 +370,9 @@ class RankSolver:
                 pi = gathered[p]
                 t = pi["partners"].index(self.rank)
                 base = self.gpu.lib.cfdp_gpu_ipc_header_bytes() + pi["recv_off"][t] * 8 * ROWLEN
-                self.gpu.ipc_connect(s, pi["handle"], base, base + pi["land"], 4 * t)
-                self.gpu.ipc_connect_flags(s, pi["fhandle"], 4 * t)  # (a block of its own in "split" mode)
+                foff = self.gpu.lib.cfdp_gpu_ipc_flag_offset(t)  # (the word of my slot there: a cache line of its own)
+                self.gpu.ipc_connect(s, pi["handle"], base, base + pi["land"], foff)
+                self.gpu.ipc_connect_flags(s, pi["fhandle"], foff)  # (a block of its own in "split" mode)
             self.gpu.ipc_ready()
         except Exception as e:
             ok, self._ipc_why = False, str(e)
