@@ -419,6 +419,62 @@ __device__ __forceinline__ void wait_previous_exchange(const gg_push_args &pa, i
   __syncthreads();
 }
 
+// The same wait with its FIRST poll overlapped with the tile's staging (the phase-split pass): a system-scope load goes
+// past every cache -- 1-2 us under load -- and with the wait in front of everything a boundary tile paid that round trip
+// before it requested a single byte, every pass.  Here wave 0 requests its partners' words at the very top of the tile
+// (wait_first_poll: untracked loads, older than every staging load of the wave, so the counted vmcnt in front of the row
+// gathers covers them), the descriptor, the row numbers and the blob travel meanwhile, and wait_check -- placed where the
+// row numbers have arrived, in front of the first request for a ghost row -- finds the word there in the common case
+// (partner not late) and polls on only otherwise.  The other waves meet wave 0 at a raw s_barrier (no memory wait: the
+// blob stays in flight) before they request rows.
+__device__ __forceinline__ int ld_i32_nowait(const int *p);
+__device__ __forceinline__ unsigned long long ld_u64_nowait(const void *p);
+__device__ __forceinline__ int ld_i32_sys_nowait(const int *p) {
+  int v;  // global_load_dword ... sc0 sc1 (system scope); not tracked by the compiler: the caller waits (counted vmcnt)
+  asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ bool wait_wanted(const gg_push_args &pa, int tile) {  // uniform per workgroup
+  return pa.tile_off && tile < pa.nbtiles && (pa.wait_polls > 0 || pa.inv_after_flag);
+}
+struct gg_wait_probe {  // what wave 0 requests at the top of a boundary tile (every field an untracked load)
+  int word = 0, nin = 1, err = 0;
+  unsigned long long mask = ~0ull;
+};
+__device__ __forceinline__ void wait_first_poll(const gg_push_args &pa, int tile, int tid, gg_wait_probe &w) {
+  if (tid >= 64) return;  // wave 0, every lane (clamped): what the wave issues does not depend on data
+  const int *slot = pa.hdr + (tid < pa.nslots ? tid : pa.nslots - 1) * GG_IPC_SLOT_STRIDE;
+  w.word = ld_i32_sys_nowait(slot);
+  w.nin = ld_i32_sys_nowait(slot + GG_IPC_NEED_IN);
+  w.err = ld_i32_nowait(pa.hdr + GG_IPC_ERR);
+  if (pa.need) w.mask = ld_u64_nowait(pa.tile_mask + tile);
+}
+__device__ __forceinline__ void wait_check(const gg_push_args &pa, int tile, int tid, int iter0, gg_wait_probe w) {
+  if (tid < 64) {
+    asm volatile("" : "+v"(w.word), "+v"(w.nin), "+v"(w.err), "+v"(w.mask));  // (uses stay behind the caller's counted wait)
+    const int word = w.word, nin = w.nin;
+    const bool mine = pa.wait_polls > 0 && tid < pa.nslots && ((w.mask >> tid) & 1ull);
+    if (mine && !w.err) {
+      const int *slot = pa.hdr + tid * GG_IPC_SLOT_STRIDE;
+      const int need = pa.counters ? iter0 * nin : iter0;
+      bool ok = (int)((unsigned)word - (unsigned)need) >= 0;
+      for (long k = 0; k < pa.wait_polls && !ok; k++) {  // the partner IS late: poll on (relaxed, see wait_previous_exchange)
+        __builtin_amdgcn_s_sleep(32);
+        ok = (int)((unsigned)__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)need) >= 0;
+      }
+      if (!ok) {
+        pa.hdr[GG_IPC_ERR] = 1;
+        pa.hdr[GG_IPC_ERR + 1] = tid;
+        pa.hdr[GG_IPC_ERR + 2] = need;
+        pa.hdr[GG_IPC_ERR + 3] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        atomicAdd(&pa.hdr[GG_IPC_ERR + 4], 1);
+      }
+    }
+    if (pa.inv_after_flag) asm volatile("buffer_inv sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");  // split mode, see above
+  }
+  asm volatile("s_barrier" ::: "memory");  // the other waves request ghost rows only behind wave 0's verdict
+}
+
 // After the pushes of a boundary tile: count it.  Every wave has waited for the acknowledgement of its (write-through)
 // remote stores before the tile is counted.
 // Coarse protocol (pa.need == nullptr): ONE counter; the last boundary tile of the launch raises this rank's iteration
@@ -968,10 +1024,13 @@ void gg_fused_split_kernel(
     gg_stamp_buf[(size_t)t * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                                      (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
   int iter0 = 0;
+  gg_wait_probe wprobe;
+  bool waiting = false;  // uniform: this boundary tile owes the previous exchange a wait (or split mode its invalidate)
   unsigned long long pfirst = ~0ull;  // {partner slot or -1, row}: where this lane's point goes first (boundary tiles)
   if constexpr (PUSH) {
     if (pa.tile_off && t < pa.nbtiles) iter0 = exchanges_so_far(pa, t);  // uniform: scalar loads
-    if (!(dbg & 0x100)) wait_previous_exchange(pa, t, tid, iter0);  // before any ghost row is requested
+    waiting = !(dbg & 0x100) && wait_wanted(pa, t);
+    if (waiting) wait_first_poll(pa, t, tid, wprobe);  // the partners' words travel with the staging loads below
     if (pa.tile_off && t < pa.nbtiles) pfirst = ld_u64_nowait(pa.pt_first + (size_t)t * pa.pt_stride + (tid >> 2));
   }
   int hv[KV], hg[KG], part[KG], rloc[KG];
@@ -1028,6 +1087,8 @@ void gg_fused_split_kernel(
   for (int k = 0; k < KV; k++) asm volatile("" : "+v"(hv[k]));
 #pragma unroll
   for (int k = 0; k < KG; k++) asm volatile("" : "+v"(hg[k]));
+  if constexpr (PUSH)
+    if (waiting) wait_check(pa, t, tid, iter0, wprobe);  // before any ghost row is requested
   double *push_row = nullptr;  // this lane's point, in its first partner's arena (the slice pointer travels with the rows)
   if constexpr (PUSH) {
     asm volatile("" : "+v"(pfirst));
