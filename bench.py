@@ -500,7 +500,7 @@ def main() -> None:
             solver = part = None
         try:
             xres, _, _ = measure(mg.bench_config(extra[1], world))
-            out[extra[0]] = {k: xres[k] for k in ("value", "ms_per_step", "scaling", "config", "clock_conditioning", "exchange_check", "overlap")
+            out[extra[0]] = {k: xres[k] for k in ("value", "ms_per_step", "scaling", "shared_gpu", "config", "clock_conditioning", "exchange_check", "overlap")
                              if k in xres}
         except Exception as e:  # the extra must never cost the line
             out[extra[0]] = {"error": repr(e)[:300]}

@@ -19,7 +19,7 @@ if sys.argv[1] == "run":
     g.ipc_ready()
     g.run_steps_ipc(200, with_exchange=True, overlap=True); g.sync()
     for rep in range(4):
-        g.run_steps_ipc(20, with_exchange=True, overlap=True); g.sync()
+        g.run_steps_ipc(20, with_exchange=bool(int(os.environ.get("EXCH", "1"))), overlap=True, use_graph=int(os.environ.get("UG", "2"))); g.sync()
     g.ipc_disconnect(); g.close()
 else:
     f = sorted(glob.glob(os.path.join(sys.argv[2], "*", "*_kernel_trace.csv")), key=os.path.getmtime)[-1]
