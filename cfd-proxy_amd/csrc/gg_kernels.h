@@ -76,9 +76,11 @@ struct gg_args {
 hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int ntiles,
                               int tile_points, size_t lds, int max_halo, int max_blob_qw,
                               bool nt, hipStream_t stream);
+// wait != nullptr: the boundary tiles wait for the previous exchange themselves (only where gg_flux_can_wait says so)
 hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_begin, int ntiles,
                           int tile_points, size_t lds, int max_halo, int max_blob_qw, bool nt,
-                          hipStream_t stream);
+                          hipStream_t stream, const gg_push_args *wait = nullptr);
+bool gg_flux_can_wait(int lanes, int tile_points, int max_halo, int max_blob_qw);
 // flux(i) read from a.grad + gradients(i+1) written to `gnew` in one pass over the tile blobs;
 // hipErrorNotSupported when the tile sizes fit no instantiated capacity
 // allow_split: the phase-split form (36 instead of 48 KiB of LDS per tile, 4 workgroups per CU) may

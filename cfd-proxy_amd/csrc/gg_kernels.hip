@@ -808,13 +808,17 @@ __global__ __launch_bounds__(1024) void gg_flux_kernel(
 // pieces per wave, the gradient rows as KV pieces per wave -- 5 pieces (80 bytes) per row: own
 // rows by position and owned halo rows by number from part A, ghost halo rows = the first 80
 // bytes of their 168-byte row in the ghost block
-template <int LPP, bool REFMODE, bool NT, int CB, int KV>
+// WAIT: the flux that closes a batch of exchanging iterations -- its boundary tiles wait for the rows of the last exchange
+// themselves (as the boundary tiles of a pushing pass do), so that no wait kernel stands between the last pass and it
+template <int LPP, bool REFMODE, bool NT, int CB, int KV, bool WAIT = false>
 __global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
     const int *__restrict__ halo_idx, const double *__restrict__ gradA /*[nown][10]*/,
-    const double *__restrict__ ghost /*[nghost][21]*/, double *__restrict__ flux /*[nown][3]*/, int nown) {
+    const double *__restrict__ ghost /*[nghost][21]*/, double *__restrict__ flux /*[nown][3]*/, int nown, gg_push_args pa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
+  if constexpr (WAIT)
+    if (pa.tile_off && t < pa.nbtiles) wait_previous_exchange(pa, t, (int)threadIdx.x, exchanges_so_far(pa, t));
   const cfdp_tile_desc td = tiles[t];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, w0 = tid & ~63;
@@ -1398,10 +1402,17 @@ template <int L, bool R> hipError_t launch_flux_generic(const gg_args &a, bool n
 }
 
 template <bool R, int CB, int KV> hipError_t launch_flux_dma(const gg_args &a, bool nt, int tile_begin, int ntiles, int block,
-                                                             hipStream_t stream) {
+                                                             hipStream_t stream, const gg_push_args *wait) {
   const size_t lds = (size_t)(CB + KV) * block * 16;
-  if (nt) return launch(gg_flux_dma_kernel<8, R, true, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown);
-  return launch(gg_flux_dma_kernel<8, R, false, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown);
+  gg_push_args pa;
+  memset(&pa, 0, sizeof pa);
+  if (wait) {
+    pa = *wait;
+    if (nt) return launch(gg_flux_dma_kernel<8, R, true, CB, KV, true>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown, pa);
+    return launch(gg_flux_dma_kernel<8, R, false, CB, KV, true>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown, pa);
+  }
+  if (nt) return launch(gg_flux_dma_kernel<8, R, true, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown, pa);
+  return launch(gg_flux_dma_kernel<8, R, false, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown, pa);
 }
 
 template <bool R, bool N, int D, bool L, bool P>
@@ -1459,9 +1470,18 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
   }
 }
 
+// can the flux kernel these tile sizes select wait for an exchange in its boundary tiles (gg_launch_flux's `wait`)?
+bool gg_flux_can_wait(int lanes, int tile_points, int max_halo, int max_blob_qw) {
+  const int block = ((tile_points * lanes + 63) / 64) * 64;
+  if (block > 1024 || lanes != 8 || (gg_debug_flags & 16)) return false;
+  const int cb = (max_blob_qw + block - 1) / block, kv = ((tile_points + max_halo) * 5 + block - 1) / block;
+  return cb >= 1 && kv >= 1 && cb <= 6 && kv <= 4 && (size_t)(6 + 4) * block * 16 <= LDS_MAX;
+}
+
 hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_begin, int ntiles, int tile_points, size_t lds,
-                          int max_halo, int max_blob_qw, bool nt, hipStream_t stream) {
+                          int max_halo, int max_blob_qw, bool nt, hipStream_t stream, const gg_push_args *wait) {
   if (ntiles <= 0) return hipSuccess;
+  if (wait && !gg_flux_can_wait(lanes, tile_points, max_halo, max_blob_qw)) return hipErrorNotSupported;
   const int block = ((tile_points * lanes + 63) / 64) * 64;
   if (block > 1024) return hipErrorInvalidConfiguration;
   if (lanes == 8 && !(gg_debug_flags & 16)) {  // fixed-count LDS-DMA staging
@@ -1469,8 +1489,8 @@ hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_be
     const int kv = ((tile_points + max_halo) * 5 + block - 1) / block;
 #define FLUX_DMA(CB, KV)                                                                                 \
   if (cb <= CB && kv <= KV && (size_t)(CB + KV) * block * 16 <= LDS_MAX)                                   \
-    return refmode ? launch_flux_dma<true, CB, KV>(a, nt, tile_begin, ntiles, block, stream)               \
-                   : launch_flux_dma<false, CB, KV>(a, nt, tile_begin, ntiles, block, stream)
+    return refmode ? launch_flux_dma<true, CB, KV>(a, nt, tile_begin, ntiles, block, stream, wait)         \
+                   : launch_flux_dma<false, CB, KV>(a, nt, tile_begin, ntiles, block, stream, wait)
     if (cb >= 1 && kv >= 1) {
       FLUX_DMA(3, 2);
       FLUX_DMA(4, 3);

@@ -270,11 +270,27 @@ extern "C++" int cfdp_detail::scaled_lag(const cfdp_gpu *g, int with_flux) { ret
 
 // run the deferred flux of the last fused-mode iteration, if any
 extern "C++" int cfdp_detail::flush_flux(cfdp_gpu *g, bool record, hipStream_t st) {
-  if (ipc_settle(g)) return 1;
-  if (g->flux_pending < 0) return 0;
+  if (g->flux_pending < 0) return ipc_settle(g);
+  // the flux that closes a run of exchanging iterations reads the ghost rows of the LAST exchange: where the passes'
+  // boundary tiles wait themselves and the flux kernel of these tiles can do the same, ITS boundary tiles wait -- no wait
+  // kernel (4-5 us and a kernel boundary) between the last pass and the flux; everywhere else the wait kernel first
+  gg_push_args wa;
+  const gg_push_args *wait = nullptr;
+  {
+    auto &I = g->ipc;
+    const tile_range r = range_of(g, CFDP_TILES_ALL);
+    if (I.on && I.wait_pending && I.inkernel && I.wait_inkernel && !I.fault_skip_wait && (!st || st == g->s_main) &&
+        gg_flux_can_wait(g->flux_lanes, r.tp, r.row_halo(), r.max_blob)) {
+      ipc_push_args(g, (int)(I.xiter & 1), &wa);
+      wait = &wa;
+      I.wait_pending = false;  // absorbed by the flux kernel's boundary tiles
+    } else if (ipc_settle(g)) {
+      return 1;
+    }
+  }
   const int mode = g->flux_pending;
   g->flux_pending = -1;
-  if (launch_flux(g, mode, st ? st : g->s_main)) return 1;
+  if (launch_flux(g, mode, st ? st : g->s_main, wait)) return 1;
   if (scaled_tail(g, 1, false, st ? st : g->s_main)) return 1;
   if (record) {
     HIP_TRY(hipEventRecord(g->ev_fluxdone, st ? st : g->s_main));
@@ -451,17 +467,19 @@ extern "C++" int cfdp_detail::launch_grad(cfdp_gpu *g, int which, hipStream_t st
   return 0;
 }
 
-extern "C++" int cfdp_detail::launch_flux_tiles(cfdp_gpu *g, int mode, int which, hipStream_t st) {
+extern "C++" int cfdp_detail::launch_flux_tiles(cfdp_gpu *g, int mode, int which, hipStream_t st, const gg_push_args *wait) {
   g->main_marked = false;
   g->last_flux_mode = mode;
   const gg_args a = g->args();
   const tile_range r = range_of(g, which);
   HIP_TRY(gg_launch_flux(a, g->flux_lanes, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.lds_flux, r.row_halo(),
-                         r.max_blob, g->streaming, st));
+                         r.max_blob, g->streaming, st, wait));
   return 0;
 }
 
-extern "C++" int cfdp_detail::launch_flux(cfdp_gpu *g, int mode, hipStream_t st) { return launch_flux_tiles(g, mode, CFDP_TILES_ALL, st); }
+extern "C++" int cfdp_detail::launch_flux(cfdp_gpu *g, int mode, hipStream_t st, const gg_push_args *wait) {
+  return launch_flux_tiles(g, mode, CFDP_TILES_ALL, st, wait);
+}
 
 // the deferred flux (from d_grad) + the next gradients (into d_grad_alt) over the selected tiles
 // in one pass; falls back to the two separate kernels when no fused capacity fits the tiles.

@@ -282,12 +282,13 @@ int mark_main(cfdp_gpu *g);
 int fork_comm(cfdp_gpu *g);
 __attribute__((visibility("hidden"))) tile_range range_of(const cfdp_gpu *g, int which);
 int launch_grad(cfdp_gpu *g, int which, hipStream_t st, const gg_grad_view *into = nullptr);
-__attribute__((visibility("hidden"))) int launch_flux_tiles(cfdp_gpu *g, int mode, int which, hipStream_t st);
-int launch_flux(cfdp_gpu *g, int mode, hipStream_t st);
+__attribute__((visibility("hidden"))) int launch_flux_tiles(cfdp_gpu *g, int mode, int which, hipStream_t st, const gg_push_args *wait = nullptr);
+int launch_flux(cfdp_gpu *g, int mode, hipStream_t st, const gg_push_args *wait = nullptr);
 int launch_fused(cfdp_gpu *g, int which, hipStream_t st, const gg_push_args *push = nullptr);
 void fused_done(cfdp_gpu *g);
 // gpu_exchange.hip
 void ipc_release(cfdp_gpu *g);
+void ipc_push_args(cfdp_gpu *g, int parity, gg_push_args *out);
 long ipc_max_polls();
 void drop_ipc_graphs(cfdp_gpu *g);
 }  // namespace cfdp_detail

@@ -283,6 +283,22 @@ extern "C++" void cfdp_detail::ipc_release(cfdp_gpu *g) {
   I.on = false; I.xiter = 0;
 }
 
+// the tables a tile of the pass (or of the closing flux kernel) needs to push, notify and wait
+extern "C++" void cfdp_detail::ipc_push_args(cfdp_gpu *g, int par, gg_push_args *out) {
+  auto &I = g->ipc;
+  gg_push_args pa;
+  pa.tile_off = I.d_tile_off; pa.ent = I.d_ent; pa.ent_row = I.d_ent_row; pa.dst = I.d_dst[par];
+  pa.hdr = g->ipc_hdr(); pa.rflag = I.d_rflag; pa.done = I.d_done;
+  pa.need = I.per_partner ? I.d_need : nullptr; pa.tile_mask = I.per_partner ? I.d_tile_mask : nullptr;
+  pa.pt_first = I.d_pt_first; pa.pt_stride = I.pt_stride; pa.tile_xoff = I.d_tile_xoff;
+  pa.nbtiles = g->nbtiles; pa.nslots = (int)g->partner.size();
+  pa.inv_after_flag = I.mode == 2 ? 1 : 0;
+  pa.counters = I.counters ? 1 : 0;
+  pa.tile_iter = I.d_tile_iter;
+  pa.wait_polls = I.wait_pending && I.wait_inkernel && !I.fault_skip_wait ? (long)ipc_max_polls() : 0;
+  *out = pa;
+}
+
 namespace {
 int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   const bool comm = with_exchange && !g->partner.empty();
@@ -312,15 +328,7 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
       // rows arrive while the interior tiles run.  (Both exchange schedules map to this one: a
       // fork/join between two streams costs 8-18 us per iteration inside a hipGraph.)
       gg_push_args pa;
-      pa.tile_off = I.d_tile_off; pa.ent = I.d_ent; pa.ent_row = I.d_ent_row; pa.dst = I.d_dst[par];
-      pa.hdr = g->ipc_hdr(); pa.rflag = I.d_rflag; pa.done = I.d_done;
-      pa.need = I.per_partner ? I.d_need : nullptr; pa.tile_mask = I.per_partner ? I.d_tile_mask : nullptr;
-      pa.pt_first = I.d_pt_first; pa.pt_stride = I.pt_stride; pa.tile_xoff = I.d_tile_xoff;
-      pa.nbtiles = g->nbtiles; pa.nslots = nslots;
-      pa.inv_after_flag = I.mode == 2 ? 1 : 0;
-      pa.counters = I.counters ? 1 : 0;
-      pa.tile_iter = I.d_tile_iter;
-      pa.wait_polls = I.wait_pending && I.wait_inkernel && !I.fault_skip_wait ? (long)ipc_max_polls() : 0;
+      ipc_push_args(g, par, &pa);
       const int rc = launch_fused(g, CFDP_TILES_ALL, g->s_main, &pa);
       if (rc == 1) return 1;
       pushed = rc == 0;
