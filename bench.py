@@ -576,11 +576,11 @@ def main() -> None:
                         best = min(best, (time.perf_counter() - t_) / steps)
                     return best * 1e6
 
-                def loopback(notify):
+                def loopback(notify, push_inkernel=None):
                     """one row of the table: the memory mode the hosts try first, the given notification form"""
                     g8 = pkg.GpuPartition(parts8[0], device=device)
                     g8.set_fusion(True)
-                    g8.ipc_configure(memory_mode=mg.ipc_mode_attempts()[0], notify=notify)
+                    g8.ipc_configure(memory_mode=mg.ipc_mode_attempts()[0], notify=notify, push_inkernel=push_inkernel)
                     g8.ipc_export()
                     for s_ in range(len(g8.partners())):
                         g8._ck(g8.lib.cfdp_gpu_ipc_connect_loopback(g8.h, s_))
@@ -601,8 +601,12 @@ def main() -> None:
                     return row
                 lb[name] = loopback("counter")
                 flag = loopback("flag")
-                lb[name]["flag_notification"] = {k: flag[k] for k in ("us_per_iteration_with_exchange", "efficiency_bound",
-                                                                       "steps20_with_exchange", "steps20_ratio", "wait_timeouts")}
+                keys = ("us_per_iteration_with_exchange", "efficiency_bound", "steps20_with_exchange", "steps20_ratio", "wait_timeouts")
+                lb[name]["flag_notification"] = {k: flag[k] for k in keys}
+                # the conservative rung on the same mappings (the hosts try it after every in-kernel rung, before RCCL):
+                # push, notify and wait as kernels of their own, flags, release / acquire at kernel boundaries
+                sep = loopback("flag", push_inkernel=False)
+                lb[name]["push_notify_wait_kernels"] = {k: sep[k] for k in keys}
                 # the fall-back branch priced on the same partition: grouped ncclSend / ncclRecv issued by the C library from
                 # the streams (RCCL cannot be captured into a hipGraph in this ROCm: replay hangs), a communicator of ONE rank
                 # exchanging with itself -- pack kernel + RCCL kernel + stream launches per iteration, no link crossed

@@ -270,7 +270,7 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_gpu_ipc_connect_flags.argtypes = [vp, C.c_int, vp, C.c_size_t]
     lib.cfdp_gpu_ipc_mode.argtypes = [vp]
     lib.cfdp_gpu_ipc_graph_stats.argtypes = [vp, P(C.c_long), P(C.c_long), P(C.c_long)]
-    lib.cfdp_gpu_ipc_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.cfdp_gpu_ipc_configure.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_rccl_nranks.argtypes = [vp]
     lib.cfdp_gpu_ipc_flag_offset.argtypes = [C.c_int]
     lib.cfdp_gpu_ipc_flag_offset.restype = C.c_size_t
@@ -827,13 +827,15 @@ class GpuPartition:
 
     IPC_MODES = {"coarse": 0, "fine": 1, "split": 2}
 
-    def ipc_configure(self, memory_mode=None, wait_inkernel=None, notify=None) -> None:
-        """cfdp_gpu_ipc_configure: memory_mode "coarse" | "fine" | "split", wait_inkernel bool, notify "counter" | "flag";
-        None = what the environment says, else the library default.  Takes effect at the next ipc_export / ipc_ready"""
+    def ipc_configure(self, memory_mode=None, wait_inkernel=None, notify=None, push_inkernel=None) -> None:
+        """cfdp_gpu_ipc_configure: memory_mode "coarse" | "fine" | "split", wait_inkernel bool, notify "counter" | "flag",
+        push_inkernel bool (False: push / notify / wait as kernels of their own); None = what the environment says, else
+        the library default.  Takes effect at the next ipc_export / ipc_ready"""
         self._ck(self.lib.cfdp_gpu_ipc_configure(
             self.h, -1 if memory_mode is None else self.IPC_MODES[memory_mode],
             -1 if wait_inkernel is None else int(bool(wait_inkernel)),
-            -1 if notify is None else {"counter": 1, "flag": 0}[notify]))
+            -1 if notify is None else {"counter": 1, "flag": 0}[notify],
+            -1 if push_inkernel is None else int(bool(push_inkernel))))
 
     def ipc_graph_stats(self) -> dict:
         """steps of run_steps_ipc replayed from hipGraphs / launched from the streams, captures abandoned"""

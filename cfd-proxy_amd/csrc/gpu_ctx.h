@@ -95,7 +95,7 @@ struct cfdp_gpu {
     // notification: per partner (done[1 + s] / need[s] / tile_mask[t], gg_push_args) or one counter for all partners
     bool per_partner = false;
     bool counters = false;  // notification by counters (gg_push_args::counters); needs the per-partner protocol
-    int cfg_mode = -1, cfg_wait_inkernel = -1, cfg_notify = -1;  // cfdp_gpu_ipc_configure (-1: environment / default)
+    int cfg_mode = -1, cfg_wait_inkernel = -1, cfg_notify = -1, cfg_inkernel = -1;  // cfdp_gpu_ipc_configure (-1: environment / default)
     int *d_done = nullptr, *d_need = nullptr, *d_tile_iter = nullptr;
     unsigned long long *d_tile_mask = nullptr;
     size_t land_bytes = 0;

@@ -416,13 +416,17 @@ static int ipc_open(cfdp_gpu *g, const void *handle64, unsigned char **base_out)
 //   memory_mode    0 coarse, 1 fine, 2 split                        (CFDP_IPC_MODE)
 //   wait_inkernel  1 the boundary tiles wait themselves, 0 wait kernel (CFDP_IPC_WAIT_INKERNEL; ranks sharing a device: 0)
 //   notify         1 counters (fire-and-forget atomic adds), 0 flags   (CFDP_IPC_NOTIFY=counter|flag)
-int cfdp_gpu_ipc_configure(cfdp_gpu *g, int memory_mode, int wait_inkernel, int notify) {
+//   push_inkernel  1 the fused pass pushes and notifies itself, 0 push / notify / wait are kernels of their own -- the
+//                  conservative rung: release / acquire at kernel boundaries instead of inside a kernel (CFDP_IPC_INKERNEL)
+int cfdp_gpu_ipc_configure(cfdp_gpu *g, int memory_mode, int wait_inkernel, int notify, int push_inkernel) {
   if (!g) return fail("null context");
-  if (memory_mode < -1 || memory_mode > 2 || wait_inkernel < -1 || wait_inkernel > 1 || notify < -1 || notify > 1)
-    return fail("cfdp_gpu_ipc_configure(%d, %d, %d): out of range", memory_mode, wait_inkernel, notify);
+  if (memory_mode < -1 || memory_mode > 2 || wait_inkernel < -1 || wait_inkernel > 1 || notify < -1 || notify > 1 ||
+      push_inkernel < -1 || push_inkernel > 1)
+    return fail("cfdp_gpu_ipc_configure(%d, %d, %d, %d): out of range", memory_mode, wait_inkernel, notify, push_inkernel);
   g->ipc.cfg_mode = memory_mode;
   g->ipc.cfg_wait_inkernel = wait_inkernel;
   g->ipc.cfg_notify = notify;
+  g->ipc.cfg_inkernel = push_inkernel;
   return 0;
 }
 
@@ -608,7 +612,7 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       // the tiles push what they have just computed; a send point WITHOUT faces is computed by nobody
       // and its stored row must travel (as pack / the push kernel send it, and the reference's
       // exchange_dbl_copy_in, src/threads.c:791-813): such partitions keep the separate push kernel
-      I.inkernel = g->nbtiles > 0 && !g->faceless_send && !(e && atoi(e) == 0);
+      I.inkernel = g->nbtiles > 0 && !g->faceless_send && (I.cfg_inkernel >= 0 ? I.cfg_inkernel != 0 : !(e && atoi(e) == 0));
       const char *w = getenv("CFDP_IPC_WAIT_INKERNEL");  // 0: always a separate wait kernel (A/B timing)
       I.wait_inkernel = I.cfg_wait_inkernel >= 0 ? I.cfg_wait_inkernel != 0 : !(w && atoi(w) == 0);
       // per-partner notification needs: every boundary tile reads ghost rows only of partners it sends to (then the

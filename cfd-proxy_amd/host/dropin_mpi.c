@@ -256,13 +256,19 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
    * Every attempt is configured by argument -- the process environment stays as the user left it, so the attach of a
    * further multigrid level or solver starts from the user's presets, not from the last rung tried here */
   const char *npre = getenv("CFDP_IPC_NOTIFY");
-  for (int attempt = 0; try_ipc && attempt < 6; attempt++) {
-    const int mi = attempt / 2, counters = attempt % 2 == 0;
+  /* attempts 6-8: the conservative rung on the same mappings -- push, notify and wait as kernels of their own with flags
+   * (release / acquire at kernel boundaries) -- still ahead of RCCL, whose steps cannot be replayed from a hipGraph in this
+   * ROCm (priced in loopback: 53 / 25 us per iteration against 73 / 65 us, dualgrid.384 / .192 partitions) */
+  for (int attempt = 0; try_ipc && attempt < 9; attempt++) {
+    const int separate = attempt >= 6;
+    const int mi = separate ? attempt - 6 : attempt / 2, counters = separate ? 0 : attempt % 2 == 0;
     if (preset && *preset && strcmp(preset, modes[mi])) continue;
-    if (npre && *npre && strcmp(npre, counters ? "counter" : "flag")) continue;
-    (void)cfdp_gpu_ipc_configure(gpu, mode_id[mi], wait_inkernel, counters);
-    char what[160];
-    snprintf(what, sizeof what, "%s, %s notification", labels[mi], counters ? "counter" : "flag");
+    if (!separate && npre && *npre && strcmp(npre, counters ? "counter" : "flag")) continue;
+    if (separate && getenv("CFDP_IPC_INKERNEL")) continue;
+    (void)cfdp_gpu_ipc_configure(gpu, mode_id[mi], wait_inkernel, counters, separate ? 0 : -1);
+    char what[200];
+    snprintf(what, sizeof what, "%s, %s notification%s", labels[mi], counters ? "counter" : "flag",
+             separate ? ", push / notify / wait as kernels of their own" : "");
     if (!ipc_setup(gpu, r, G)) {
       if (r == 0) printf("exchange: HIP IPC setup failed (%s): %s\n", what, cfdp_gpu_last_error());
       ipc_teardown(gpu);

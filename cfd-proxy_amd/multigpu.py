@@ -292,22 +292,27 @@ class RankSolver:
             # from all-reduced evidence only): memory modes of the landing block, and per mode the notification forms.
             # Each attempt is configured BY ARGUMENT (cfdp_gpu_ipc_configure): the process environment is left alone, so
             # a later solver of this process starts from the user's presets again, not from the last rung tried here
-            done = False
-            for mode in ipc_mode_attempts():
-                for notify in ipc_notify_attempts():
-                    self.gpu.ipc_configure(memory_mode=mode, wait_inkernel=wait_in, notify=notify)
-                    self._ipc_mode_now = mode
-                    self._validating = f"ipc / {IPC_MODE_LABEL[mode]}, {IPC_NOTIFY_LABEL[notify]}"
-                    try:
-                        self._init_ipc()
-                        self.available.append("ipc")
-                        done = True
-                        break
-                    except Exception as e:
-                        self.validation.setdefault(self._validating, {"ok": False, "failed": f"setup: {e}"[:160]})
-                        print(f"[rank {rank}] xGMI write+notify setup failed ({self._validating}: {e})", file=sys.stderr)
-                if done:
+            # Last rung on the IPC mappings, before any other transport: push, notify and wait as KERNELS OF THEIR OWN
+            # with flags (plain release stores / acquire loads at kernel boundaries, nothing handed over inside a kernel).
+            # Why it stands in front of RCCL: priced on one GPU, same partitions, steps between two syncs (bench.py,
+            # exchange_protocol_loopback; profiles/r05_bench_n1_steps20.json) an iteration takes 53 / 25 us this way on the
+            # dualgrid.384 / dualgrid.192 partitions (38 / 10 us without exchange) but 73 / 65 us with stream-launched RCCL
+            # send/recv -- RCCL cannot be captured into a hipGraph in this ROCm, so every step pays its launches
+            rungs = [(m, n, None) for m in ipc_mode_attempts() for n in ipc_notify_attempts()]
+            if "CFDP_IPC_INKERNEL" not in os.environ:
+                rungs += [(m, "flag", False) for m in ipc_mode_attempts()]
+            for mode, notify, push_in in rungs:
+                self.gpu.ipc_configure(memory_mode=mode, wait_inkernel=wait_in, notify=notify, push_inkernel=push_in)
+                self._ipc_mode_now = mode
+                self._validating = (f"ipc / {IPC_MODE_LABEL[mode]}, {IPC_NOTIFY_LABEL[notify]}"
+                                    + (", push / notify / wait as kernels of their own" if push_in is False else ""))
+                try:
+                    self._init_ipc()
+                    self.available.append("ipc")
                     break
+                except Exception as e:
+                    self.validation.setdefault(self._validating, {"ok": False, "failed": f"setup: {e}"[:160]})
+                    print(f"[rank {rank}] xGMI write+notify setup failed ({self._validating}: {e})", file=sys.stderr)
             if "ipc" not in self.available and transport == "ipc":
                 transport = "rccl"
         elif transport in ("ipc", "auto"):

@@ -218,11 +218,13 @@ int  cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int over
  * meet (a barrier, a collective) between _ready on every rank and the first exchanging step.
  *   cfdp_gpu_ipc_configure  per context, by argument instead of through the environment (-1 = environment / default):
  *                           memory_mode 0 coarse | 1 fine | 2 split; wait_inkernel 1 | 0 (ranks sharing a device: 0);
- *                           notify 1 counters | 0 flags.  Takes effect at the next _export / _ready.                   */
+ *                           notify 1 counters | 0 flags; push_inkernel 1 the fused pass pushes and notifies itself |
+ *                           0 push, notify and wait are kernels of their own (release / acquire at kernel boundaries:
+ *                           the conservative rung).  Takes effect at the next _export / _ready.                        */
 #define CFDP_IPC_HEADER_BYTES 8192
 int  cfdp_gpu_ipc_header_bytes(void);
 size_t cfdp_gpu_ipc_flag_offset(int slot); /* flag_off of cfdp_gpu_ipc_connect[_flags]: one cache line per partner slot */
-int  cfdp_gpu_ipc_configure(cfdp_gpu *g, int memory_mode, int wait_inkernel, int notify);
+int  cfdp_gpu_ipc_configure(cfdp_gpu *g, int memory_mode, int wait_inkernel, int notify, int push_inkernel);
 int  cfdp_gpu_ipc_export(cfdp_gpu *g, void *handle64, size_t *land_bytes);
 int  cfdp_gpu_ipc_connect(cfdp_gpu *g, int slot, const void *partner_handle64, size_t land_off0,
                           size_t land_off1, size_t flag_off);
