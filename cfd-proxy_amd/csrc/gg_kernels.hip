@@ -677,12 +677,14 @@ __device__ __forceinline__ void glds16_nt(const uint4 *src, unsigned char *lds_w
 // once per incidence: 6 adds + 9 FMAs per incidence instead of ~48 fp64 operations -- the fp64
 // vector rate, not LDS or HBM, bounded this loop (measured: the flux phase cost 64 us of the
 // 331-us fused pass on the 128^3 mesh).  Differs from the reference's association by round-off.
-template <int LPP, bool REFMODE>
+// GS / PRE (timing experiment of round 5 only, EXPERIMENTS.md D.2): rows of GS doubles that already hold P -- no pass over
+// the rows, no barrier
+template <int LPP, bool REFMODE, int GS = 10, bool PRE = true>
 __device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, double *g_l,
                                                   const cfdp_tile_desc &td, const int *__restrict__ hid,
                                                   int tid, int nthr, double *__restrict__ flux, int nown) {
   const int npts = td.npts;
-  {
+  if constexpr (PRE) {
     const double mue_eff = 1.0, lambda = -2.0 / 3.0 * mue_eff;  // src/flux.c:125,163
     const int nrows = npts + td.nhalo;
     for (int r = tid; r < nrows; r += nthr) {
@@ -718,7 +720,7 @@ __device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, dou
     ke = (int)ioff[li + 1];
     double ps[6];
 #pragma unroll
-    for (int c = 0; c < 6; c++) ps[c] = g_l[li * 10 + c];
+    for (int c = 0; c < 6; c++) ps[c] = g_l[li * GS + c];
     // U of this lane's incidences per batch: all incidence words, then all operands, then the
     // FMAs, so the lane pays the LDS round trips once per batch (as in grad_batch).  With few
     // lanes per point a lane has ~4 incidences and runs in a workgroup of few waves: U = 4.
@@ -742,7 +744,7 @@ __device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, dou
           on[i] = on[i] && nbr_ghost;
         }
         sx[i] = fnx[f]; sy[i] = fny[f]; sz[i] = fnz[f];
-        const double *p = g_l + nbr * 10;
+        const double *p = g_l + nbr * GS;
 #pragma unroll
         for (int c = 0; c < 6; c++) pn[i][c] = p[c];
       }
@@ -1004,7 +1006,10 @@ __device__ __forceinline__ void gg_stamp_wave(int dbg, int ntiles, int tile, int
 // tiles wait for the previous exchange, push their rows, notify) -- both compile-time, so the pass that runs one
 // partition on one GPU carries neither the other path's code nor its registers
 // DIAG: 0 = the timed kernel; 1 = phase stamps (tools/phase_stamps.py); 2 = data movement only: every load and every
-// store of the pass, neither face loop (cfdp_gpu_time_fused_movement: the floor bench.py reports beside the pass)
+// store of the pass, neither face loop (cfdp_gpu_time_fused_movement: the floor bench.py reports beside the pass);
+// 3 = TIMING EXPERIMENT, values wrong (CFDP_EXP_PROWS=1, EXPERIMENTS.md D.2): the flux phase as if the gradient phase of
+// the previous pass had stored P(g) (6 doubles, 48 bytes) per point -- 3 pieces per row instead of 5, no pass over the
+// staged rows, no barrier behind it, and a row region of 3 pieces per thread: a 32-KiB image, FIVE workgroups per CU
 template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, int DIAG = 0, bool LISTED = true, bool PUSH = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(
@@ -1048,11 +1053,12 @@ void gg_fused_split_kernel(
       const int r = (tid + k * nthr) >> 2;
       hv[k] = ld_i32_nowait(rl + (r < GG_ROW_STRIDE - 1 ? r : GG_ROW_STRIDE - 1));
     }
+    constexpr int PPR = DIAG == 3 ? 3 : 5;  // 16-byte pieces per gradient row
 #pragma unroll
     for (int k = 0; k < KG; k++) {
       const int q = tid + k * nthr;
-      rloc[k] = q / 5;
-      part[k] = q - 5 * rloc[k];
+      rloc[k] = q / PPR;
+      part[k] = q - PPR * rloc[k];
       hg[k] = ld_i32_nowait(rl + (rloc[k] < GG_ROW_STRIDE - 1 ? rloc[k] : GG_ROW_STRIDE - 1));
     }
   }
@@ -1106,7 +1112,7 @@ void gg_fused_split_kernel(
   for (int k = 0; k < KG; k++) {
     const int row = !listed && rloc[k] < td.npts ? td.pstart + rloc[k] : hg[k];
     if (row < nown)
-      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * 80 + part[k] * 16), xbuf + (size_t)(w0 + k * nthr) * 16);
+      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * (DIAG == 3 ? 48 : 80) + part[k] * 16), xbuf + (size_t)(w0 + k * nthr) * 16);
     else
       glds16_sys(reinterpret_cast<const uint4 *>(hbytes + (size_t)(row - nown) * 168 + part[k] * 16),
                  xbuf + (size_t)(w0 + k * nthr) * 16);
@@ -1130,6 +1136,8 @@ void gg_fused_split_kernel(
   if constexpr (STAMP) gg_stamp(dbg, t, 2);  // blob + gradient rows (+ var rows in registers) have landed
   if constexpr (DIAG == 2) {
     if (tid < td.npts * 3) flux[(size_t)td.pstart * 3 + tid] = 0.0;  // the flux rows leave as they do in the real pass
+  } else if constexpr (DIAG == 3) {
+    flux_tile_compute<LPP, REFMODE, 6, false>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   } else {
     flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   }
@@ -1421,6 +1429,15 @@ hipError_t launch_split(const gg_args &a, const gg_grad_view &gnew, int tile_beg
   return launch(gg_fused_split_kernel<R, N, 5, 4, 4, 4, D, L, P>, ntiles, block, (size_t)(5 + 4) * block * 16, stream, a.tiles, tile_begin,
                 a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa);
 }
+// CFDP_EXP_PROWS: see DIAG == 3 of gg_fused_split_kernel
+#define GG_DBG_PROWS 0x80000
+template <bool N>
+hipError_t launch_split_prows(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
+                              int dbgf, const gg_push_args &pa) {
+  return launch(gg_fused_split_kernel<false, N, 5, 3, 3, 3, 3, true, false>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles,
+                tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa);
+}
+
 template <bool R, bool N>
 hipError_t launch_split_lp(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
                            int dbgf, const gg_push_args &pa) {
@@ -1548,6 +1565,9 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
       return nt ? launch_split<false, true, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                 : launch_split<false, false, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     }
+    if ((gg_debug_flags & GG_DBG_PROWS) && a.rowlist && !push && !refmode && kv <= 3)
+      return nt ? launch_split_prows<true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                : launch_split_prows<false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     if (refmode) return nt ? launch_split_lp<true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                            : launch_split_lp<true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     return nt ? launch_split_lp<false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
