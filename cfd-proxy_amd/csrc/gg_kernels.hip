@@ -677,29 +677,40 @@ __device__ __forceinline__ void glds16_nt(const uint4 *src, unsigned char *lds_w
 // once per incidence: 6 adds + 9 FMAs per incidence instead of ~48 fp64 operations -- the fp64
 // vector rate, not LDS or HBM, bounded this loop (measured: the flux phase cost 64 us of the
 // 331-us fused pass on the 128^3 mesh).  Differs from the reference's association by round-off.
-// GS / PRE (timing experiment of round 5 only, EXPERIMENTS.md D.2): rows of GS doubles that already hold P -- no pass over
-// the rows, no barrier
+// P(g) = -stress(g) / 2 of one row's 3x3 velocity-gradient block (src/flux.c:125,139-173): the ONE statement of it, so
+// that every kernel form produces the same bits
+__device__ __forceinline__ void half_stress(const double (&g)[9], double (&p)[6]) {
+  const double mue_eff = 1.0, lambda = -2.0 / 3.0 * mue_eff;  // src/flux.c:125,163
+  const double dvx_dx = g[0], dvx_dy = g[1], dvx_dz = g[2];
+  const double dvy_dx = g[3], dvy_dy = g[4], dvy_dz = g[5];
+  const double dvz_dx = g[6], dvz_dy = g[7], dvz_dz = g[8];
+  const double sts_xx = lambda * (dvy_dy + dvz_dz - 2.0 * dvx_dx);
+  const double sts_yy = lambda * (dvx_dx + dvz_dz - 2.0 * dvy_dy);
+  const double sts_zz = lambda * (dvx_dx + dvy_dy - 2.0 * dvz_dz);
+  const double sts_xy = mue_eff * (dvx_dy + dvy_dx);
+  const double sts_xz = mue_eff * (dvx_dz + dvz_dx);
+  const double sts_yz = mue_eff * (dvy_dz + dvz_dy);
+  p[0] = -0.5 * sts_xx; p[1] = -0.5 * sts_xy; p[2] = -0.5 * sts_xz;
+  p[3] = -0.5 * sts_yy; p[4] = -0.5 * sts_yz; p[5] = -0.5 * sts_zz;
+}
+
+// GS / PRE: the staged rows are GS doubles apart; PRE = false: they already hold P (the register-staged form of the
+// fused pass, and the timing experiment of EXPERIMENTS.md D.2) -- no pass over the rows, no barrier
 template <int LPP, bool REFMODE, int GS = 10, bool PRE = true>
 __device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, double *g_l,
                                                   const cfdp_tile_desc &td, const int *__restrict__ hid,
                                                   int tid, int nthr, double *__restrict__ flux, int nown) {
   const int npts = td.npts;
   if constexpr (PRE) {
-    const double mue_eff = 1.0, lambda = -2.0 / 3.0 * mue_eff;  // src/flux.c:125,163
     const int nrows = npts + td.nhalo;
     for (int r = tid; r < nrows; r += nthr) {
-      double *g = g_l + r * 10;
-      const double dvx_dx = g[0], dvx_dy = g[1], dvx_dz = g[2];
-      const double dvy_dx = g[3], dvy_dy = g[4], dvy_dz = g[5];
-      const double dvz_dx = g[6], dvz_dy = g[7], dvz_dz = g[8];
-      const double sts_xx = lambda * (dvy_dy + dvz_dz - 2.0 * dvx_dx);
-      const double sts_yy = lambda * (dvx_dx + dvz_dz - 2.0 * dvy_dy);
-      const double sts_zz = lambda * (dvx_dx + dvy_dy - 2.0 * dvz_dz);
-      const double sts_xy = mue_eff * (dvx_dy + dvy_dx);
-      const double sts_xz = mue_eff * (dvx_dz + dvz_dx);
-      const double sts_yz = mue_eff * (dvy_dz + dvz_dy);
-      g[0] = -0.5 * sts_xx; g[1] = -0.5 * sts_xy; g[2] = -0.5 * sts_xz;
-      g[3] = -0.5 * sts_yy; g[4] = -0.5 * sts_yz; g[5] = -0.5 * sts_zz;
+      double *g = g_l + r * GS;
+      double gv[9], p[6];
+#pragma unroll
+      for (int c = 0; c < 9; c++) gv[c] = g[c];
+      half_stress(gv, p);
+#pragma unroll
+      for (int c = 0; c < 6; c++) g[c] = p[c];
     }
     __syncthreads();
   }
@@ -1010,6 +1021,11 @@ __device__ __forceinline__ void gg_stamp_wave(int dbg, int ntiles, int tile, int
 // 3 = TIMING EXPERIMENT, values wrong (CFDP_EXP_PROWS=1, EXPERIMENTS.md D.2): the flux phase as if the gradient phase of
 // the previous pass had stored P(g) (6 doubles, 48 bytes) per point -- 3 pieces per row instead of 5, no pass over the
 // staged rows, no barrier behind it, and a row region of 3 pieces per thread: a 32-KiB image, FIVE workgroups per CU
+// 4 = the product form for tiles of at most 192 staged rows (round 5): what D.2 measured, without a new array in memory.
+// Thread r requests the 80-byte part-A row of staged row r into REGISTERS (five 16-byte loads; ghost rows: system-scope
+// loads), forms P(g) there -- half_stress, the same statement as everywhere -- and stores the 48-byte P row into the
+// row region.  No pass over the staged rows, no barrier behind it, rows of 3 pieces instead of 5 in LDS: a 32-KiB image
+// (CB = 5, KX = 3), five workgroups per CU.  Values: bit for bit those of the other forms.
 template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, int DIAG = 0, bool LISTED = true, bool PUSH = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(
@@ -1043,6 +1059,7 @@ void gg_fused_split_kernel(
     if (pa.tile_off && t < pa.nbtiles) pfirst = ld_u64_nowait(pa.pt_first + (size_t)t * pa.pt_stride + (tid >> 2));
   }
   int hv[KV], hg[KG], part[KG], rloc[KG];
+  int ha = 0;  // DIAG == 4: the row whose part A this thread requests (staged row `tid`)
   // with a fixed-stride row list the row numbers are requested before the descriptor is even here:
   // descriptor -> blob and row list -> rows are two chains of two round trips instead of one of three
   constexpr bool listed = LISTED;
@@ -1053,9 +1070,10 @@ void gg_fused_split_kernel(
       const int r = (tid + k * nthr) >> 2;
       hv[k] = ld_i32_nowait(rl + (r < GG_ROW_STRIDE - 1 ? r : GG_ROW_STRIDE - 1));
     }
+    if constexpr (DIAG == 4) ha = ld_i32_nowait(rl + (tid < GG_ROW_STRIDE - 1 ? tid : GG_ROW_STRIDE - 1));
     constexpr int PPR = DIAG == 3 ? 3 : 5;  // 16-byte pieces per gradient row
 #pragma unroll
-    for (int k = 0; k < KG; k++) {
+    for (int k = 0; k < (DIAG == 4 ? 0 : KG); k++) {
       const int q = tid + k * nthr;
       rloc[k] = q / PPR;
       part[k] = q - PPR * rloc[k];
@@ -1072,8 +1090,13 @@ void gg_fused_split_kernel(
       h = h < 0 ? 0 : (h > hmax ? hmax : h);
       hv[k] = ld_i32_nowait(hid + h);
     }
+    if constexpr (DIAG == 4) {
+      int h = tid - td.npts;
+      h = h < 0 ? 0 : (h > hmax ? hmax : h);
+      ha = ld_i32_nowait(hid + h);
+    }
 #pragma unroll
-    for (int k = 0; k < KG; k++) {
+    for (int k = 0; k < (DIAG == 4 ? 0 : KG); k++) {
       const int q = tid + k * nthr;
       rloc[k] = q / 5;
       part[k] = q - 5 * rloc[k];
@@ -1096,7 +1119,8 @@ void gg_fused_split_kernel(
 #pragma unroll
   for (int k = 0; k < KV; k++) asm volatile("" : "+v"(hv[k]));
 #pragma unroll
-  for (int k = 0; k < KG; k++) asm volatile("" : "+v"(hg[k]));
+  for (int k = 0; k < (DIAG == 4 ? 0 : KG); k++) asm volatile("" : "+v"(hg[k]));
+  if constexpr (DIAG == 4) asm volatile("" : "+v"(ha));
   if constexpr (PUSH)
     if (waiting) wait_check(pa, t, tid, iter0, wprobe);  // before any ghost row is requested
   double *push_row = nullptr;  // this lane's point, in its first partner's arena (the slice pointer travels with the rows)
@@ -1108,8 +1132,29 @@ void gg_fused_split_kernel(
   unsigned char *xbuf = smem + (size_t)CB * nthr * 16;  // the shared row region
   const unsigned char *abytes = reinterpret_cast<const unsigned char *>(gradA_old);
   const unsigned char *hbytes = reinterpret_cast<const unsigned char *>(ghost_old);
+  double ga[DIAG == 4 ? 10 : 1];  // DIAG == 4: this thread's part-A row (9 doubles are used)
+  const bool arow = DIAG == 4 && tid < td.npts + td.nhalo;
+  if constexpr (DIAG == 4) {
+    if (arow) {
+      const int row = !listed && tid < td.npts ? td.pstart + tid : ha;
+      if (row < nown) {
+        const double2 *src = reinterpret_cast<const double2 *>(abytes + (size_t)row * 80);
 #pragma unroll
-  for (int k = 0; k < KG; k++) {
+        for (int c = 0; c < 5; c++) {
+          const double2 v = src[c];
+          ga[2 * c] = v.x;
+          ga[2 * c + 1] = v.y;
+        }
+      } else {  // a ghost row: written by another device, read past every cache (see glds16_sys)
+        const double *src = reinterpret_cast<const double *>(hbytes + (size_t)(row - nown) * 168);
+#pragma unroll
+        for (int c = 0; c < 9; c++) ga[c] = __hip_atomic_load(src + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ga[9] = 0.0;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < (DIAG == 4 ? 0 : KG); k++) {
     const int row = !listed && rloc[k] < td.npts ? td.pstart + rloc[k] : hg[k];
     if (row < nown)
       glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * (DIAG == 3 ? 48 : 80) + part[k] * 16), xbuf + (size_t)(w0 + k * nthr) * 16);
@@ -1128,6 +1173,18 @@ void gg_fused_split_kernel(
     const int row = !listed && r < td.npts ? td.pstart + r : hv[k];
     vr[k] = *reinterpret_cast<const u32x4 *>(gv4 + (size_t)row * 4 + (q & 3));
   }
+  if constexpr (DIAG == 4) {
+    if (arow) {  // P(g) of this thread's row, into the row region (48-byte rows)
+      double gv[9], p[6];
+#pragma unroll
+      for (int c = 0; c < 9; c++) gv[c] = ga[c];
+      half_stress(gv, p);
+      double2 *dst = reinterpret_cast<double2 *>(xbuf + (size_t)tid * 48);
+      dst[0] = make_double2(p[0], p[1]);
+      dst[1] = make_double2(p[2], p[3]);
+      dst[2] = make_double2(p[4], p[5]);
+    }
+  }
   if constexpr (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     gg_stamp_wave(dbg, (int)gridDim.x, t, 0);  // this wave's own pieces have landed
@@ -1136,7 +1193,7 @@ void gg_fused_split_kernel(
   if constexpr (STAMP) gg_stamp(dbg, t, 2);  // blob + gradient rows (+ var rows in registers) have landed
   if constexpr (DIAG == 2) {
     if (tid < td.npts * 3) flux[(size_t)td.pstart * 3 + tid] = 0.0;  // the flux rows leave as they do in the real pass
-  } else if constexpr (DIAG == 3) {
+  } else if constexpr (DIAG == 3 || DIAG == 4) {
     flux_tile_compute<LPP, REFMODE, 6, false>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   } else {
     flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
@@ -1360,7 +1417,9 @@ hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, const int *tile_
 hipError_t gg_set_stamp_buffer(unsigned long long *dev) {
   return hipMemcpyToSymbol(HIP_SYMBOL(gg_stamp_buf), &dev, sizeof dev);
 }
-int gg_fused_split = 1;  // fused pass: prefer the phase-split form (one shared row region, 4 workgroups per CU)
+// fused pass: 0 everything staged up front; 1 the phase-split form (one shared row region, 36 KiB, 4 workgroups per CU);
+// 2 (default) the register-staged form where the tiles allow it (32 KiB, 5 workgroups per CU), else the phase-split form
+int gg_fused_split = 2;
 int gg_debug_flags = 0;  // 16: register-staged kernels only; 64: per-lane row stores; GG_DBG_STAMP: phase stamps
 
 namespace {
@@ -1446,6 +1505,23 @@ hipError_t launch_split_lp(const gg_args &a, const gg_grad_view &gnew, int tile_
                              : launch_split<R, N, 0, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
   return pushing ? launch_split<R, N, 0, false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                  : launch_split<R, N, 0, false, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
+}
+
+// the register-staged form (DIAG == 4 of gg_fused_split_kernel): 5 blob + 3 row pieces per thread = a 32-KiB image
+template <bool R, bool N, bool L, bool P>
+hipError_t launch_preg(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
+                       int dbgf, const gg_push_args &pa) {
+  return launch(gg_fused_split_kernel<R, N, 5, 3, 3, 3, 4, L, P>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles, tile_begin,
+                a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa);
+}
+template <bool R, bool N>
+hipError_t launch_preg_lp(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
+                          int dbgf, const gg_push_args &pa) {
+  const bool listed = a.rowlist != nullptr, pushing = pa.tile_off != nullptr;
+  if (listed) return pushing ? launch_preg<R, N, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                             : launch_preg<R, N, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
+  return pushing ? launch_preg<R, N, false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                 : launch_preg<R, N, false, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
 }
 
 template <int CB, int KV, int KG>
@@ -1564,6 +1640,13 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
       if (!a.rowlist) return hipErrorNotSupported;
       return nt ? launch_split<false, true, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                 : launch_split<false, false, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
+    }
+    // tiles of at most 192 staged rows (3 var pieces per thread) and one thread per staged row: the register-staged form
+    if (gg_fused_split >= 2 && kv <= 3 && tile_points + max_halo <= block && !(gg_debug_flags & GG_DBG_PROWS)) {
+      if (refmode) return nt ? launch_preg_lp<true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                             : launch_preg_lp<true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
+      return nt ? launch_preg_lp<false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
+                : launch_preg_lp<false, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     }
     if ((gg_debug_flags & GG_DBG_PROWS) && a.rowlist && !push && !refmode && kv <= 3)
       return nt ? launch_split_prows<true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
