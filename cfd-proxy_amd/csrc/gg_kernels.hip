@@ -1157,7 +1157,7 @@ void gg_fused_split_kernel(
   for (int k = 0; k < (DIAG == 4 ? 0 : KG); k++) {
     const int row = !listed && rloc[k] < td.npts ? td.pstart + rloc[k] : hg[k];
     if (row < nown)
-      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * (DIAG == 3 ? 48 : 80) + part[k] * 16), xbuf + (size_t)(w0 + k * nthr) * 16);
+      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * (DIAG == 3 && !(dbg & 0x100000) ? 48 : 80) + part[k] * 16), xbuf + (size_t)(w0 + k * nthr) * 16);
     else
       glds16_sys(reinterpret_cast<const uint4 *>(hbytes + (size_t)(row - nown) * 168 + part[k] * 16),
                  xbuf + (size_t)(w0 + k * nthr) * 16);

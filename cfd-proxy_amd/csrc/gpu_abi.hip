@@ -62,7 +62,7 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
   g->device = device;
   if (const char *e = cfdp_experiment_getenv("CFDP_DEBUG_ABLATE")) gg_debug_flags = atoi(e);  // honoured only with CFDP_EXPERIMENTS=1
   if (const char *e = cfdp_experiment_getenv("CFDP_EXP_PROWS"))  // timing experiment, values WRONG (EXPERIMENTS.md D.2)
-    gg_debug_flags = (gg_debug_flags & ~0x80000) | (atoi(e) ? 0x80000 : 0);
+    gg_debug_flags = (gg_debug_flags & ~0x180000) | (atoi(e) ? 0x80000 : 0) | (atoi(e) == 2 ? 0x100000 : 0);  // 2: 48 of every 80 bytes
   if (const char *e = getenv("CFDP_FUSED_SPLIT")) gg_fused_split = atoi(e);
   HIP_TRY(hipStreamCreateWithFlags(&g->s_main, hipStreamNonBlocking));
   {

@@ -9,7 +9,7 @@ from __graft_entry__ import load_package
 m = load_package()
 for n in [int(a) for a in sys.argv[1:]] or [64, 128]:
     dom = m.gen_domain(m.gen_params(n, ndomains=1), 0); m.fill_var(dom, None, m.VAR_HASH)
-    for exp in ("0", "1", "0", "1", "0", "1"):
+    for exp in ("0", "1", "2", "0", "1", "2"):  # 1: 48-byte rows; 2: the first 48 bytes of 80-byte rows
         os.environ["CFDP_EXPERIMENTS"] = "1"
         os.environ["CFDP_EXP_PROWS"] = exp
         part = m.GpuPartition(dom); part.set_fusion(True)
