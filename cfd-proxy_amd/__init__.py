@@ -575,6 +575,29 @@ def merge_scatter(part: Domain, dl: int, npoints_d: int, field: np.ndarray) -> n
     return out
 
 
+def stored_rows(rows: np.ndarray) -> np.ndarray:
+    """gradient rows [n][21] (or [n][7][3]) as the DEVICE keeps and sends them: the first 10 doubles of a row -- the 3x3
+    velocity-gradient block g0..g8 and g9 -- as [g0 g4 g8 | g1+g3 g2+g6 g5+g7 | g3 g6 g7 | g9] (gg_a_encode,
+    csrc/gg_kernels.h: the first 48 bytes are all the flux loop stages); the other 11 as they are"""
+    r = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, 21)
+    e = r.copy()
+    e[:, 0], e[:, 1], e[:, 2] = r[:, 0], r[:, 4], r[:, 8]
+    e[:, 3], e[:, 4], e[:, 5] = r[:, 1] + r[:, 3], r[:, 2] + r[:, 6], r[:, 5] + r[:, 7]
+    e[:, 6], e[:, 7], e[:, 8] = r[:, 3], r[:, 6], r[:, 7]
+    return e
+
+
+def handed_out_rows(stored: np.ndarray) -> np.ndarray:
+    """the inverse at the host boundary (gg_a_decode): the three upper off-diagonals come back as (sum) - (lower one),
+    within one rounding of the sum of the two"""
+    e = np.ascontiguousarray(stored, dtype=np.float64).reshape(-1, 21)
+    r = e.copy()
+    r[:, 0], r[:, 4], r[:, 8] = e[:, 0], e[:, 1], e[:, 2]
+    r[:, 3], r[:, 6], r[:, 7] = e[:, 6], e[:, 7], e[:, 8]
+    r[:, 1], r[:, 2], r[:, 5] = e[:, 3] - e[:, 6], e[:, 4] - e[:, 7], e[:, 5] - e[:, 8]
+    return r
+
+
 def device_bus_id(device: int) -> str:
     """PCI bus id of a visible device: the same string in every process that sees the same physical device"""
     buf = C.create_string_buffer(64)

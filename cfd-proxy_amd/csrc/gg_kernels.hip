@@ -179,8 +179,12 @@ __device__ __forceinline__ void st16_sys(void *p, gg_u32x4 v) {  // global_store
 // the top of the kernel, the slice pointer behind the staging wait), so nothing but the stores themselves sits on the
 // boundary tile's critical path.  Write-through system-scope stores, 16 bytes wherever the arena's alignment allows
 // (rows start at 0 or 8 mod 16).  The caller drains them (s_waitcnt vmcnt(0), push_tile_done) before it counts the tile.
+// The row leaves in its stored form (gg_a_encode): lane group 0 holds g0..g5 and stores e0..e5 = [g0 g4 g8 g1+g3 g2+g6
+// g5+g7], lane group 1 holds g6..g11 and stores [e6..e9 | d10 d11] = [g3 g6 g7 g9 | g10 g11]; ex[] = what each takes from
+// the other (group 0: g6 g7 g8 of group 1; group 1: g3 of group 0), shuffled in by the caller.
 template <int NE>
-__device__ __forceinline__ void push_from_registers(double *row, int eq0, const double (&acc)[NE][3], double tmp) {
+__device__ __forceinline__ void push_from_registers(double *row, int eq0, const double (&acc)[NE][3], double tmp,
+                                                    const double (&ex)[3]) {
   double *p = row + eq0 * 3;
   auto st8 = [](double *q, double x) { __hip_atomic_store(q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
   auto st16 = [](double *q, double a, double b) {
@@ -190,8 +194,15 @@ __device__ __forceinline__ void push_from_registers(double *row, int eq0, const 
     st16_sys(q, u);
   };
   if constexpr (NE == 2) {  // 4 lanes per point (every kernel that pushes): 6 doubles, the last lane group 3
-    const double v0 = acc[0][0] * tmp, v1 = acc[0][1] * tmp, v2 = acc[0][2] * tmp;
-    const double v3 = acc[1][0] * tmp, v4 = acc[1][1] * tmp, v5 = acc[1][2] * tmp;
+    double v0 = acc[0][0] * tmp, v1 = acc[0][1] * tmp, v2 = acc[0][2] * tmp;
+    double v3 = acc[1][0] * tmp, v4 = acc[1][1] * tmp, v5 = acc[1][2] * tmp;
+    if (eq0 == 0) {  // g0..g5 here, ex = g6 g7 g8
+      const double e0 = v0, e1 = v4, e2 = ex[2], e3 = v1 + v3, e4 = v2 + ex[0], e5 = v5 + ex[1];
+      v0 = e0; v1 = e1; v2 = e2; v3 = e3; v4 = e4; v5 = e5;
+    } else if (eq0 == 2) {  // g6..g11 here, ex[0] = g3
+      const double e6 = ex[0], e7 = v0, e8 = v1, e9 = v3;
+      v0 = e6; v1 = e7; v2 = e8; v3 = e9;  // v4, v5 = d10, d11 as they are
+    }
     const bool six = eq0 + 2 <= 7;
     if (((uintptr_t)p & 15) == 0) {
       st16(p, v0, v1);
@@ -215,12 +226,13 @@ __device__ __forceinline__ void push_from_registers(double *row, int eq0, const 
 // The finished rows are stored 8 bytes per lane in contiguous runs (NT: non-temporal).
 // MOVE (the data-movement floor, a diagnostic instantiation): no incidence is walked -- every row is stored as zeros
 // through the same slab and the same store instructions.
+// pushing (uniform per workgroup): some lanes of this tile push their rows (push_row != nullptr for those)
 template <int LPP, bool NT, bool SYNC = false, bool MOVE = false>
 __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, const cfdp_tile_desc &td,
                                                   int tid, double *__restrict__ gradA,
                                                   double *__restrict__ gradB,
                                                   double *__restrict__ stage, int dbg = 0,
-                                                  int var_off = -1, double *push_row = nullptr) {
+                                                  int var_off = -1, double *push_row = nullptr, bool pushing = false) {
   constexpr int NE = grad_cfg<LPP>::NE;
   constexpr int PPW = 64 / LPP;  // points per wave
   const int li = tid / LPP, sub = tid % LPP;
@@ -261,7 +273,17 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   }
   // this point's row goes to a partner: out of the registers, now (before the tile's own stores: the acknowledgement of a
   // remote store takes longest).  A point without faces is pushed by nobody (such partitions keep the push kernel)
-  if (push_row && active && ke0 > ks) push_from_registers<NE>(push_row, eq0, acc, tmp);
+  if constexpr (NE == 2) {
+    if (pushing) {  // (every lane takes part in the shuffles: lanes 4p and 4p + 1 swap what the stored form mixes)
+      double ex[3];
+      const double up = __shfl_up(acc[1][0] * tmp, 1, 64);  // g3 of lane group 0, for group 1
+      ex[0] = __shfl_down(acc[0][0] * tmp, 1, 64);          // g6 g7 g8 of lane group 1, for group 0
+      ex[1] = __shfl_down(acc[0][1] * tmp, 1, 64);
+      ex[2] = __shfl_down(acc[0][2] * tmp, 1, 64);
+      if (sub == 1) ex[0] = up;
+      if (push_row && active && ke0 > ks) push_from_registers<NE>(push_row, eq0, acc, tmp, ex);
+    }
+  }
   // SYNC: `stage` aliases a region of the tile image other waves may still be reading
   if constexpr (SYNC) __syncthreads();
   // ---- write the finished rows.  A lane holds NE*3 doubles of a 168-byte row; storing them
@@ -272,23 +294,8 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   const int wave = tid >> 6, lane = tid & 63;
   const int wp = wave * PPW;                                    // first point of this wave
   const int nv = td.npts - wp < PPW ? td.npts - wp : PPW;       // its valid points (may be <= 0)
-  // a point without faces is in no colour list: the reference leaves its row alone
-  const bool faceless = active && ke0 == ks;
-  if (__any(faceless) || (dbg & 64)) {  // rare: fall back to per-lane stores that can skip a row
-    if (active && !faceless) {
-      double *ga = gradA + (size_t)(td.pstart + li) * 10, *gb = gradB + (size_t)(td.pstart + li) * 11 - 10;
-#pragma unroll
-      for (int j = 0; j < NE; j++)
-        if (eq0 + j < 7) {
-#pragma unroll
-          for (int c = 0; c < 3; c++) {
-            const int d = (eq0 + j) * 3 + c;  // position in the 21-double row
-            (d < 10 ? ga : gb)[d] = acc[j][c] * tmp;
-          }
-        }
-    }
-    return;
-  }
+  // a point without faces is in no colour list: the reference leaves its row alone (rare: its row is skipped below)
+  const unsigned long long faceless = __ballot(active && ke0 == ks);
   // 8 points (1344 bytes) per pass: the slab stays small enough for four workgroups per CU.
   // Slab image of a pass: [A parts: 8 x 10][B parts: 8 x 11], the two runs it is stored as.
   constexpr int SPP = 8, NPASS = PPW / SPP;
@@ -311,10 +318,23 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     __builtin_amdgcn_wave_barrier();  // LDS executes a wave's accesses in order; keep the compiler in order too
     int nvh = nv - h * SPP;
     nvh = nvh < 0 ? 0 : (nvh > SPP ? SPP : nvh);
+    if (lane < nvh) {  // part A of the pass's rows into its stored form (gg_a_encode, gg_kernels.h), in place
+      double *r = slab + lane * 10, g[10], e[10];
+#pragma unroll
+      for (int c = 0; c < 10; c++) g[c] = r[c];
+      gg_a_encode(g, e);
+#pragma unroll
+      for (int c = 0; c < 10; c++) r[c] = e[c];
+    }
+    __builtin_amdgcn_wave_barrier();
     const size_t p0 = (size_t)(td.pstart + wp + h * SPP);
     double *ga = gradA + p0 * 10, *gb = gradB + p0 * 11;
     const int na = nvh * 10, nd = nvh * 21;
     for (int c = lane; c < nd; c += 64) {
+      if (faceless) {  // uniform: some point of this wave has no faces -- its row stays as it is
+        const int row = h * SPP + (c < na ? c / 10 : (c - na) / 11);
+        if ((faceless >> (row * LPP)) & 1ull) continue;
+      }
       if (c < na) st_row<NT>(slab[c], &ga[c]);
       else st_row<NT>(slab[SPP * 10 + c - na], &gb[c - na]);
     }
@@ -348,7 +368,7 @@ __device__ __forceinline__ void push_tile_rows(const gg_push_args &pa, int tile,
     const int c0 = odd ? (q == 0 ? 0 : 2 * q - 1) : 2 * q;  // first double of this piece
     const bool pair = odd ? q != 0 : q != 10;
     // past this CU's L1: the values were written a moment ago by other waves of this workgroup
-    auto ld = [&](int c) {
+    auto ld = [&](int c) {  // (rows travel in their stored form: part A as gg_a_encode leaves it)
       const double *src = c < 10 ? gradA + p * 10 + c : gradB + p * 11 + (c - 10);
       return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
@@ -679,23 +699,26 @@ __device__ __forceinline__ void glds16_nt(const uint4 *src, unsigned char *lds_w
 // 331-us fused pass on the 128^3 mesh).  Differs from the reference's association by round-off.
 // P(g) = -stress(g) / 2 of one row's 3x3 velocity-gradient block (src/flux.c:125,139-173): the ONE statement of it, so
 // that every kernel form produces the same bits
-__device__ __forceinline__ void half_stress(const double (&g)[9], double (&p)[6]) {
+// Input: the six numbers the stress needs -- the diagonal of the velocity-gradient block and its three symmetric sums,
+// s = [dvx_dx, dvy_dy, dvz_dz, dvx_dy + dvy_dx, dvx_dz + dvz_dx, dvy_dz + dvz_dy] -- which is what the first 48 bytes
+// of every row on the device hold (gg_a_encode: owned rows and, sent that way, ghost rows alike).
+__device__ __forceinline__ void half_stress(const double (&s)[6], double (&p)[6]) {
   const double mue_eff = 1.0, lambda = -2.0 / 3.0 * mue_eff;  // src/flux.c:125,163
-  const double dvx_dx = g[0], dvx_dy = g[1], dvx_dz = g[2];
-  const double dvy_dx = g[3], dvy_dy = g[4], dvy_dz = g[5];
-  const double dvz_dx = g[6], dvz_dy = g[7], dvz_dz = g[8];
+  const double dvx_dx = s[0], dvy_dy = s[1], dvz_dz = s[2];
   const double sts_xx = lambda * (dvy_dy + dvz_dz - 2.0 * dvx_dx);
   const double sts_yy = lambda * (dvx_dx + dvz_dz - 2.0 * dvy_dy);
   const double sts_zz = lambda * (dvx_dx + dvy_dy - 2.0 * dvz_dz);
-  const double sts_xy = mue_eff * (dvx_dy + dvy_dx);
-  const double sts_xz = mue_eff * (dvx_dz + dvz_dx);
-  const double sts_yz = mue_eff * (dvy_dz + dvz_dy);
+  const double sts_xy = mue_eff * s[3];
+  const double sts_xz = mue_eff * s[4];
+  const double sts_yz = mue_eff * s[5];
   p[0] = -0.5 * sts_xx; p[1] = -0.5 * sts_xy; p[2] = -0.5 * sts_xz;
   p[3] = -0.5 * sts_yy; p[4] = -0.5 * sts_yz; p[5] = -0.5 * sts_zz;
 }
 
-// GS / PRE: the staged rows are GS doubles apart; PRE = false: they already hold P (the register-staged form of the
-// fused pass, and the timing experiment of EXPERIMENTS.md D.2) -- no pass over the rows, no barrier
+
+// GS: the staged rows are GS doubles apart (10: whole 80-byte rows; 6: their first 48 bytes) -- either way a row starts
+// with the six numbers half_stress takes.  PRE = false (the timing experiment of EXPERIMENTS.md D.2 only): the rows are
+// taken as P as they stand
 template <int LPP, bool REFMODE, int GS = 10, bool PRE = true>
 __device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, double *g_l,
                                                   const cfdp_tile_desc &td, const int *__restrict__ hid,
@@ -705,10 +728,10 @@ __device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, dou
     const int nrows = npts + td.nhalo;
     for (int r = tid; r < nrows; r += nthr) {
       double *g = g_l + r * GS;
-      double gv[9], p[6];
+      double s[6], p[6];
 #pragma unroll
-      for (int c = 0; c < 9; c++) gv[c] = g[c];
-      half_stress(gv, p);
+      for (int c = 0; c < 6; c++) s[c] = g[c];
+      half_stress(s, p);
 #pragma unroll
       for (int c = 0; c < 6; c++) g[c] = p[c];
     }
@@ -974,7 +997,7 @@ void gg_fused_dma_kernel(
   }
   flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
   grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(gbuf), dbg,
-                                   CB * nthr * 16, push_row);
+                                   CB * nthr * 16, push_row, pa.tile_off && t < pa.nbtiles);
   push_tile_rows(pa, t, tid, nthr, td, gradA_new, gradB_new);
   push_tile_done(pa, t, tid, iter0);
 }
@@ -988,7 +1011,7 @@ __global__ __launch_bounds__(256) void gg_pack_kernel(const int *__restrict__ se
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int j = i / 21, c = i - 21 * j;
     const size_t p = (size_t)send_idx[j];  // send points are owned points
-    sendbuf[i] = c < 10 ? gradA[p * 10 + c] : gradB[p * 11 + c - 10];  // whole 168-byte rows on the wire
+    sendbuf[i] = c < 10 ? gradA[p * 10 + c] : gradB[p * 11 + c - 10];  // whole 168-byte rows on the wire, in their stored form
   }
 }
 
@@ -1021,11 +1044,10 @@ __device__ __forceinline__ void gg_stamp_wave(int dbg, int ntiles, int tile, int
 // 3 = TIMING EXPERIMENT, values wrong (CFDP_EXP_PROWS=1, EXPERIMENTS.md D.2): the flux phase as if the gradient phase of
 // the previous pass had stored P(g) (6 doubles, 48 bytes) per point -- 3 pieces per row instead of 5, no pass over the
 // staged rows, no barrier behind it, and a row region of 3 pieces per thread: a 32-KiB image, FIVE workgroups per CU
-// 4 = the product form for tiles of at most 192 staged rows (round 5): what D.2 measured, without a new array in memory.
-// Thread r requests the 80-byte part-A row of staged row r into REGISTERS (five 16-byte loads; ghost rows: system-scope
-// loads), forms P(g) there -- half_stress, the same statement as everywhere -- and stores the 48-byte P row into the
-// row region.  No pass over the staged rows, no barrier behind it, rows of 3 pieces instead of 5 in LDS: a 32-KiB image
-// (CB = 5, KX = 3), five workgroups per CU.  Values: bit for bit those of the other forms.
+// 4 = the product form for tiles of at most 192 staged rows (round 5): what D.2 measured, made real by the stored form of
+// part A (gg_a_encode, gg_kernels.h): the flux phase stages the FIRST 48 BYTES of every row -- the six numbers the stress
+// needs -- 3 pieces per row instead of 5, so the shared row region holds 3 pieces per thread: a 32-KiB image (CB = 5,
+// KX = 3), five workgroups per CU.  Values: bit for bit those of the other forms.
 template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, int DIAG = 0, bool LISTED = true, bool PUSH = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(
@@ -1059,7 +1081,7 @@ void gg_fused_split_kernel(
     if (pa.tile_off && t < pa.nbtiles) pfirst = ld_u64_nowait(pa.pt_first + (size_t)t * pa.pt_stride + (tid >> 2));
   }
   int hv[KV], hg[KG], part[KG], rloc[KG];
-  int ha = 0;  // DIAG == 4: the row whose part A this thread requests (staged row `tid`)
+  constexpr int PPR = DIAG == 3 || DIAG == 4 ? 3 : 5;  // 16-byte pieces staged per gradient row
   // with a fixed-stride row list the row numbers are requested before the descriptor is even here:
   // descriptor -> blob and row list -> rows are two chains of two round trips instead of one of three
   constexpr bool listed = LISTED;
@@ -1070,10 +1092,8 @@ void gg_fused_split_kernel(
       const int r = (tid + k * nthr) >> 2;
       hv[k] = ld_i32_nowait(rl + (r < GG_ROW_STRIDE - 1 ? r : GG_ROW_STRIDE - 1));
     }
-    if constexpr (DIAG == 4) ha = ld_i32_nowait(rl + (tid < GG_ROW_STRIDE - 1 ? tid : GG_ROW_STRIDE - 1));
-    constexpr int PPR = DIAG == 3 ? 3 : 5;  // 16-byte pieces per gradient row
 #pragma unroll
-    for (int k = 0; k < (DIAG == 4 ? 0 : KG); k++) {
+    for (int k = 0; k < KG; k++) {
       const int q = tid + k * nthr;
       rloc[k] = q / PPR;
       part[k] = q - PPR * rloc[k];
@@ -1090,16 +1110,11 @@ void gg_fused_split_kernel(
       h = h < 0 ? 0 : (h > hmax ? hmax : h);
       hv[k] = ld_i32_nowait(hid + h);
     }
-    if constexpr (DIAG == 4) {
-      int h = tid - td.npts;
-      h = h < 0 ? 0 : (h > hmax ? hmax : h);
-      ha = ld_i32_nowait(hid + h);
-    }
 #pragma unroll
-    for (int k = 0; k < (DIAG == 4 ? 0 : KG); k++) {
+    for (int k = 0; k < KG; k++) {
       const int q = tid + k * nthr;
-      rloc[k] = q / 5;
-      part[k] = q - 5 * rloc[k];
+      rloc[k] = q / PPR;
+      part[k] = q - PPR * rloc[k];
       int h = rloc[k] - td.npts;
       h = h < 0 ? 0 : (h > hmax ? hmax : h);
       hg[k] = ld_i32_nowait(hid + h);
@@ -1119,8 +1134,7 @@ void gg_fused_split_kernel(
 #pragma unroll
   for (int k = 0; k < KV; k++) asm volatile("" : "+v"(hv[k]));
 #pragma unroll
-  for (int k = 0; k < (DIAG == 4 ? 0 : KG); k++) asm volatile("" : "+v"(hg[k]));
-  if constexpr (DIAG == 4) asm volatile("" : "+v"(ha));
+  for (int k = 0; k < KG; k++) asm volatile("" : "+v"(hg[k]));
   if constexpr (PUSH)
     if (waiting) wait_check(pa, t, tid, iter0, wprobe);  // before any ghost row is requested
   double *push_row = nullptr;  // this lane's point, in its first partner's arena (the slice pointer travels with the rows)
@@ -1132,29 +1146,8 @@ void gg_fused_split_kernel(
   unsigned char *xbuf = smem + (size_t)CB * nthr * 16;  // the shared row region
   const unsigned char *abytes = reinterpret_cast<const unsigned char *>(gradA_old);
   const unsigned char *hbytes = reinterpret_cast<const unsigned char *>(ghost_old);
-  double ga[DIAG == 4 ? 10 : 1];  // DIAG == 4: this thread's part-A row (9 doubles are used)
-  const bool arow = DIAG == 4 && tid < td.npts + td.nhalo;
-  if constexpr (DIAG == 4) {
-    if (arow) {
-      const int row = !listed && tid < td.npts ? td.pstart + tid : ha;
-      if (row < nown) {
-        const double2 *src = reinterpret_cast<const double2 *>(abytes + (size_t)row * 80);
 #pragma unroll
-        for (int c = 0; c < 5; c++) {
-          const double2 v = src[c];
-          ga[2 * c] = v.x;
-          ga[2 * c + 1] = v.y;
-        }
-      } else {  // a ghost row: written by another device, read past every cache (see glds16_sys)
-        const double *src = reinterpret_cast<const double *>(hbytes + (size_t)(row - nown) * 168);
-#pragma unroll
-        for (int c = 0; c < 9; c++) ga[c] = __hip_atomic_load(src + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        ga[9] = 0.0;
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < (DIAG == 4 ? 0 : KG); k++) {
+  for (int k = 0; k < KG; k++) {
     const int row = !listed && rloc[k] < td.npts ? td.pstart + rloc[k] : hg[k];
     if (row < nown)
       glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * (DIAG == 3 && !(dbg & 0x100000) ? 48 : 80) + part[k] * 16), xbuf + (size_t)(w0 + k * nthr) * 16);
@@ -1173,18 +1166,6 @@ void gg_fused_split_kernel(
     const int row = !listed && r < td.npts ? td.pstart + r : hv[k];
     vr[k] = *reinterpret_cast<const u32x4 *>(gv4 + (size_t)row * 4 + (q & 3));
   }
-  if constexpr (DIAG == 4) {
-    if (arow) {  // P(g) of this thread's row, into the row region (48-byte rows)
-      double gv[9], p[6];
-#pragma unroll
-      for (int c = 0; c < 9; c++) gv[c] = ga[c];
-      half_stress(gv, p);
-      double2 *dst = reinterpret_cast<double2 *>(xbuf + (size_t)tid * 48);
-      dst[0] = make_double2(p[0], p[1]);
-      dst[1] = make_double2(p[2], p[3]);
-      dst[2] = make_double2(p[4], p[5]);
-    }
-  }
   if constexpr (STAMP) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     gg_stamp_wave(dbg, (int)gridDim.x, t, 0);  // this wave's own pieces have landed
@@ -1193,8 +1174,10 @@ void gg_fused_split_kernel(
   if constexpr (STAMP) gg_stamp(dbg, t, 2);  // blob + gradient rows (+ var rows in registers) have landed
   if constexpr (DIAG == 2) {
     if (tid < td.npts * 3) flux[(size_t)td.pstart * 3 + tid] = 0.0;  // the flux rows leave as they do in the real pass
-  } else if constexpr (DIAG == 3 || DIAG == 4) {
+  } else if constexpr (DIAG == 3) {
     flux_tile_compute<LPP, REFMODE, 6, false>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
+  } else if constexpr (DIAG == 4) {
+    flux_tile_compute<LPP, REFMODE, 6>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   } else {
     flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   }
@@ -1206,7 +1189,7 @@ void gg_fused_split_kernel(
   __syncthreads();  // vmcnt(0) + barrier
   if constexpr (STAMP) gg_stamp(dbg, t, 4);  // var rows in place
   grad_tile_compute<LPP, NT, true, DIAG == 2>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
-                                              CB * nthr * 16, push_row);
+                                              CB * nthr * 16, push_row, PUSH && pa.tile_off && t < pa.nbtiles);
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 2);  // this wave is through its gradient phase (stores issued)
   if constexpr (STAMP) gg_stamp(dbg, t, 5);  // gradient arithmetic done, row stores issued (wave 0)
   if constexpr (STAMP) {
@@ -1542,7 +1525,7 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
   const int block = ((tile_points * lanes + 63) / 64) * 64;
   if (block > 1024) return hipErrorInvalidConfiguration;
   lds = (lds + 15) & ~(size_t)15;
-  const size_t stage_bytes = (gg_debug_flags & 64) ? 0 : (size_t)(block / 64) * 8 * 21 * 8;  // 8 rows of 168 bytes per wave
+  const size_t stage_bytes = (size_t)(block / 64) * 8 * 21 * 8;  // 8 rows of 168 bytes per wave
   if (lanes == 4 && !(gg_debug_flags & 16)) {  // fixed-count LDS-DMA staging; two equations per lane
     const int cb = (max_blob_qw + block - 1) / block;                    // blob pieces per thread
     const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;  // var-row pieces per thread

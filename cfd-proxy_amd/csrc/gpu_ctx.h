@@ -237,10 +237,12 @@ struct cfdp_gpu {
     for (int i = 0; i < nall; i++) {
       const double *r = rows + (size_t)new2old[i] * 21;
       if (i < nown) {
-        memcpy(a + (size_t)i * 10, r, 10 * sizeof(double));
+        gg_a_encode(r, a + (size_t)i * 10);  // part A as the flux loop wants it (gg_kernels.h)
         memcpy(b + (size_t)i * 11, r + 10, 11 * sizeof(double));
       } else {
-        memcpy(gh + (size_t)(i - nown) * 21, r, 21 * sizeof(double));
+        double *d = gh + (size_t)(i - nown) * 21;
+        gg_a_encode(r, d);
+        memcpy(d + 10, r + 10, 11 * sizeof(double));
       }
     }
   }
@@ -250,10 +252,12 @@ struct cfdp_gpu {
     for (int i = 0; i < nall; i++) {
       double *r = rows + (size_t)new2old[i] * 21;
       if (i < nown) {
-        memcpy(r, a + (size_t)i * 10, 10 * sizeof(double));
+        for (int c = 0; c < 10; c++) r[c] = gg_a_decode(a + (size_t)i * 10, c);
         memcpy(r + 10, b + (size_t)i * 11, 11 * sizeof(double));
       } else {
-        memcpy(r, gh + (size_t)(i - nown) * 21, 21 * sizeof(double));
+        const double *d = gh + (size_t)(i - nown) * 21;
+        for (int c = 0; c < 10; c++) r[c] = gg_a_decode(d, c);
+        memcpy(r + 10, d + 10, 11 * sizeof(double));
       }
     }
   }

@@ -105,7 +105,9 @@ def test_halo_exchange_between_in_process_ranks(gpu, orc, name, nd, overlap):
 
 
 def test_pack_and_unpack_kernels_match_copy_in_out(gpu, orc):
-    """gg_pack_kernel / gg_unpack_kernel vs exchange_dbl_copy_in/out (threads.c:791-839)"""
+    """gg_pack_kernel / gg_unpack_kernel vs exchange_dbl_copy_in/out (threads.c:791-839).  Rows travel as the device keeps
+    them (part A in its stored form, csrc/gg_kernels.h): the packed rows are stored_rows(copy_in), and what arrives is handed
+    out through the inverse -- the three upper off-diagonals of the velocity-gradient block within one rounding"""
     import torch
     pkg = gpu
     fx = load_golden("g4_12x10x9")
@@ -122,9 +124,9 @@ def test_pack_and_unpack_kernels_match_copy_in_out(gpu, orc):
     part.pack()
     part.sync()
     expect = np.concatenate([orc.pack(dom.sendindex(k), g0) for k in part.partners()])
-    assert np.array_equal(send.cpu().numpy().reshape(-1, 21), expect)
+    assert np.array_equal(send.cpu().numpy().reshape(-1, 21), pkg.stored_rows(expect))
     msg = rng.standard_normal((c["nrecv"], 21))
-    recv = torch.from_numpy(msg).cuda()
+    recv = torch.from_numpy(pkg.stored_rows(msg)).cuda()
     part.unpack(recv.data_ptr())
     part.pull_fields()
     ref = g0.copy()
@@ -133,7 +135,11 @@ def test_pack_and_unpack_kernels_match_copy_in_out(gpu, orc):
         ri = dom.recvindex(k)
         orc.unpack(ri, ref, msg[off: off + len(ri)])
         off += len(ri)
+    raw = ref.copy()
+    ref = pkg.handed_out_rows(pkg.stored_rows(ref)).reshape(ref.shape)  # every row went through the device's stored form
     assert np.array_equal(dom.grad, ref)
+    # ... which is the raw row within one rounding of the sums it is stored with
+    assert np.abs(ref - raw).max() <= 2.3e-16 * 2 * np.abs(raw).max() and np.array_equal(ref.reshape(-1, 21)[:, 9:], raw.reshape(-1, 21)[:, 9:])
     part.close()
     for d in doms:
         d.free()
