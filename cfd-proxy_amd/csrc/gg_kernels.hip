@@ -170,8 +170,12 @@ __device__ __forceinline__ void grad_batch(const uint32_t *__restrict__ inc, int
 // write-through system-scope store (sc0 sc1): the bytes leave this device's caches with the store itself.  Inline asm is
 // invisible to the compiler's vmcnt bookkeeping: the caller drains with s_waitcnt vmcnt(0) before it signals.
 typedef unsigned int gg_u32x4 __attribute__((ext_vector_type(4)));
+// s_nop 1: a store of more than 64 bits reads its data VGPRs over several cycles, and the instruction BEHIND an inline-asm
+// store is not checked against it by the compiler's hazard recogniser -- a VALU write of those registers in the next slot
+// (the address of the next piece, typically) went out as the first 8 bytes of the row piece (found in round 5: ghost rows
+// whose doubles 2, 8 and 14 held an address).  Two wait states, as the ISA asks for this write-after-read case.
 __device__ __forceinline__ void st16_sys(void *p, gg_u32x4 v) {  // global_store_dwordx4 ... sc0 sc1
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 // xGMI write + notify, a point's first destination, pushed from the REGISTERS of its lanes the moment the row is finished:
 // the lane holds the doubles [eq0 * 3, eq0 * 3 + n) of the 168-byte row (n = 6, or 3 for the lane group with the last

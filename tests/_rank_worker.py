@@ -162,6 +162,11 @@ def main():
                 dist.destroy_process_group()
                 sys.exit(77)
             assert solver.transport == args.transport, solver.transport  # no silent fallback in the tests
+            if args.transport == "ipc" and not args.mode_may_be_rejected:
+                # ... and no silent fall to a later RUNG either (round 5: a conservative rung behind the in-kernel ones
+                # masked a broken in-kernel push in every multi-rank test): the first rung attempted is the one accepted
+                first_rung, first_ev = next(iter(solver.validation.items()))
+                assert first_ev.get("ok"), (first_rung, solver.validation)
             if args.soak:  # a long run in the scaled field: no flux phase of any step may have read a row of an earlier exchange
                 ev = solver.stale_read_check(batches=(args.soak,))
                 assert ev["ok"] and ev["stale_reads"] == 0, ev
