@@ -315,22 +315,16 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
 #pragma unroll
           for (int c = 0; c < 3; c++) {
             const int d = (eq0 + j) * 3 + c;
-            (d < 10 ? oa : ob)[d] = acc[j][c] * tmp;
+            // part A goes into the slab in its stored ORDER (gg_a_encode, gg_kernels.h: raw double d -> slot, one nibble
+            // each): [g0 g4 g8 | g1 g2 g5 | g3 g6 g7 | g9]; the three sums are formed on the way out (below)
+            if (d < 10) oa[(int)((0x9287516430ull >> (4 * d)) & 15ull)] = acc[j][c] * tmp;
+            else ob[d] = acc[j][c] * tmp;
           }
         }
     }
     __builtin_amdgcn_wave_barrier();  // LDS executes a wave's accesses in order; keep the compiler in order too
     int nvh = nv - h * SPP;
     nvh = nvh < 0 ? 0 : (nvh > SPP ? SPP : nvh);
-    if (lane < nvh) {  // part A of the pass's rows into its stored form (gg_a_encode, gg_kernels.h), in place
-      double *r = slab + lane * 10, g[10], e[10];
-#pragma unroll
-      for (int c = 0; c < 10; c++) g[c] = r[c];
-      gg_a_encode(g, e);
-#pragma unroll
-      for (int c = 0; c < 10; c++) r[c] = e[c];
-    }
-    __builtin_amdgcn_wave_barrier();
     const size_t p0 = (size_t)(td.pstart + wp + h * SPP);
     double *ga = gradA + p0 * 10, *gb = gradB + p0 * 11;
     const int na = nvh * 10, nd = nvh * 21;
@@ -339,8 +333,14 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
         const int row = h * SPP + (c < na ? c / 10 : (c - na) / 11);
         if ((faceless >> (row * LPP)) & 1ull) continue;
       }
-      if (c < na) st_row<NT>(slab[c], &ga[c]);
-      else st_row<NT>(slab[SPP * 10 + c - na], &gb[c - na]);
+      if (c < na) {
+        double v = slab[c];
+        const int k = c % 10;
+        if (k >= 3 && k <= 5) v += slab[c + 3];  // g1 + g3, g2 + g6, g5 + g7: the stored form's symmetric sums
+        st_row<NT>(v, &ga[c]);
+      } else {
+        st_row<NT>(slab[SPP * 10 + c - na], &gb[c - na]);
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
