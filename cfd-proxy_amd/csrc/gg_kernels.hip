@@ -304,6 +304,8 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   // Slab image of a pass: [A parts: 8 x 10][B parts: 8 x 11], the two runs it is stored as.
   constexpr int SPP = 8, NPASS = PPW / SPP;
   double *slab = stage + wave * (SPP * 21);
+  // does this lane's double of round 0 / round 1 of a full pass sit in a sum slot (3..5 of a 10-double row)?
+  const bool sum0 = (unsigned)lane % 10u - 3u < 3u, sum1 = lane < 16 && (unsigned)(lane + 64) % 10u - 3u < 3u;
 #pragma unroll
   for (int h = 0; h < NPASS; h++) {
     const int lp = li - wp - h * SPP;  // this lane's point within the pass
@@ -328,19 +330,38 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     const size_t p0 = (size_t)(td.pstart + wp + h * SPP);
     double *ga = gradA + p0 * 10, *gb = gradB + p0 * 11;
     const int na = nvh * 10, nd = nvh * 21;
-    for (int c = lane; c < nd; c += 64) {
-      if (faceless) {  // uniform: some point of this wave has no faces -- its row stays as it is
+    // three rounds of 64 doubles cover the pass's 8 x 21; the symmetric sums of the stored form (g1 + g3, g2 + g6, g5 + g7:
+    // slots 3..5 take slots 6..8 on board) are formed here, on the way out
+    auto out = [&](int c, bool skip_rows) {
+      if (c >= nd) return;
+      if (skip_rows) {  // some point of this wave has no faces: its row stays as it is
         const int row = h * SPP + (c < na ? c / 10 : (c - na) / 11);
-        if ((faceless >> (row * LPP)) & 1ull) continue;
+        if ((faceless >> (row * LPP)) & 1ull) return;
       }
       if (c < na) {
         double v = slab[c];
-        const int k = c % 10;
-        if (k >= 3 && k <= 5) v += slab[c + 3];  // g1 + g3, g2 + g6, g5 + g7: the stored form's symmetric sums
+        const unsigned k = (unsigned)c % 10u;
+        if (k - 3u < 3u) v += slab[c + 3];
         st_row<NT>(v, &ga[c]);
       } else {
         st_row<NT>(slab[SPP * 10 + c - na], &gb[c - na]);
       }
+    };
+    if (nvh == SPP && !faceless) {
+      // the common case, a full pass (uniform per wave): the slab is one run [A: 80][B: 88] and so is what leaves --
+      // no index arithmetic, no branch; which lanes hold a sum slot is known per lane (sum0, sum1)
+      {
+        const double v = slab[lane], t = slab[lane + 3];
+        st_row<NT>(sum0 ? v + t : v, &ga[lane]);
+      }
+      {
+        const int c = lane + 64;
+        const double v = slab[c], t = slab[c + 3];
+        st_row<NT>(sum1 ? v + t : v, lane < 16 ? &ga[c] : &gb[c - 80]);
+      }
+      if (lane < 40) st_row<NT>(slab[lane + 128], &gb[lane + 48]);
+    } else {  // a partial pass (the tile's last points) or a point without faces in this wave: rare
+      for (int i = 0; i < 3; i++) out(lane + 64 * i, faceless != 0);
     }
     __builtin_amdgcn_wave_barrier();
   }
