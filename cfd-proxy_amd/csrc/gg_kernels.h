@@ -7,29 +7,28 @@
 #include "cfdproxy_hip.h"   // CFDP_IPC_HEADER_BYTES
 #include "cfdproxy_host.h"  // cfdp_tile_desc
 
-// grad in HBM: one allocation of nall*21 doubles.  An owned row's 21 doubles are split into
-// part A (doubles 0..9: the 3x3 velocity-gradient block + 1) and part B (doubles 10..20);
-// ghost rows stay whole, in message order:  [A: nown x 10][ghost: nghost x 21][B: nown x 11]
-//
-// Part A of every row ON THE DEVICE -- owned rows and ghost rows alike; rows travel between ranks as they are stored -- is
-// kept in the order and combination the flux loop wants it (round 5).  With g[0..8] the
-// row-major 3x3 block d(vx,vy,vz)/d(x,y,z) and g[9] the row's tenth double:
-//     e = [ g0  g4  g8 | g1+g3  g2+g6  g5+g7 | g3  g6  g7 | g9 ]
-// The viscous stress needs the diagonal and the three symmetric sums, nothing else (src/flux.c:139-173): the flux
-// loop stages the first 48 bytes of every 80-byte row -- 3 instead of 5 16-byte pieces per row through the CU's
-// memory pipe and into LDS, a 32-KiB tile image instead of 36 (five workgroups per CU), measured -7 % on the fused pass
-// at 64^3 (EXPERIMENTS.md D.2).  The sums are formed with the very addition the stress formula performs, so the flux is
-// bit for bit what it was.  The three upper off-diagonals are handed out as (g1+g3)-g3, (g2+g6)-g6, (g5+g7)-g7: within
-// one rounding of the sum of the two -- 1e-16 of the scale the 1e-10 tolerance is written against -- and the SAME value
-// wherever a row is seen: a ghost row is a bit copy of its owner's stored row, and rows leave the device through
-// gg_a_decode (cfdp_gpu_get_grad / cfdp_sync_fields_to_host) -- the one statement of it.
+// grad in HBM: one allocation of nall*21 doubles (round 5):
+//     [A1: nown x 6][ghost rows: nghost x 21, message order][A2: nown x 4][B: nown x 11]
+// With g[0..8] the row-major 3x3 block d(vx,vy,vz)/d(x,y,z) of a row and g[9] its tenth double, a row is kept -- on the
+// device and on the wire alike -- as
+//     e = [ g0  g4  g8  g1+g3  g2+g6  g5+g7 | g3  g6  g7  g9 | d10 .. d20 ]
+//            A1: all the flux loop needs      A2              B (untouched)
+// The viscous stress needs the diagonal and the three symmetric sums of the velocity-gradient block, nothing else
+// (src/flux.c:139-173).  A1 of the owned points is one array of contiguous 48-byte rows: the flux loop stages 3 instead
+// of 5 16-byte pieces per row through the CU's memory pipe and into LDS (a 32-KiB tile image instead of 36: five
+// workgroups per CU) and streams 48 instead of 80 bytes per owned point from memory (EXPERIMENTS.md D.2).  The sums are
+// formed with the very addition the stress formula performs, so the flux is bit for bit what it was.  The three upper
+// off-diagonals are handed out as (g1+g3)-g3, (g2+g6)-g6, (g5+g7)-g7: within one rounding of the sum of the two -- 1e-16 of
+// the scale the 1e-10 tolerance is written against -- and the SAME value wherever a row is seen: a ghost row (168 bytes,
+// whole, [e0..e9 | B]) is a bit copy of its owner's stored row, and rows leave the device through gg_a_decode
+// (cfdp_gpu_get_grad / cfdp_sync_fields_to_host), the one statement of it.
 __host__ __device__ inline void gg_a_encode(const double *g, double *e) {  // g, e: 10 doubles, may not alias
   e[0] = g[0]; e[1] = g[4]; e[2] = g[8];
   e[3] = g[1] + g[3]; e[4] = g[2] + g[6]; e[5] = g[5] + g[7];
   e[6] = g[3]; e[7] = g[6]; e[8] = g[7];
   e[9] = g[9];
 }
-__host__ __device__ inline double gg_a_decode(const double *e, int c) {  // component c (0..9) of the row stored at e
+__host__ __device__ inline double gg_a_decode(const double *e, int c) {  // component c (0..9) of the stored row e[0..9]
   switch (c) {
     case 0: return e[0];
     case 1: return e[3] - e[6];
@@ -44,12 +43,13 @@ __host__ __device__ inline double gg_a_decode(const double *e, int c) {  // comp
   }
 }
 struct gg_grad_view {
-  double *a, *ghost, *b;
+  double *a, *ghost, *a2, *b;  // a = A1
   static gg_grad_view of(double *base, int nown, int nall) {
     gg_grad_view v;
     v.a = base;
-    v.ghost = base + (size_t)nown * 10;
-    v.b = v.ghost + (size_t)(nall - nown) * 21;
+    v.ghost = base + (size_t)nown * 6;
+    v.a2 = v.ghost + (size_t)(nall - nown) * 21;
+    v.b = v.a2 + (size_t)nown * 4;
     return v;
   }
 };

@@ -28,13 +28,12 @@
 //
 // Algorithmic bytes per launch: 32*F + 232*P_own + 56*P_add.
 //
-// grad in HBM (one allocation of nall*21 doubles, see gg_grad_view in gg_kernels.h): the 21
-// doubles of an OWNED row are split into part A = doubles 0..9 (the 3x3 velocity-gradient
-// block the flux loop reads, + 1) and part B = doubles 10..20, stored as
-//   [A: nown x 10][ghost rows: nghost x 21, message order][B: nown x 11]
-// so that the flux kernel streams contiguous, 16-byte aligned 80-byte rows instead of the
-// first 80 bytes of every 168-byte row (measured: its gradient-row reads were 3x algorithmic),
-// while the halo exchange still delivers whole 168-byte rows straight into the ghost block.
+// grad in HBM (one allocation of nall*21 doubles, see gg_grad_view in gg_kernels.h): the 21 doubles of an OWNED row are
+// split into A1 (6 doubles: the diagonal and the three symmetric sums of the 3x3 velocity-gradient block -- all the flux
+// loop reads), A2 (4 doubles: the rest of the block and the row's tenth double) and B (doubles 10..20), stored as
+//   [A1: nown x 6][ghost rows: nghost x 21, message order][A2: nown x 4][B: nown x 11]
+// so that the flux loop streams contiguous, 16-byte aligned 48-byte rows, while the halo exchange still delivers whole
+// 168-byte rows [A1 | A2 | B] straight into the ghost block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -233,10 +232,10 @@ __device__ __forceinline__ void push_from_registers(double *row, int eq0, const 
 // pushing (uniform per workgroup): some lanes of this tile push their rows (push_row != nullptr for those)
 template <int LPP, bool NT, bool SYNC = false, bool MOVE = false>
 __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, const cfdp_tile_desc &td,
-                                                  int tid, double *__restrict__ gradA,
-                                                  double *__restrict__ gradB,
+                                                  int tid, const gg_grad_view &gout,
                                                   double *__restrict__ stage, int dbg = 0,
                                                   int var_off = -1, double *push_row = nullptr, bool pushing = false) {
+  double *__restrict__ gradA = gout.a, *__restrict__ gradA2 = gout.a2, *__restrict__ gradB = gout.b;
   constexpr int NE = grad_cfg<LPP>::NE;
   constexpr int PPW = 64 / LPP;  // points per wave
   const int li = tid / LPP, sub = tid % LPP;
@@ -300,27 +299,32 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   const int nv = td.npts - wp < PPW ? td.npts - wp : PPW;       // its valid points (may be <= 0)
   // a point without faces is in no colour list: the reference leaves its row alone (rare: its row is skipped below)
   const unsigned long long faceless = __ballot(active && ke0 == ks);
-  // 8 points (1344 bytes) per pass: the slab stays small enough for four workgroups per CU.
-  // Slab image of a pass: [A parts: 8 x 10][B parts: 8 x 11], the two runs it is stored as.
+  // 8 points (1344 bytes) per pass: the slab stays small enough for five workgroups per CU.
+  // Slab image of a pass: [A1: 8 x 6][A2: 8 x 4][B: 8 x 11], the three runs it is stored as.
   constexpr int SPP = 8, NPASS = PPW / SPP;
   double *slab = stage + wave * (SPP * 21);
-  // does this lane's double of round 0 / round 1 of a full pass sit in a sum slot (3..5 of a 10-double row)?
-  const bool sum0 = (unsigned)lane % 10u - 3u < 3u, sum1 = lane < 16 && (unsigned)(lane + 64) % 10u - 3u < 3u;
+  // round 0 of a full pass: lanes 0..47 hold A1, slot k = lane % 6 of row lane / 6; slots 3..5 take A2's 0..2 on board
+  const bool sum0 = lane < 48 && (unsigned)lane % 6u >= 3u;
+  const int sidx0 = sum0 ? SPP * 6 + (lane / 6) * 4 + (lane % 6 - 3) : 0;
 #pragma unroll
   for (int h = 0; h < NPASS; h++) {
     const int lp = li - wp - h * SPP;  // this lane's point within the pass
     if (active && lp >= 0 && lp < SPP) {
-      double *oa = slab + lp * 10, *ob = slab + SPP * 10 + lp * 11 - 10;
+      double *oa1 = slab + lp * 6, *oa2 = slab + SPP * 6 + lp * 4 - 6, *ob = slab + SPP * 10 + lp * 11 - 10;
 #pragma unroll
       for (int j = 0; j < NE; j++)
         if (eq0 + j < 7) {
 #pragma unroll
           for (int c = 0; c < 3; c++) {
             const int d = (eq0 + j) * 3 + c;
-            // part A goes into the slab in its stored ORDER (gg_a_encode, gg_kernels.h: raw double d -> slot, one nibble
-            // each): [g0 g4 g8 | g1 g2 g5 | g3 g6 g7 | g9]; the three sums are formed on the way out (below)
-            if (d < 10) oa[(int)((0x9287516430ull >> (4 * d)) & 15ull)] = acc[j][c] * tmp;
-            else ob[d] = acc[j][c] * tmp;
+            // the first ten doubles go into the slab in their stored ORDER (gg_a_encode, gg_kernels.h: raw double d ->
+            // slot, one nibble each): A1 [g0 g4 g8 | g1 g2 g5], A2 [g3 g6 g7 g9]; the three sums are formed on the way out
+            if (d < 10) {
+              const int slot = (int)((0x9287516430ull >> (4 * d)) & 15ull);
+              (slot < 6 ? oa1 : oa2)[slot] = acc[j][c] * tmp;
+            } else {
+              ob[d] = acc[j][c] * tmp;
+            }
           }
         }
     }
@@ -328,37 +332,33 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     int nvh = nv - h * SPP;
     nvh = nvh < 0 ? 0 : (nvh > SPP ? SPP : nvh);
     const size_t p0 = (size_t)(td.pstart + wp + h * SPP);
-    double *ga = gradA + p0 * 10, *gb = gradB + p0 * 11;
-    const int na = nvh * 10, nd = nvh * 21;
+    double *ga1 = gradA + p0 * 6, *ga2 = gradA2 + p0 * 4, *gb = gradB + p0 * 11;
+    const int na1 = nvh * 6, na2 = nvh * 4, nd = nvh * 21;
     // three rounds of 64 doubles cover the pass's 8 x 21; the symmetric sums of the stored form (g1 + g3, g2 + g6, g5 + g7:
-    // slots 3..5 take slots 6..8 on board) are formed here, on the way out
+    // A1's slots 3..5 take A2's 0..2 on board) are formed here, on the way out
     auto out = [&](int c, bool skip_rows) {
       if (c >= nd) return;
-      if (skip_rows) {  // some point of this wave has no faces: its row stays as it is
-        const int row = h * SPP + (c < na ? c / 10 : (c - na) / 11);
-        if ((faceless >> (row * LPP)) & 1ull) return;
-      }
-      if (c < na) {
+      const int row = c < na1 ? c / 6 : (c < na1 + na2 ? (c - na1) / 4 : (c - na1 - na2) / 11);
+      if (skip_rows && ((faceless >> ((h * SPP + row) * LPP)) & 1ull)) return;  // a point without faces: its row stays
+      if (c < na1) {
         double v = slab[c];
-        const unsigned k = (unsigned)c % 10u;
-        if (k - 3u < 3u) v += slab[c + 3];
-        st_row<NT>(v, &ga[c]);
+        const int k = c - 6 * row;
+        if (k >= 3) v += slab[SPP * 6 + row * 4 + k - 3];
+        st_row<NT>(v, &ga1[c]);
+      } else if (c < na1 + na2) {
+        st_row<NT>(slab[SPP * 6 + c - na1], &ga2[c - na1]);
       } else {
-        st_row<NT>(slab[SPP * 10 + c - na], &gb[c - na]);
+        st_row<NT>(slab[SPP * 10 + c - na1 - na2], &gb[c - na1 - na2]);
       }
     };
     if (nvh == SPP && !faceless) {
-      // the common case, a full pass (uniform per wave): the slab is one run [A: 80][B: 88] and so is what leaves --
-      // no index arithmetic, no branch; which lanes hold a sum slot is known per lane (sum0, sum1)
+      // the common case, a full pass (uniform per wave): the slab is one run [A1: 48][A2: 32][B: 88] and so is what
+      // leaves -- no index arithmetic, no branch; which lanes hold a sum slot is known per lane (sum0, sidx0)
       {
-        const double v = slab[lane], t = slab[lane + 3];
-        st_row<NT>(sum0 ? v + t : v, &ga[lane]);
+        const double v = slab[lane], t = slab[sidx0];
+        st_row<NT>(sum0 ? v + t : v, lane < 48 ? &ga1[lane] : &ga2[lane - 48]);
       }
-      {
-        const int c = lane + 64;
-        const double v = slab[c], t = slab[c + 3];
-        st_row<NT>(sum1 ? v + t : v, lane < 16 ? &ga[c] : &gb[c - 80]);
-      }
+      st_row<NT>(slab[lane + 64], lane < 16 ? &ga2[lane + 16] : &gb[lane - 16]);
       if (lane < 40) st_row<NT>(slab[lane + 128], &gb[lane + 48]);
     } else {  // a partial pass (the tile's last points) or a point without faces in this wave: rare
       for (int i = 0; i < 3; i++) out(lane + 64 * i, faceless != 0);
@@ -375,7 +375,8 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
 // storing 8 bytes at a 24-byte stride from their registers: 40-80 entries x ~1 us on the critical path of EVERY boundary
 // tile -- a pass with exchange took 99 us where the same pass without took 39.)
 __device__ __forceinline__ void push_tile_rows(const gg_push_args &pa, int tile, int tid, int nthr, const cfdp_tile_desc &td,
-                                               const double *gradA, const double *gradB) {
+                                               const gg_grad_view &gout) {
+  const double *gradA = gout.a, *gradA2 = gout.a2, *gradB = gout.b;
   if (!pa.tile_off || tile >= pa.nbtiles) return;  // uniform per workgroup
   // a 168-byte row leaves as ELEVEN stores: ten of 16 bytes and one of 8 (rows start at 0 or 8 mod 16 in the arena; narrow
   // write-through stores are one fabric write each and cost 2.7x a 16-byte store per byte, MI355X_MICROARCH.md)
@@ -393,8 +394,8 @@ __device__ __forceinline__ void push_tile_rows(const gg_push_args &pa, int tile,
     const int c0 = odd ? (q == 0 ? 0 : 2 * q - 1) : 2 * q;  // first double of this piece
     const bool pair = odd ? q != 0 : q != 10;
     // past this CU's L1: the values were written a moment ago by other waves of this workgroup
-    auto ld = [&](int c) {  // (rows travel in their stored form: part A as gg_a_encode leaves it)
-      const double *src = c < 10 ? gradA + p * 10 + c : gradB + p * 11 + (c - 10);
+    auto ld = [&](int c) {  // (rows travel in their stored form: [A1 | A2 | B])
+      const double *src = c < 6 ? gradA + p * 6 + c : (c < 10 ? gradA2 + p * 4 + (c - 6) : gradB + p * 11 + (c - 10));
       return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // write-through at system scope: the bytes leave this device's caches with the store itself, so NO cache write-back
@@ -584,7 +585,7 @@ template <int LPP, bool NT>
 __global__ __launch_bounds__(1024) void gg_gradient_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
     const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
-    double *__restrict__ gradA /*[nown][10]*/, double *__restrict__ gradB /*[nown][11]*/) {
+    gg_grad_view gout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(1024) void gg_gradient_kernel(
   }
   __syncthreads();
   double *stage = reinterpret_cast<double *>(smem + (size_t)td.blob_qw * 16 + (size_t)(npts + nhalo) * 64);
-  grad_tile_compute<LPP, NT>(smem, td, tid, gradA, gradB, stage);
+  grad_tile_compute<LPP, NT>(smem, td, tid, gout, stage);
 }
 
 // ---- fixed-count LDS-DMA staging ------------------------------------------------------------
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LPP == 8 ?
 void gg_gradient_dma_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
     const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
-    double *__restrict__ gradA /*[nown][10]*/, double *__restrict__ gradB /*[nown][11]*/, int dbg) {
+    gg_grad_view gout, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = tile_begin + xcd_tile(blockIdx.x, gridDim.x);
   const cfdp_tile_desc td = tiles[t];
@@ -687,7 +688,7 @@ void gg_gradient_dma_kernel(
   __syncthreads();  // vmcnt(0) + barrier: every wave's pieces have landed
   const int var_off = CB * nthr * 16;
   double *stage = reinterpret_cast<double *>(smem + (size_t)(CB + KV) * nthr * 16);
-  grad_tile_compute<LPP, NT>(smem, td, tid, gradA, gradB, stage, dbg, var_off);
+  grad_tile_compute<LPP, NT>(smem, td, tid, gout, stage, dbg, var_off);
 }
 
 // LDS-DMA: global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs, asynchronous (vmcnt)
@@ -850,13 +851,13 @@ __global__ __launch_bounds__(1024) void gg_flux_kernel(
   uint4 *s4 = reinterpret_cast<uint4 *>(smem);
   const uint4 *b4 = blob + td.blob_off;
   for (int q = tid; q < td.blob_qw; q += nthr) s4[q] = ld_blob<NT>(&b4[q]);
-  // velocity-gradient block grad[p][IVX..IVZ][0..2] = first 9 doubles of each 21-double row
+  // the six numbers of the velocity-gradient block the stress needs = A1 of an owned row, the first 6 doubles of a ghost row
   double *g_l = reinterpret_cast<double *>(s4 + td.blob_qw);  // [(npts+nhalo)][10]
   const int *hid = halo_idx + td.halo_off;
-  for (int q = tid; q < (npts + nhalo) * 9; q += nthr) {
-    const int r = q / 9, c = q - 9 * r;
+  for (int q = tid; q < (npts + nhalo) * 6; q += nthr) {
+    const int r = q / 6, c = q - 6 * r;
     const int row = r < npts ? td.pstart + r : hid[r - npts];
-    g_l[r * 10 + c] = row < nown ? gradA[(size_t)row * 10 + c]
+    g_l[r * 10 + c] = row < nown ? gradA[(size_t)row * 6 + c]
                                  : __hip_atomic_load(&ghost[(size_t)(row - nown) * 21 + c], __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_SYSTEM);  // see glds16_sys
   }
@@ -866,8 +867,8 @@ __global__ __launch_bounds__(1024) void gg_flux_kernel(
 }
 
 // one workgroup per tile, fixed-count LDS-DMA staging (see gg_gradient_dma_kernel): the blob as CB
-// pieces per wave, the gradient rows as KV pieces per wave -- 5 pieces (80 bytes) per row: own
-// rows by position and owned halo rows by number from part A, ghost halo rows = the first 80
+// pieces per wave, the gradient rows as KV pieces per wave -- 3 pieces (48 bytes: A1) per row: own
+// rows by position and owned halo rows by number from A1, ghost halo rows = the first 48
 // bytes of their 168-byte row in the ghost block
 // WAIT: the flux that closes a batch of exchanging iterations -- its boundary tiles wait for the rows of the last exchange
 // themselves (as the boundary tiles of a pushing pass do), so that no wait kernel stands between the last pass and it
@@ -890,8 +891,8 @@ __global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
 #pragma unroll
   for (int k = 0; k < KV; k++) {
     const int q = tid + k * nthr;
-    rloc[k] = q / 5;
-    part[k] = q - 5 * rloc[k];
+    rloc[k] = q / 3;
+    part[k] = q - 3 * rloc[k];
     int h = rloc[k] - td.npts;
     h = h < 0 ? 0 : (h > hmax ? hmax : h);
     hrow[k] = ld_i32_nowait(hid + h);
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(CB) : "memory");
 #pragma unroll
   for (int k = 0; k < KV; k++) asm volatile("" : "+v"(hrow[k]));  // uses stay behind the wait
-  // (4) gradient rows, 80 bytes each
+  // (4) gradient rows, 48 bytes each
   unsigned char *gbuf = smem + (size_t)CB * nthr * 16;
   const unsigned char *abytes = reinterpret_cast<const unsigned char *>(gradA);
   const unsigned char *hbytes = reinterpret_cast<const unsigned char *>(ghost);
@@ -918,13 +919,13 @@ __global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
   for (int k = 0; k < KV; k++) {
     const int row = rloc[k] < td.npts ? td.pstart + rloc[k] : hrow[k];
     if (row < nown)
-      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * 80 + part[k] * 16), gbuf + (size_t)(w0 + k * nthr) * 16);
+      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * 48 + part[k] * 16), gbuf + (size_t)(w0 + k * nthr) * 16);
     else
       glds16_sys(reinterpret_cast<const uint4 *>(hbytes + (size_t)(row - nown) * 168 + part[k] * 16),
                  gbuf + (size_t)(w0 + k * nthr) * 16);
   }
   __syncthreads();
-  flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
+  flux_tile_compute<LPP, REFMODE, 6>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
 }
 
 // ------------------------------------------------------------------- fused iteration kernel
@@ -944,7 +945,7 @@ void gg_fused_dma_kernel(
     const int *__restrict__ halo_idx, const double *__restrict__ var /*[nall][8]*/,
     const double *__restrict__ gradA_old /*[nown][10]*/, const double *__restrict__ ghost_old /*[nghost][21]*/,
     double *__restrict__ flux /*[nown][3]*/, int nown,
-    double *__restrict__ gradA_new /*[nown][10]*/, double *__restrict__ gradB_new /*[nown][11]*/, int dbg,
+    gg_grad_view gnew, int dbg,
     gg_push_args pa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LPP = 4;
@@ -970,8 +971,8 @@ void gg_fused_dma_kernel(
 #pragma unroll
   for (int k = 0; k < KG; k++) {
     const int q = tid + k * nthr;
-    rloc[k] = q / 5;
-    part[k] = q - 5 * rloc[k];
+    rloc[k] = q / 3;
+    part[k] = q - 3 * rloc[k];
     int h = rloc[k] - td.npts;
     h = h < 0 ? 0 : (h > hmax ? hmax : h);
     hg[k] = ld_i32_nowait(hid + h);
@@ -1008,7 +1009,7 @@ void gg_fused_dma_kernel(
   for (int k = 0; k < KG; k++) {
     const int row = rloc[k] < td.npts ? td.pstart + rloc[k] : hg[k];
     if (row < nown)
-      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * 80 + part[k] * 16), gbuf + (size_t)(w0 + k * nthr) * 16);
+      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * 48 + part[k] * 16), gbuf + (size_t)(w0 + k * nthr) * 16);
     else
       glds16_sys(reinterpret_cast<const uint4 *>(hbytes + (size_t)(row - nown) * 168 + part[k] * 16),
                  gbuf + (size_t)(w0 + k * nthr) * 16);
@@ -1020,23 +1021,25 @@ void gg_fused_dma_kernel(
     const int pslot = (int)(unsigned)pfirst, prow = (int)(pfirst >> 32);
     if (pslot >= 0) push_row = pa.dst[pslot] + (size_t)prow * 21;
   }
-  flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
-  grad_tile_compute<LPP, NT, true>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(gbuf), dbg,
+  flux_tile_compute<LPP, REFMODE, 6>(smem, reinterpret_cast<double *>(gbuf), td, hid, tid, nthr, flux, nown);
+  grad_tile_compute<LPP, NT, true>(smem, td, tid, gnew, reinterpret_cast<double *>(gbuf), dbg,
                                    CB * nthr * 16, push_row, pa.tile_off && t < pa.nbtiles);
-  push_tile_rows(pa, t, tid, nthr, td, gradA_new, gradB_new);
+  push_tile_rows(pa, t, tid, nthr, td, gnew);
   push_tile_done(pa, t, tid, iter0);
 }
 
 // --------------------------------------------------------------------------- pack/unpack
 __global__ __launch_bounds__(256) void gg_pack_kernel(const int *__restrict__ send_idx, int nsend,
                                                       const double *__restrict__ gradA,
+                                                      const double *__restrict__ gradA2,
                                                       const double *__restrict__ gradB,
                                                       double *__restrict__ sendbuf) {
   const int n = nsend * 21;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int j = i / 21, c = i - 21 * j;
     const size_t p = (size_t)send_idx[j];  // send points are owned points
-    sendbuf[i] = c < 10 ? gradA[p * 10 + c] : gradB[p * 11 + c - 10];  // whole 168-byte rows on the wire, in their stored form
+    // whole 168-byte rows on the wire, in their stored form [A1 | A2 | B]
+    sendbuf[i] = c < 6 ? gradA[p * 6 + c] : (c < 10 ? gradA2[p * 4 + c - 6] : gradB[p * 11 + c - 10]);
   }
 }
 
@@ -1065,14 +1068,10 @@ __device__ __forceinline__ void gg_stamp_wave(int dbg, int ntiles, int tile, int
 // tiles wait for the previous exchange, push their rows, notify) -- both compile-time, so the pass that runs one
 // partition on one GPU carries neither the other path's code nor its registers
 // DIAG: 0 = the timed kernel; 1 = phase stamps (tools/phase_stamps.py); 2 = data movement only: every load and every
-// store of the pass, neither face loop (cfdp_gpu_time_fused_movement: the floor bench.py reports beside the pass);
-// 3 = TIMING EXPERIMENT, values wrong (CFDP_EXP_PROWS=1, EXPERIMENTS.md D.2): the flux phase as if the gradient phase of
-// the previous pass had stored P(g) (6 doubles, 48 bytes) per point -- 3 pieces per row instead of 5, no pass over the
-// staged rows, no barrier behind it, and a row region of 3 pieces per thread: a 32-KiB image, FIVE workgroups per CU
-// 4 = the product form for tiles of at most 192 staged rows (round 5): what D.2 measured, made real by the stored form of
-// part A (gg_a_encode, gg_kernels.h): the flux phase stages the FIRST 48 BYTES of every row -- the six numbers the stress
-// needs -- 3 pieces per row instead of 5, so the shared row region holds 3 pieces per thread: a 32-KiB image (CB = 5,
-// KX = 3), five workgroups per CU.  Values: bit for bit those of the other forms.
+// store of the pass, neither face loop (cfdp_gpu_time_fused_movement: the floor bench.py reports beside the pass)
+// Two capacities are instantiated: CB = 5, KV = 4, KG = 3, KX = 4 (tiles of up to 256 staged rows: 36 KiB, four workgroups
+// per CU) and CB = 5, KV = KG = KX = 3 (up to 192 staged rows -- every tile of the 64-point lattice plans: 32 KiB, FIVE
+// workgroups per CU).  The flux phase stages the first 48 bytes of every row (A1: the six numbers the stress needs).
 template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, int DIAG = 0, bool LISTED = true, bool PUSH = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(
@@ -1080,7 +1079,7 @@ void gg_fused_split_kernel(
     const int *__restrict__ halo_idx, const int *__restrict__ rowlist, const double *__restrict__ var /*[nall][8]*/,
     const double *__restrict__ gradA_old /*[nown][10]*/, const double *__restrict__ ghost_old /*[nghost][21]*/,
     double *__restrict__ flux /*[nown][3]*/, int nown,
-    double *__restrict__ gradA_new /*[nown][10]*/, double *__restrict__ gradB_new /*[nown][11]*/, int dbg,
+    gg_grad_view gnew, int dbg,
     gg_push_args pa) {
   static_assert(KX >= KV && KX >= KG, "the shared row region must hold either set of rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1106,7 +1105,7 @@ void gg_fused_split_kernel(
     if (pa.tile_off && t < pa.nbtiles) pfirst = ld_u64_nowait(pa.pt_first + (size_t)t * pa.pt_stride + (tid >> 2));
   }
   int hv[KV], hg[KG], part[KG], rloc[KG];
-  constexpr int PPR = DIAG == 3 || DIAG == 4 ? 3 : 5;  // 16-byte pieces staged per gradient row
+  constexpr int PPR = 3;  // 16-byte pieces staged per gradient row: its first 48 bytes (A1)
   // with a fixed-stride row list the row numbers are requested before the descriptor is even here:
   // descriptor -> blob and row list -> rows are two chains of two round trips instead of one of three
   constexpr bool listed = LISTED;
@@ -1175,7 +1174,7 @@ void gg_fused_split_kernel(
   for (int k = 0; k < KG; k++) {
     const int row = !listed && rloc[k] < td.npts ? td.pstart + rloc[k] : hg[k];
     if (row < nown)
-      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * (DIAG == 3 && !(dbg & 0x100000) ? 48 : 80) + part[k] * 16), xbuf + (size_t)(w0 + k * nthr) * 16);
+      glds16(reinterpret_cast<const uint4 *>(abytes + (size_t)row * 48 + part[k] * 16), xbuf + (size_t)(w0 + k * nthr) * 16);
     else
       glds16_sys(reinterpret_cast<const uint4 *>(hbytes + (size_t)(row - nown) * 168 + part[k] * 16),
                  xbuf + (size_t)(w0 + k * nthr) * 16);
@@ -1199,12 +1198,8 @@ void gg_fused_split_kernel(
   if constexpr (STAMP) gg_stamp(dbg, t, 2);  // blob + gradient rows (+ var rows in registers) have landed
   if constexpr (DIAG == 2) {
     if (tid < td.npts * 3) flux[(size_t)td.pstart * 3 + tid] = 0.0;  // the flux rows leave as they do in the real pass
-  } else if constexpr (DIAG == 3) {
-    flux_tile_compute<LPP, REFMODE, 6, false>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
-  } else if constexpr (DIAG == 4) {
-    flux_tile_compute<LPP, REFMODE, 6>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   } else {
-    flux_tile_compute<LPP, REFMODE>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
+    flux_tile_compute<LPP, REFMODE, 6>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   }
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 1);  // this wave is through its flux phase
   __syncthreads();  // every wave is done with the gradient rows: the region takes the var rows
@@ -1213,7 +1208,7 @@ void gg_fused_split_kernel(
   for (int k = 0; k < KV; k++) *reinterpret_cast<u32x4 *>(xbuf + (size_t)(tid + k * nthr) * 16) = vr[k];
   __syncthreads();  // vmcnt(0) + barrier
   if constexpr (STAMP) gg_stamp(dbg, t, 4);  // var rows in place
-  grad_tile_compute<LPP, NT, true, DIAG == 2>(smem, td, tid, gradA_new, gradB_new, reinterpret_cast<double *>(xbuf), dbg,
+  grad_tile_compute<LPP, NT, true, DIAG == 2>(smem, td, tid, gnew, reinterpret_cast<double *>(xbuf), dbg,
                                               CB * nthr * 16, push_row, PUSH && pa.tile_off && t < pa.nbtiles);
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 2);  // this wave is through its gradient phase (stores issued)
   if constexpr (STAMP) gg_stamp(dbg, t, 5);  // gradient arithmetic done, row stores issued (wave 0)
@@ -1222,7 +1217,7 @@ void gg_fused_split_kernel(
     gg_stamp(dbg, t, 6);  // wave 0's stores acknowledged
   }
   if constexpr (PUSH) {
-    if (!(dbg & 0x200)) push_tile_rows(pa, t, tid, nthr, td, gradA_new, gradB_new);
+    if (!(dbg & 0x200)) push_tile_rows(pa, t, tid, nthr, td, gnew);
     if (!(dbg & 0x400)) push_tile_done(pa, t, tid, iter0, dbg);
   }
 }
@@ -1241,6 +1236,7 @@ __global__ __launch_bounds__(256) void gg_push_kernel(const int *__restrict__ se
                                                       const int *__restrict__ slot_of_row,
                                                       const int *__restrict__ send_off,
                                                       const double *__restrict__ gradA,
+                                                      const double *__restrict__ gradA2,
                                                       const double *__restrict__ gradB,
                                                       double *const *__restrict__ dst) {
   const int n = nsend * 21;
@@ -1248,7 +1244,7 @@ __global__ __launch_bounds__(256) void gg_push_kernel(const int *__restrict__ se
     const int j = i / 21, c = i - 21 * j;
     const size_t p = (size_t)send_idx[j];
     const int s = slot_of_row[j];
-    const double v = c < 10 ? gradA[p * 10 + c] : gradB[p * 11 + c - 10];
+    const double v = c < 6 ? gradA[p * 6 + c] : (c < 10 ? gradA2[p * 4 + c - 6] : gradB[p * 11 + c - 10]);
     dst[s][(size_t)(j - send_off[s]) * 21 + c] = v;
   }
 }
@@ -1402,7 +1398,7 @@ hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row
   int blocks = (nsend * 21 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(gg_push_kernel, dim3(blocks), dim3(256), 0, stream, send_idx, nsend, slot_of_row, send_off,
-                     grad.a, grad.b, dst);
+                     grad.a, grad.a2, grad.b, dst);
   return hipGetLastError();
 }
 hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, const int *need, int *tile_iter, int nbtiles, hipStream_t stream) {
@@ -1425,8 +1421,8 @@ hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, const int *tile_
 hipError_t gg_set_stamp_buffer(unsigned long long *dev) {
   return hipMemcpyToSymbol(HIP_SYMBOL(gg_stamp_buf), &dev, sizeof dev);
 }
-// fused pass: 0 everything staged up front; 1 the phase-split form (one shared row region, 36 KiB, 4 workgroups per CU);
-// 2 (default) the register-staged form where the tiles allow it (32 KiB, 5 workgroups per CU), else the phase-split form
+// fused pass: 0 everything staged up front; 1 the phase-split form at its large capacity only (36 KiB, 4 workgroups per
+// CU); 2 (default) its small capacity where the tiles allow it (32 KiB, 5 workgroups per CU)
 int gg_fused_split = 2;
 int gg_debug_flags = 0;  // 16: register-staged kernels only; 64: per-lane row stores; GG_DBG_STAMP: phase stamps
 
@@ -1459,15 +1455,15 @@ hipError_t launch(K *kernel, int grid, int block, size_t lds, hipStream_t stream
 
 template <int L> hipError_t launch_grad_generic(const gg_args &a, bool nt, int tile_begin, int ntiles, int block, size_t lds,
                                                 hipStream_t stream) {
-  if (nt) return launch(gg_gradient_kernel<L, true>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b);
-  return launch(gg_gradient_kernel<L, false>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b);
+  if (nt) return launch(gg_gradient_kernel<L, true>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad);
+  return launch(gg_gradient_kernel<L, false>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad);
 }
 
 template <int CB, int KV> hipError_t launch_grad_dma(const gg_args &a, bool nt, int tile_begin, int ntiles, int block,
                                                      size_t stage_bytes, hipStream_t stream) {
   const size_t lds = (size_t)(CB + KV) * block * 16 + stage_bytes;
-  if (nt) return launch(gg_gradient_dma_kernel<4, true, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b, gg_debug_flags);
-  return launch(gg_gradient_dma_kernel<4, false, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.b, gg_debug_flags);
+  if (nt) return launch(gg_gradient_dma_kernel<4, true, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags);
+  return launch(gg_gradient_dma_kernel<4, false, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags);
 }
 
 template <int L, bool R> hipError_t launch_flux_generic(const gg_args &a, bool nt, int tile_begin, int ntiles, int block, size_t lds,
@@ -1493,18 +1489,9 @@ template <bool R, int CB, int KV> hipError_t launch_flux_dma(const gg_args &a, b
 template <bool R, bool N, int D, bool L, bool P>
 hipError_t launch_split(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
                         int dbgf, const gg_push_args &pa) {
-  return launch(gg_fused_split_kernel<R, N, 5, 4, 4, 4, D, L, P>, ntiles, block, (size_t)(5 + 4) * block * 16, stream, a.tiles, tile_begin,
-                a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa);
+  return launch(gg_fused_split_kernel<R, N, 5, 4, 3, 4, D, L, P>, ntiles, block, (size_t)(5 + 4) * block * 16, stream, a.tiles, tile_begin,
+                a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa);
 }
-// CFDP_EXP_PROWS: see DIAG == 3 of gg_fused_split_kernel
-#define GG_DBG_PROWS 0x80000
-template <bool N>
-hipError_t launch_split_prows(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
-                              int dbgf, const gg_push_args &pa) {
-  return launch(gg_fused_split_kernel<false, N, 5, 3, 3, 3, 3, true, false>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles,
-                tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa);
-}
-
 template <bool R, bool N>
 hipError_t launch_split_lp(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
                            int dbgf, const gg_push_args &pa) {
@@ -1515,12 +1502,12 @@ hipError_t launch_split_lp(const gg_args &a, const gg_grad_view &gnew, int tile_
                  : launch_split<R, N, 0, false, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
 }
 
-// the register-staged form (DIAG == 4 of gg_fused_split_kernel): 5 blob + 3 row pieces per thread = a 32-KiB image
+// the small capacity of gg_fused_split_kernel: 5 blob + 3 row pieces per thread = a 32-KiB image, five workgroups per CU
 template <bool R, bool N, bool L, bool P>
 hipError_t launch_preg(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
                        int dbgf, const gg_push_args &pa) {
-  return launch(gg_fused_split_kernel<R, N, 5, 3, 3, 3, 4, L, P>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles, tile_begin,
-                a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa);
+  return launch(gg_fused_split_kernel<R, N, 5, 3, 3, 3, 0, L, P>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles, tile_begin,
+                a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa);
 }
 template <bool R, bool N>
 hipError_t launch_preg_lp(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
@@ -1536,7 +1523,7 @@ template <int CB, int KV, int KG>
 hipError_t launch_fused_upfront(const gg_args &a, const gg_grad_view &gnew, bool refmode, bool nt, int tile_begin, int ntiles, int block,
                                 hipStream_t stream, int dbgf, const gg_push_args &pa) {
   const size_t lds = (size_t)(CB + KV + KG) * block * 16;
-#define FUSED_ARGS ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew.a, gnew.b, dbgf, pa
+#define FUSED_ARGS ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa
   if (refmode) return nt ? launch(gg_fused_dma_kernel<true, true, CB, KV, KG>, FUSED_ARGS) : launch(gg_fused_dma_kernel<true, false, CB, KV, KG>, FUSED_ARGS);
   return nt ? launch(gg_fused_dma_kernel<false, true, CB, KV, KG>, FUSED_ARGS) : launch(gg_fused_dma_kernel<false, false, CB, KV, KG>, FUSED_ARGS);
 #undef FUSED_ARGS
@@ -1575,7 +1562,7 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
 bool gg_flux_can_wait(int lanes, int tile_points, int max_halo, int max_blob_qw) {
   const int block = ((tile_points * lanes + 63) / 64) * 64;
   if (block > 1024 || lanes != 8 || (gg_debug_flags & 16)) return false;
-  const int cb = (max_blob_qw + block - 1) / block, kv = ((tile_points + max_halo) * 5 + block - 1) / block;
+  const int cb = (max_blob_qw + block - 1) / block, kv = ((tile_points + max_halo) * 3 + block - 1) / block;
   return cb >= 1 && kv >= 1 && cb <= 6 && kv <= 4 && (size_t)(6 + 4) * block * 16 <= LDS_MAX;
 }
 
@@ -1587,7 +1574,7 @@ hipError_t gg_launch_flux(const gg_args &a, int lanes, bool refmode, int tile_be
   if (block > 1024) return hipErrorInvalidConfiguration;
   if (lanes == 8 && !(gg_debug_flags & 16)) {  // fixed-count LDS-DMA staging
     const int cb = (max_blob_qw + block - 1) / block;
-    const int kv = ((tile_points + max_halo) * 5 + block - 1) / block;
+    const int kv = ((tile_points + max_halo) * 3 + block - 1) / block;
 #define FLUX_DMA(CB, KV)                                                                                 \
   if (cb <= CB && kv <= KV && (size_t)(CB + KV) * block * 16 <= LDS_MAX)                                   \
     return refmode ? launch_flux_dma<true, CB, KV>(a, nt, tile_begin, ntiles, block, stream, wait)         \
@@ -1619,7 +1606,7 @@ bool gg_fused_fits(int tile_points, int max_halo, int max_blob_qw) {
   if (block > 1024 || (gg_debug_flags & 16)) return false;
   const int cb = (max_blob_qw + block - 1) / block;
   const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;
-  const int kg = ((tile_points + max_halo) * 5 + block - 1) / block;
+  const int kg = ((tile_points + max_halo) * 3 + block - 1) / block;
   return cb >= 1 && kv >= 1 && kg >= 1 && cb <= 8 && kv <= 6 && kg <= 8 &&
          (size_t)(8 + 6 + 8) * block * 16 <= LDS_MAX;  // the largest instantiated capacity
 }
@@ -1636,9 +1623,9 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
   if (block > 1024 || (gg_debug_flags & 16)) return hipErrorNotSupported;
   const int cb = (max_blob_qw + block - 1) / block;
   const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;
-  const int kg = ((tile_points + max_halo) * 5 + block - 1) / block;
+  const int kg = ((tile_points + max_halo) * 3 + block - 1) / block;
   if (cb < 1 || kv < 1 || kg < 1) return hipErrorNotSupported;
-  if (gg_fused_split && allow_split && cb <= 5 && kv <= 4 && kg <= 4) {
+  if (gg_fused_split && allow_split && cb <= 5 && kv <= 4 && kg <= 3) {
     if (gg_debug_flags & GG_DBG_STAMP) {  // diagnostic build of the same kernel: phase stamps (tools/phase_stamps.py)
       if (!a.rowlist) return hipErrorNotSupported;  // the stamped instantiation reads the fixed-stride row lists
       return nt ? launch_split<false, true, 1, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
@@ -1649,16 +1636,13 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
       return nt ? launch_split<false, true, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                 : launch_split<false, false, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     }
-    // tiles of at most 192 staged rows (3 var pieces per thread) and one thread per staged row: the register-staged form
-    if (gg_fused_split >= 2 && kv <= 3 && tile_points + max_halo <= block && !(gg_debug_flags & GG_DBG_PROWS)) {
+    // tiles of at most 192 staged rows (3 var pieces per thread): the 32-KiB capacity
+    if (gg_fused_split >= 2 && kv <= 3) {
       if (refmode) return nt ? launch_preg_lp<true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                              : launch_preg_lp<true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
       return nt ? launch_preg_lp<false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                 : launch_preg_lp<false, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     }
-    if ((gg_debug_flags & GG_DBG_PROWS) && a.rowlist && !push && !refmode && kv <= 3)
-      return nt ? launch_split_prows<true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
-                : launch_split_prows<false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     if (refmode) return nt ? launch_split_lp<true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                            : launch_split_lp<true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     return nt ? launch_split_lp<false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
@@ -1683,7 +1667,7 @@ hipError_t gg_launch_pack(const int *send_idx, int nsend, const gg_grad_view &gr
   const int n = nsend * 21;
   int blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gg_pack_kernel, dim3(blocks), dim3(256), 0, stream, send_idx, nsend, grad.a, grad.b, sendbuf);
+  hipLaunchKernelGGL(gg_pack_kernel, dim3(blocks), dim3(256), 0, stream, send_idx, nsend, grad.a, grad.a2, grad.b, sendbuf);
   return hipGetLastError();
 }
 

@@ -61,8 +61,6 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
   cfdp_gpu *g = new cfdp_gpu();
   g->device = device;
   if (const char *e = cfdp_experiment_getenv("CFDP_DEBUG_ABLATE")) gg_debug_flags = atoi(e);  // honoured only with CFDP_EXPERIMENTS=1
-  if (const char *e = cfdp_experiment_getenv("CFDP_EXP_PROWS"))  // timing experiment, values WRONG (EXPERIMENTS.md D.2)
-    gg_debug_flags = (gg_debug_flags & ~0x180000) | (atoi(e) ? 0x80000 : 0) | (atoi(e) == 2 ? 0x100000 : 0);  // 2: 48 of every 80 bytes
   if (const char *e = getenv("CFDP_FUSED_SPLIT")) gg_fused_split = atoi(e);
   HIP_TRY(hipStreamCreateWithFlags(&g->s_main, hipStreamNonBlocking));
   {
@@ -365,7 +363,7 @@ int cfdp_gpu_set_grad(cfdp_gpu *g, const double *grad) {
     HIP_TRY(hipMemcpy(g->d_grad_alt, tmp, len * sizeof(double), hipMemcpyHostToDevice));
   if (g->ipc.on && g->nall > g->nown)
     for (int par = 0; par < 2; par++)
-      HIP_TRY(hipMemcpy(g->land(par), tmp + (size_t)g->nown * 10,
+      HIP_TRY(hipMemcpy(g->land(par), tmp + (size_t)g->nown * 6,
                         sizeof(double) * 21 * (size_t)(g->nall - g->nown), hipMemcpyHostToDevice));
   return 0;
 }
@@ -392,7 +390,7 @@ int cfdp_gpu_get_grad(cfdp_gpu *g, double *grad) {
   if (!tmp) return fail("no pinned host memory for the staging image");
   HIP_TRY(hipMemcpy(tmp, g->d_grad, len * sizeof(double), hipMemcpyDeviceToHost));
   if (g->ipc.on && g->nall > g->nown)  // the ghost rows live in the landing arena of the latest exchange
-    HIP_TRY(hipMemcpy(tmp + (size_t)g->nown * 10, g->grad_view().ghost,
+    HIP_TRY(hipMemcpy(tmp + (size_t)g->nown * 6, g->grad_view().ghost,
                       sizeof(double) * 21 * (size_t)(g->nall - g->nown), hipMemcpyDeviceToHost));
   g->device_to_rows(tmp, grad);
   return 0;

@@ -208,7 +208,7 @@ struct cfdp_gpu {
     graph_iters = graph_rem_iters = 0;
   }
 
-  // d_grad: nall*21 doubles laid out [A: nown x 10][ghost rows: nghost x 21][B: nown x 11]
+  // d_grad: nall*21 doubles laid out [A1: nown x 6][ghost rows: nghost x 21][A2: nown x 4][B: nown x 11] (gg_kernels.h)
   gg_grad_view grad_view() const {
     gg_grad_view v = gg_grad_view::of(d_grad, nown, nall);
     if (ipc.on) v.ghost = land((int)(ipc.xiter & 1));  // the latest exchange landed here
@@ -232,12 +232,15 @@ struct cfdp_gpu {
   }
   // device image <-> rows in FILE numbering
   void rows_to_device(const double *rows, double *img) const {
-    double *a = img, *gh = a + (size_t)nown * 10, *b = gh + (size_t)(nall - nown) * 21;
+    double *a1 = img, *gh = a1 + (size_t)nown * 6, *a2 = gh + (size_t)(nall - nown) * 21, *b = a2 + (size_t)nown * 4;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < nall; i++) {
       const double *r = rows + (size_t)new2old[i] * 21;
       if (i < nown) {
-        gg_a_encode(r, a + (size_t)i * 10);  // part A as the flux loop wants it (gg_kernels.h)
+        double e[10];
+        gg_a_encode(r, e);  // the first ten doubles as the device keeps them (gg_kernels.h)
+        memcpy(a1 + (size_t)i * 6, e, 6 * sizeof(double));
+        memcpy(a2 + (size_t)i * 4, e + 6, 4 * sizeof(double));
         memcpy(b + (size_t)i * 11, r + 10, 11 * sizeof(double));
       } else {
         double *d = gh + (size_t)(i - nown) * 21;
@@ -247,12 +250,15 @@ struct cfdp_gpu {
     }
   }
   void device_to_rows(const double *img, double *rows) const {
-    const double *a = img, *gh = a + (size_t)nown * 10, *b = gh + (size_t)(nall - nown) * 21;
+    const double *a1 = img, *gh = a1 + (size_t)nown * 6, *a2 = gh + (size_t)(nall - nown) * 21, *b = a2 + (size_t)nown * 4;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < nall; i++) {
       double *r = rows + (size_t)new2old[i] * 21;
       if (i < nown) {
-        for (int c = 0; c < 10; c++) r[c] = gg_a_decode(a + (size_t)i * 10, c);
+        double e[10];
+        memcpy(e, a1 + (size_t)i * 6, 6 * sizeof(double));
+        memcpy(e + 6, a2 + (size_t)i * 4, 4 * sizeof(double));
+        for (int c = 0; c < 10; c++) r[c] = gg_a_decode(e, c);
         memcpy(r + 10, b + (size_t)i * 11, 11 * sizeof(double));
       } else {
         const double *d = gh + (size_t)(i - nown) * 21;

@@ -668,7 +668,7 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
   // the ghost rows move into the landing arenas
   if (g->nall > g->nown)
     for (int par = 0; par < 2; par++)
-      HIP_TRY(cfdp_copy_d2d_sync(g->land(par), g->d_grad + (size_t)g->nown * 10, sizeof(double) * 21 * (size_t)(g->nall - g->nown)));
+      HIP_TRY(cfdp_copy_d2d_sync(g->land(par), g->d_grad + (size_t)g->nown * 6, sizeof(double) * 21 * (size_t)(g->nall - g->nown)));
   I.xiter = 0;
   I.on = true;
   g->drop_graphs();
