@@ -1198,8 +1198,8 @@ void gg_fused_split_kernel(
   if constexpr (STAMP) gg_stamp(dbg, t, 2);  // blob + gradient rows (+ var rows in registers) have landed
   if constexpr (DIAG == 2) {
     if (tid < td.npts * 3) flux[(size_t)td.pstart * 3 + tid] = 0.0;  // the flux rows leave as they do in the real pass
-  } else {
-    flux_tile_compute<LPP, REFMODE, 6>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
+  } else {  // (DIAG == 3: timing experiment, values wrong -- the pass over the staged rows and its barrier skipped)
+    flux_tile_compute<LPP, REFMODE, 6, DIAG != 3>(smem, reinterpret_cast<double *>(xbuf), td, hid, tid, nthr, flux, nown);
   }
   if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 1);  // this wave is through its flux phase
   __syncthreads();  // every wave is done with the gradient rows: the region takes the var rows
@@ -1636,6 +1636,9 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
       return nt ? launch_split<false, true, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                 : launch_split<false, false, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     }
+    if ((gg_debug_flags & 0x80000) && kv <= 3 && a.rowlist && !push && !refmode)  // CFDP_EXP_SKIP_PRE (EXPERIMENTS.md D.2)
+      return nt ? launch(gg_fused_split_kernel<false, true, 5, 3, 3, 3, 3, true, false>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa)
+                : launch(gg_fused_split_kernel<false, false, 5, 3, 3, 3, 3, true, false>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa);
     // tiles of at most 192 staged rows (3 var pieces per thread): the 32-KiB capacity
     if (gg_fused_split >= 2 && kv <= 3) {
       if (refmode) return nt ? launch_preg_lp<true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)

@@ -61,6 +61,8 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
   cfdp_gpu *g = new cfdp_gpu();
   g->device = device;
   if (const char *e = cfdp_experiment_getenv("CFDP_DEBUG_ABLATE")) gg_debug_flags = atoi(e);  // honoured only with CFDP_EXPERIMENTS=1
+  if (const char *e = cfdp_experiment_getenv("CFDP_EXP_SKIP_PRE"))  // timing experiment, values WRONG (EXPERIMENTS.md D.2)
+    gg_debug_flags = (gg_debug_flags & ~0x80000) | (atoi(e) ? 0x80000 : 0);
   if (const char *e = getenv("CFDP_FUSED_SPLIT")) gg_fused_split = atoi(e);
   HIP_TRY(hipStreamCreateWithFlags(&g->s_main, hipStreamNonBlocking));
   {

@@ -10,7 +10,9 @@ forms = [f for f in os.environ.get("FORMS", "1,2,1,2").split(",") if f]
 for n in [int(a) for a in sys.argv[1:]] or [64, 128]:
     dom = m.gen_domain(m.gen_params(n, ndomains=1), 0); m.fill_var(dom, None, m.VAR_HASH)
     for form in forms:
-        os.environ["CFDP_FUSED_SPLIT"] = form
+        os.environ["CFDP_FUSED_SPLIT"] = "2" if form == "x" else form
+        os.environ["CFDP_EXPERIMENTS"] = "1" if form == "x" else "0"  # x: timing experiment, values wrong (EXPERIMENTS.md D.2)
+        os.environ["CFDP_EXP_SKIP_PRE"] = "1" if form == "x" else "0"
         part = m.GpuPartition(dom); part.set_fusion(True)
         it = 200 if n <= 64 else 60
         part.time_fused(4 * it)  # (the chip's clock settles)
