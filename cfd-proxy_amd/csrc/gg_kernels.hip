@@ -303,6 +303,22 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   // Slab image of a pass: [A1: 8 x 6][A2: 8 x 4][B: 8 x 11], the three runs it is stored as.
   constexpr int SPP = 8, NPASS = PPW / SPP;
   double *slab = stage + wave * (SPP * 21);
+  // where this lane's values go in the slab of the pass its point belongs to: the first ten doubles of a row in their stored
+  // ORDER (gg_a_encode, gg_kernels.h: raw double d -> slot, one nibble each) -- A1 [g0 g4 g8 | g1 g2 g5], A2 [g3 g6 g7 g9];
+  // the three sums are formed on the way out.  Computed once per lane, not per value and pass.
+  int sidx[NE][3];
+  {
+    const int lpp = (li - wp) & (SPP - 1);
+    const int a1 = lpp * 6, a2 = SPP * 6 + lpp * 4 - 6, bb = SPP * 10 + lpp * 11 - 10;
+#pragma unroll
+    for (int j = 0; j < NE; j++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const int d = (eq0 + j) * 3 + c;
+        const int slot = (int)((0x9287516430ull >> (4 * (d < 10 ? d : 0))) & 15ull);
+        sidx[j][c] = d >= 10 ? bb + d : (slot < 6 ? a1 : a2) + slot;
+      }
+  }
   // round 0 of a full pass: lanes 0..47 hold A1, slot k = lane % 6 of row lane / 6; slots 3..5 take A2's 0..2 on board
   const bool sum0 = lane < 48 && (unsigned)lane % 6u >= 3u;
   const int sidx0 = sum0 ? SPP * 6 + (lane / 6) * 4 + (lane % 6 - 3) : 0;
@@ -310,22 +326,11 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   for (int h = 0; h < NPASS; h++) {
     const int lp = li - wp - h * SPP;  // this lane's point within the pass
     if (active && lp >= 0 && lp < SPP) {
-      double *oa1 = slab + lp * 6, *oa2 = slab + SPP * 6 + lp * 4 - 6, *ob = slab + SPP * 10 + lp * 11 - 10;
 #pragma unroll
       for (int j = 0; j < NE; j++)
         if (eq0 + j < 7) {
 #pragma unroll
-          for (int c = 0; c < 3; c++) {
-            const int d = (eq0 + j) * 3 + c;
-            // the first ten doubles go into the slab in their stored ORDER (gg_a_encode, gg_kernels.h: raw double d ->
-            // slot, one nibble each): A1 [g0 g4 g8 | g1 g2 g5], A2 [g3 g6 g7 g9]; the three sums are formed on the way out
-            if (d < 10) {
-              const int slot = (int)((0x9287516430ull >> (4 * d)) & 15ull);
-              (slot < 6 ? oa1 : oa2)[slot] = acc[j][c] * tmp;
-            } else {
-              ob[d] = acc[j][c] * tmp;
-            }
-          }
+          for (int c = 0; c < 3; c++) slab[sidx[j][c]] = acc[j][c] * tmp;
         }
     }
     __builtin_amdgcn_wave_barrier();  // LDS executes a wave's accesses in order; keep the compiler in order too
