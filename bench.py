@@ -74,6 +74,17 @@ def usable_cores() -> int:
     return min(n, 64)
 
 
+def cpu_model() -> str:
+    """the host CPU as /proc/cpuinfo names it (SURVEY 8d asks for it beside the core count)"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def kernel_source_tag() -> str:
     """identifies the kernel build a committed PMC measurement belongs to"""
     h = hashlib.sha256()
@@ -190,7 +201,9 @@ def main() -> None:
     ap.add_argument("--no-loopback", action="store_true",
                     help="skip the loopback measurement of the exchange protocol's own cost (N = 1 only)")
     ap.add_argument("--no-weak", action="store_true", help="skip the extra weak-scaling measurement at --gpus 2 / 4")
-    ap.add_argument("--cpu-samples", type=int, default=7)
+    ap.add_argument("--cpu-samples", type=int, default=25,
+                    help="samples of 25 iterations each whose median is the CPU baseline: N_MEDIAN of the reference harness "
+                         "(src/solver.c:32); meshes larger than one level-2 mesh take at most 3")
     ap.add_argument("--transport", default="auto", choices=["auto", "ipc", "rccl", "torch", "staged"],
                     help="auto: set up ipc and rccl, time both briefly, keep the faster; ipc: xGMI write + notify "
                          "between the processes of a node (falls back to rccl if its check fails); rccl: "
@@ -664,7 +677,10 @@ def main() -> None:
             gsamples = sorted(ref.timed(part.var, niter=25, with_flux=False) for _ in range(3))
             ref.close()
             med = samples[len(samples) // 2]
-            port = {"value": 25.0 / med, "unit": "iterations/s", "cores": cores, "kind": "port",
+            host = {"cpu_model": cpu_model(), "threads": cores, "n_median": nsamp, "niter": 25,
+                    "protocol": "N_MEDIAN samples of NITER iterations each, the median sample (src/solver.c:32,40,298; src/hybrid.f6.c:72)"}
+            port = {"value": 25.0 / med, "unit": "iterations/s", "cores": cores, "kind": "port", **host,
+                    "thread_binding": "none (OMP_PROC_BIND unset)",
                     "sample": f"{mesh_what}, {nsamp} samples x 25 iterations "
                               f"(gradients+flux), median; oracle/cpu_ref.c OpenMP, threads not bound",
                     "gradient_only_iterations_per_s": 25.0 / gsamples[len(gsamples) // 2],
@@ -682,21 +698,25 @@ def main() -> None:
                         orc.write_raw_domain(raw, 0, part.fpoint, part.fnormal, part.pvolume, part.nown, var=part.var)
                         # the reference spin-waits between its threads: where they are pinned matters on a box
                         # that grants a share of a bigger host, so both placements are timed and the faster kept
-                        for bind in ("false", "true"):
+                        def ref_rate(bind, samples, wf):
                             env = dict(os.environ, OMP_NUM_THREADS=str(cores), OMP_PROC_BIND=bind)
-                            for wf in (1, 0):
-                                r = subprocess.run([ref_bin, "time", raw, str(nsamp), str(wf)],
-                                                   env=env, capture_output=True, text=True, timeout=300)
-                                m = re.search(r"median_s=([0-9.]+)", r.stdout)
-                                if r.returncode == 0 and m:
-                                    v = 25.0 / float(m.group(1))
-                                    if wf and (best is None or v > best["value"]):
-                                        best = {"value": v, "omp_proc_bind": bind}
-                                    elif not wf and best is not None and best["omp_proc_bind"] == bind:
-                                        best["gradient_only_iterations_per_s"] = v
+                            r = subprocess.run([ref_bin, "time", raw, str(samples), str(wf)],
+                                               env=env, capture_output=True, text=True, timeout=300)
+                            m = re.search(r"median_s=([0-9.]+)", r.stdout)
+                            return 25.0 / float(m.group(1)) if r.returncode == 0 and m else None
+                        quick = {b: ref_rate(b, min(nsamp, 5), 1) for b in ("false", "true")}  # which placement is faster here
+                        quick = {b: v for b, v in quick.items() if v}
+                        if quick:
+                            bind = max(quick, key=quick.get)
+                            v = ref_rate(bind, nsamp, 1)  # ... and THAT one by the reference's own protocol
+                            if v:
+                                best = {"value": v, "omp_proc_bind": bind,
+                                        "gradient_only_iterations_per_s": ref_rate(bind, min(nsamp, 5), 0)}
                     if best:
                         out["cpu_baseline"] = {
-                            "value": best["value"], "unit": "iterations/s", "cores": cores, "kind": "reference",
+                            "value": best["value"], "unit": "iterations/s", "cores": cores, "kind": "reference", **host,
+                            "thread_binding": f"OMP_PROC_BIND={best['omp_proc_bind']}, OMP_NUM_THREADS={cores} (the faster of "
+                                              f"false / true on this host, picked from 5 samples each)",
                             "sample": f"compiled reference (oracle/_ref/ref_dump_raw: src/solver.c:42-58 comm_free loop + "
                                       f"compute_psd_flux), {mesh_what}{'' if cpu_dom else ' as one domain'}, {nsamp} samples x 25 "
                                       f"iterations, median; OMP_PROC_BIND={best['omp_proc_bind']} (faster of false/true)",

@@ -33,13 +33,20 @@ using cfdp_detail::fail;
 // streams are non-blocking (no implicit order with the null stream), so work enqueued on them right afterwards may run
 // first -- and a late memset / copy then lands on top of live data.  (Found as a once-in-dozens failure on a fresh box,
 // where the first use of the copy engine is slow: DESIGN appendix C.5.)  These forms wait.
+// (CFDP_EXP_ASYNC_SETUP_COPIES=1, an experiment switch: WITHOUT the wait -- the defect itself, kept so that
+// test_setup_copies_are_complete_before_the_first_kernel has something to fail on)
+static inline bool cfdp_setup_copies_wait() {
+  static const bool wait = !(cfdp_experiment_getenv("CFDP_EXP_ASYNC_SETUP_COPIES") && atoi(cfdp_experiment_getenv("CFDP_EXP_ASYNC_SETUP_COPIES")));
+  return wait;
+}
 static inline hipError_t cfdp_memset_sync(void *p, int v, size_t n) {
-  const hipError_t e = hipMemset(p, v, n);
-  return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+  const hipError_t e = cfdp_setup_copies_wait() ? hipMemset(p, v, n) : hipMemsetAsync(p, v, n, nullptr);
+  return e != hipSuccess || !cfdp_setup_copies_wait() ? e : hipStreamSynchronize(nullptr);
 }
 static inline hipError_t cfdp_copy_d2d_sync(void *dst, const void *src, size_t n) {
-  const hipError_t e = hipMemcpy(dst, src, n, hipMemcpyDeviceToDevice);
-  return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+  const hipError_t e = cfdp_setup_copies_wait() ? hipMemcpy(dst, src, n, hipMemcpyDeviceToDevice)
+                                                : hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, nullptr);
+  return e != hipSuccess || !cfdp_setup_copies_wait() ? e : hipStreamSynchronize(nullptr);
 }
 
 #define NEED_UPLOAD(g)                                                 \

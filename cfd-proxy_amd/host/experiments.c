@@ -21,6 +21,7 @@ static const char *const g_switches[] = {
     "CFDP_IPC_JITTER_US",     /* csrc/gpu_exchange.hip: random idle time in front of every step (tests) */
     "CFDP_PLAN_FAIL_STAGE",   /* csrc/plan_kernels.hip: a device plan stage fails on purpose (tests) */
     "CFDP_EXP_SKIP_PRE",      /* csrc/gpu_abi.hip: the fused pass without its pass over the staged rows (EXPERIMENTS.md D.2) -- values WRONG */
+    "CFDP_EXP_ASYNC_SETUP_COPIES", /* csrc/gpu_ctx.h: set-up memsets / copies do NOT wait (the defect of DESIGN C.5, for its regression test) */
 };
 enum { NSWITCH = sizeof g_switches / sizeof g_switches[0] };
 static int g_said[NSWITCH];

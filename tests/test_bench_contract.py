@@ -30,6 +30,7 @@ def test_bench_line(gpu):
     assert out["config"]["baseline_config"] == "dualgrid.12" and out["scaling"] == "strong"
     cb = out["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+    assert cb["cpu_model"] and cb["threads"] == cb["cores"] and cb["n_median"] == 1 and cb["niter"] == 25 and cb["thread_binding"], cb
     if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_dump_raw")):
         assert cb["kind"] == "reference" and cb["port"]["kind"] == "port", cb
     assert out["value"] > 0 and out["ms_per_step"] > 0

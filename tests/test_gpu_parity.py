@@ -614,6 +614,39 @@ def test_scaled_field_mode_counts_exactly_what_is_wrong(gpu, fusion, flux_mode):
     dom.free()
 
 
+def test_setup_copies_are_complete_before_the_first_kernel(gpu):
+    """regression test of round 4's one unexplained failure (DESIGN appendix C.5): hipMemset and device-to-device hipMemcpy
+    run on the null stream and return before the bytes are there; the context's streams are non-blocking, so work
+    enqueued right behind them could run first.  cfdp_gpu_scaled_check_begin copies the flux it holds as the reference
+    and var as the restore point; here the steps that overwrite both are enqueued straight behind it, on a mesh whose
+    copies take tens of microseconds (96^3: 57 MB of var, 21 MB of flux).  A reference taken late is the flux of a later
+    iteration -- every value of every step mismatches.  Control: with the waits switched off (CFDP_EXP_ASYNC_SETUP_COPIES=1,
+    an experiment switch) the same flow is run in a child process; whether the race then shows depends on the copy
+    engine's latency at that moment, so the control only has to run -- when it does show, that is printed"""
+    import subprocess
+    import sys
+    code = ("import sys, os; sys.path.insert(0, %r)\n"
+            "from __graft_entry__ import load_package\n"
+            "p = load_package(); d = p.gen_domain(p.gen_params(96, ndomains=1), 0); p.fill_var(d, None, p.VAR_HASH)\n"
+            "bad = 0\n"
+            "for rep in range(4):\n"
+            "    g = p.GpuPartition(d); g.set_fusion(True)\n"
+            "    g.step_pre(False, False); g.step_post(True, 0); g.sync()\n"
+            "    g.scaled_check_begin()\n"
+            "    for _ in range(4):\n"
+            "        g.step_pre(False, False); g.step_post(True, 0)\n"
+            "    ev = g.scaled_check_end(); bad += ev['mismatches'] + ev['var_mismatches']; g.close()\n"
+            "print('MISMATCHES', bad)\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("CFDP_")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "MISMATCHES 0" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+    c = subprocess.run([sys.executable, "-c", code], env=dict(env, CFDP_EXPERIMENTS="1", CFDP_EXP_ASYNC_SETUP_COPIES="1"),
+                       capture_output=True, text=True, timeout=600)
+    line = [l for l in c.stdout.splitlines() if l.startswith("MISMATCHES")]
+    print("control (waits off):", line[-1] if line else c.stderr[-300:])
+    assert c.returncode == 0 and line, c.stdout[-800:] + c.stderr[-800:]
+
+
 @pytest.mark.parametrize("name,world,steady_min,k20_min", [("dualgrid.48", 4, 0.93, 0.92), ("dualgrid.192", 8, 0.88, 0.86)])
 def test_exchange_protocol_overhead_in_loopback(gpu, name, world, steady_min, k20_min):
     """what the write + notify protocol itself costs per iteration when no partner is ever late: rank 0 of the 4-rank
