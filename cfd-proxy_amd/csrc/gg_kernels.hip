@@ -1638,6 +1638,12 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
     }
     if (gg_debug_flags & GG_DBG_MOVE) {  // data movement only (cfdp_gpu_time_fused_movement): results are zeros
       if (!a.rowlist) return hipErrorNotSupported;
+      if (gg_fused_split >= 2 && kv <= 3) {  // (at the capacity the real pass of these tiles runs at)
+#define MOVE_SMALL(N) launch(gg_fused_split_kernel<false, N, 5, 3, 3, 3, 2, true, false>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, \
+                             a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa)
+        return nt ? MOVE_SMALL(true) : MOVE_SMALL(false);
+#undef MOVE_SMALL
+      }
       return nt ? launch_split<false, true, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                 : launch_split<false, false, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     }
