@@ -71,11 +71,18 @@ int  cfdp_plan_build_gpu(const solver_data *sd, const comm_data *cd, const cfdp_
 int  cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *plan);
 /* optional: use caller-owned device memory (16-byte aligned) for grad [nall*21 doubles] / the
  * send arena [nsend*21 doubles] (e.g. buffers registered with a communication library).
- * Device layout of grad: an owned row's 21 doubles are split into part A (doubles 0..9, read
- * by the flux loop) and part B (doubles 10..20); ghost rows stay whole, in message order:
- *   [A: nown x 10][ghost rows: (nall-nown) x 21][B: nown x 11]
- * cfdp_gpu_recv_ptr() points into the ghost block; cfdp_gpu_get_grad/_set_grad convert from
- * and to the reference's grad[nall][7][3] in file numbering.                               */
+ * Device layout of grad (csrc/gg_kernels.h has the full statement): with g0..g8 the row-major 3x3
+ * velocity-gradient block of a row and g9 its tenth double, a row is kept -- on the device and on the
+ * wire alike -- as  [ g0 g4 g8 g1+g3 g2+g6 g5+g7 | g3 g6 g7 g9 | doubles 10..20 ]  =  [ A1 | A2 | B ]:
+ * the first 48 bytes are all the flux loop reads.  Owned rows are split, ghost rows stay whole (168
+ * bytes, message order):
+ *   [A1: nown x 6][ghost rows: (nall-nown) x 21][A2: nown x 4][B: nown x 11]
+ * cfdp_gpu_recv_ptr() points into the ghost block, cfdp_gpu_send_ptr() into the send arena: whole rows
+ * in that stored form -- a transport moves them as opaque bytes.  cfdp_gpu_get_grad/_set_grad convert
+ * from and to the reference's grad[nall][7][3] in file numbering; the three upper off-diagonals of the
+ * block come back as (g1+g3)-g3, (g2+g6)-g6, (g5+g7)-g7: within one rounding of the pair's sum (1e-16 of
+ * the scale the 1e-10 tolerance is written against), the same value wherever a row is seen.  (A row
+ * taken off the device and put back keeps its sums to within one more rounding.)                     */
 int  cfdp_gpu_bind_grad(cfdp_gpu *g, void *dev_grad);
 int  cfdp_gpu_bind_sendbuf(cfdp_gpu *g, void *dev_sendbuf);
 

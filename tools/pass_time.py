@@ -13,13 +13,13 @@ for n in [int(a) for a in sys.argv[1:]] or [64, 128]:
         os.environ["CFDP_FUSED_SPLIT"] = "2" if form == "x" else form
         os.environ["CFDP_EXPERIMENTS"] = "1" if form == "x" else "0"  # x: timing experiment, values wrong (EXPERIMENTS.md D.2)
         os.environ["CFDP_EXP_SKIP_PRE"] = "1" if form == "x" else "0"
-        part = m.GpuPartition(dom); part.set_fusion(True)
+        part = m.GpuPartition(dom, tile_points=int(os.environ.get("TP", "0"))); part.set_fusion(True)
         it = 200 if n <= 64 else 60
         part.time_fused(4 * it)  # (the chip's clock settles)
         ts = sorted(part.time_fused(it) for _ in range(7))
         mv = min(part.time_fused_movement(it) for _ in range(3))
         tg, tf = part.time_kernels(it, m.FLUX_CONSISTENT)
-        print(f"n {n} form {form}: fused pass {ts[0]*1e3:.2f} / {ts[3]*1e3:.2f} / {ts[6]*1e3:.2f} us; movement floor {mv*1e3:.2f} us; "
+        print(f"n {n} form {form} tiles {part.stats['ntiles']} x <= {part.stats['tile_points']} points: fused pass {ts[0]*1e3:.2f} / {ts[3]*1e3:.2f} / {ts[6]*1e3:.2f} us; movement floor {mv*1e3:.2f} us; "
               f"gradient kernel {tg*1e3:.2f} us, flux kernel {tf*1e3:.2f} us", flush=True)
         part.close()
     dom.free()
