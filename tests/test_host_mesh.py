@@ -354,3 +354,27 @@ def test_host_stages_do_not_depend_on_the_thread_count(pkg):
         assert r.returncode == 0, r.stdout + r.stderr
         seen.add([l for l in r.stdout.splitlines() if l.startswith("PLAN")][-1])
     assert len(seen) == 1, seen
+
+
+def test_stored_form_of_gradient_rows(pkg):
+    """the two maps between a gradient row as the reference has it and as the device keeps and sends it (csrc/gg_kernels.h:
+    gg_a_encode / gg_a_decode; numpy statements in the package): the first six stored doubles are the diagonal and the
+    three symmetric sums of the velocity-gradient block -- exactly the operands of the stress formula, src/flux.c:139-173 --
+    and a row comes back with 18 of its 21 doubles untouched and the three upper off-diagonals within one rounding of the
+    pair's sum"""
+    rng = np.random.default_rng(3)
+    rows = rng.standard_normal((1000, 7, 3)) * 10.0 ** rng.integers(-6, 7, size=(1000, 1, 1))
+    e = pkg.stored_rows(rows)
+    g = rows.reshape(-1, 21)
+    assert np.array_equal(e[:, :3], g[:, [0, 4, 8]])                      # dvx_dx, dvy_dy, dvz_dz
+    assert np.array_equal(e[:, 3:6], g[:, [1, 2, 5]] + g[:, [3, 6, 7]])  # dvx_dy + dvy_dx, dvx_dz + dvz_dx, dvy_dz + dvz_dy
+    assert np.array_equal(e[:, 6:10], g[:, [3, 6, 7, 9]]) and np.array_equal(e[:, 10:], g[:, 10:])
+    back = pkg.handed_out_rows(e)
+    same = [c for c in range(21) if c not in (1, 2, 5)]
+    assert np.array_equal(back[:, same], g[:, same])
+    ulp = np.spacing(np.abs(e[:, 3:6]))
+    assert np.all(np.abs(back[:, [1, 2, 5]] - g[:, [1, 2, 5]]) <= ulp)    # one rounding of the sum, nothing more
+    # ... and what is handed out is a fixed point of the two maps as far as the flux is concerned: re-stored, the six
+    # numbers the stress reads are within one more rounding
+    again = pkg.stored_rows(back)
+    assert np.array_equal(again[:, :3], e[:, :3]) and np.all(np.abs(again[:, 3:6] - e[:, 3:6]) <= ulp)
