@@ -1633,6 +1633,12 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
   if (gg_fused_split && allow_split && cb <= 5 && kv <= 4 && kg <= 3) {
     if (gg_debug_flags & GG_DBG_STAMP) {  // diagnostic build of the same kernel: phase stamps (tools/phase_stamps.py)
       if (!a.rowlist) return hipErrorNotSupported;  // the stamped instantiation reads the fixed-stride row lists
+      if (gg_fused_split >= 2 && kv <= 3) {  // (at the capacity the real pass of these tiles runs at)
+#define STAMP_SMALL(N) launch(gg_fused_split_kernel<false, N, 5, 3, 3, 3, 1, true, true>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, \
+                              a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa)
+        return nt ? STAMP_SMALL(true) : STAMP_SMALL(false);
+#undef STAMP_SMALL
+      }
       return nt ? launch_split<false, true, 1, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                 : launch_split<false, false, 1, true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     }
