@@ -146,6 +146,7 @@ hipError_t gg_launch_push(const int *send_idx, int nsend, const int *slot_of_row
 hipError_t gg_launch_notify(int *hdr, int *const *remote_flag, int nslots, const int *need, int *tile_iter, int nbtiles, hipStream_t stream);
 // tile_iter != nullptr: counter notification (wait for counter >= NEED_IN of the slot x tile_iter[0])
 hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, const int *tile_iter, hipStream_t stream);
+hipError_t gg_launch_poke(int *const *dst, const int *words, int offset, int n, hipStream_t stream);  // *(dst[i] + offset) = words[i], n <= 64
 hipError_t gg_launch_jitter(unsigned *rng, int max_us, hipStream_t stream);  // tests: a pseudo-random idle time in front of a step
 // scaled-field validation of an exchange (gg_validate_kernel): words of its device-side state block (16 ints, 8-byte
 // aligned): gradient launches so far, flux fields compared, mismatching values (64 bit), first mismatch (claimed,

@@ -719,8 +719,8 @@ __device__ __forceinline__ void glds16_nt(const uint4 *src, unsigned char *lds_w
 // ---------------------------------------------------------------------------------- flux
 // LPP lanes share a point and split its incidence list; partial sums are combined with
 // wave shuffles in a fixed order (deterministic).
-// The per-tile flux arithmetic.  `smem` holds the tile blob, `g_l` the 3x3 velocity-gradient
-// blocks of own + halo points, 10 doubles (80 bytes) per row.
+// The per-tile flux arithmetic.  `smem` holds the tile blob, `g_l` the rows of own + halo points, GS doubles
+// apart, each starting with the six numbers of its velocity-gradient block the stress needs (A1, gg_kernels.h).
 //
 // The viscous stress is linear in the velocity gradient, and the face value is the mean of the
 // two ends (src/flux.c:139-173): flux = -stress(0.5*(g0+g1)).n = (P(g0) + P(g1)).n with
@@ -937,11 +937,11 @@ __global__ __launch_bounds__(1024) void gg_flux_dma_kernel(
 // flux(i) and gradients(i+1) of a tile in ONE pass: both face loops read the same tile blob
 // (normals + incidence lists = more than half of either kernel's HBM traffic), so a run of
 // iterations streams it once per iteration instead of twice.  grad is double-buffered: the flux
-// phase reads part A / the ghost block of the buffer iteration i wrote (its halo exchange has
+// phase reads A1 / the ghost block of the buffer iteration i wrote (its halo exchange has
 // completed), the gradient phase writes the other buffer.  The results are those of the two
 // separate kernels, bit for bit (same per-tile arithmetic, flux_tile_compute /
 // grad_tile_compute).  4 lanes per point in both phases; fixed-count LDS-DMA staging as above:
-// LDS image [blob: CB][var rows: KV][gradient rows (80 bytes each): KG] x nthr x 16 bytes; the
+// LDS image [blob: CB][var rows: KV][gradient rows (their first 48 bytes each): KG] x nthr x 16 bytes; the
 // store slab of the gradient phase reuses the gradient-row region once the flux phase is done.
 template <bool REFMODE, bool NT, int CB, int KV, int KG>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
@@ -1391,6 +1391,18 @@ __global__ void gg_jitter_kernel(unsigned *__restrict__ rng, int max_us) {
   const long long ticks = (long long)(x % (unsigned)(max_us > 0 ? max_us : 1)) * 100;  // s_memrealtime: 100 MHz
   const unsigned long long start = __builtin_amdgcn_s_memrealtime();
   while ((long long)(__builtin_amdgcn_s_memrealtime() - start) < ticks) __builtin_amdgcn_s_sleep(16);
+}
+// set-up: words[i] -> *dst[i] with system-scope stores -- how a rank tells its partners something once (how many of its
+// boundary tiles count per exchange): the same kind of store, to the same mappings, as the exchange itself relies on
+// (a host-side copy into another device's IPC-mapped memory is one more thing a machine could refuse)
+__global__ void gg_poke_kernel(int *const *__restrict__ dst, const int *__restrict__ words, int offset, int n) {
+  const int i = threadIdx.x;
+  if (i < n) __hip_atomic_store(dst[i] + offset, words[i], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t gg_launch_poke(int *const *dst, const int *words, int offset, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gg_poke_kernel, dim3(1), dim3(64), 0, stream, dst, words, offset, n);
+  return hipGetLastError();
 }
 hipError_t gg_launch_jitter(unsigned *rng, int max_us, hipStream_t stream) {
   hipLaunchKernelGGL(gg_jitter_kernel, dim3(1), dim3(1), 0, stream, rng, max_us);

@@ -640,8 +640,9 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       // NEED_IN + (this rank's slot there) of ITS header, next to the counter word itself.  Written once, here; read by the
       // partner's waits from its first exchanging step on -- the hosts meet between _ready and that step (every set-up in
       // this repo validates collectively first; cfdproxy_hip.h says so for other hosts)
-      for (int s2 = 0; s2 < nslots; s2++)
-        HIP_TRY(hipMemcpy(I.rflag[(size_t)s2] + GG_IPC_NEED_IN, &need[(size_t)s2], sizeof(int), hipMemcpyHostToDevice));
+      // (written from THIS device with system-scope stores, like every push: d_rflag / d_need are uploaded above)
+      HIP_TRY(gg_launch_poke(I.d_rflag, I.d_need, GG_IPC_NEED_IN, nslots, g->s_main));
+      HIP_TRY(hipStreamSynchronize(g->s_main));
       HIP_TRY(hipMalloc(&I.d_tile_mask, sizeof(unsigned long long) * (smask.size() + 1)));
       if (!smask.empty())
         HIP_TRY(hipMemcpy(I.d_tile_mask, smask.data(), sizeof(unsigned long long) * smask.size(), hipMemcpyHostToDevice));
