@@ -679,9 +679,7 @@ __device__ __forceinline__ void dma_stage_tile(unsigned char *buf, const cfdp_ti
   }
 }
 
-// ALIAS: the store slab lies on the var-row region (behind a barrier: every wave is through its incidence loop) instead of
-// behind it -- a 64-point tile then occupies 32 KiB instead of 37, five workgroups per CU
-template <int LPP, bool NT, int CB, int KV, bool ALIAS = false>
+template <int LPP, bool NT, int CB, int KV>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LPP == 8 ? GG_WAVES_EU : LPP == 4 ? 4 : 2)))
 void gg_gradient_dma_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
@@ -694,8 +692,8 @@ void gg_gradient_dma_kernel(
   dma_stage_tile<NT, CB, KV>(smem, td, blob, reinterpret_cast<const uint4 *>(var), halo_idx, tid, nthr);
   __syncthreads();  // vmcnt(0) + barrier: every wave's pieces have landed
   const int var_off = CB * nthr * 16;
-  double *stage = reinterpret_cast<double *>(smem + (size_t)(ALIAS ? CB : CB + KV) * nthr * 16);
-  grad_tile_compute<LPP, NT, ALIAS>(smem, td, tid, gout, stage, dbg, var_off);
+  double *stage = reinterpret_cast<double *>(smem + (size_t)(CB + KV) * nthr * 16);
+  grad_tile_compute<LPP, NT>(smem, td, tid, gout, stage, dbg, var_off);
 }
 
 // LDS-DMA: global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs, asynchronous (vmcnt)
@@ -1480,11 +1478,6 @@ template <int L> hipError_t launch_grad_generic(const gg_args &a, bool nt, int t
 
 template <int CB, int KV> hipError_t launch_grad_dma(const gg_args &a, bool nt, int tile_begin, int ntiles, int block,
                                                      size_t stage_bytes, hipStream_t stream) {
-  if (CB == 5 && KV == 3 && gg_fused_split >= 2 && stage_bytes <= (size_t)KV * block * 16) {  // the slab on the var rows: 32 KiB
-    const size_t lds32 = (size_t)(CB + KV) * block * 16;
-    if (nt) return launch(gg_gradient_dma_kernel<4, true, CB, KV, true>, ntiles, block, lds32, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags);
-    return launch(gg_gradient_dma_kernel<4, false, CB, KV, true>, ntiles, block, lds32, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags);
-  }
   const size_t lds = (size_t)(CB + KV) * block * 16 + stage_bytes;
   if (nt) return launch(gg_gradient_dma_kernel<4, true, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags);
   return launch(gg_gradient_dma_kernel<4, false, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags);
