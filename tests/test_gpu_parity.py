@@ -1231,3 +1231,26 @@ def test_unstructured_delaunay_mesh_partitioned_with_halo_exchange(gpu, orc, nd)
             gp_.close()
     for dom in doms:
         dom.free()
+
+
+def test_exchange_setup_helpers(gpu):
+    """the small things a host builds an exchange from: the PCI bus id ranks compare to find out whether they share a
+    device, the header geometry hosts must not hard-code (a cache line per partner slot), and the per-context configuration
+    that replaced the environment as the way to pick a rung"""
+    import re
+    pkg = gpu
+    bus = pkg.device_bus_id(0)
+    assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F]", bus), bus
+    lib = pkg.hip_lib()
+    assert lib.cfdp_gpu_ipc_header_bytes() == 8192 and lib.cfdp_gpu_ipc_flag_offset(0) == 0 and lib.cfdp_gpu_ipc_flag_offset(5) == 5 * 128
+    assert 48 * 128 + 6 * 4 <= lib.cfdp_gpu_ipc_header_bytes()  # 48 slot lines + the rank's own words
+    d = pkg.gen_domain(pkg.gen_params(8, 8, 8, ndomains=1), 0)
+    g = pkg.GpuPartition(d)
+    assert lib.cfdp_gpu_device(g.h) == 0 and g.rccl_nranks() == 0
+    g.ipc_configure(memory_mode="split", wait_inkernel=False, notify="flag", push_inkernel=False)
+    g.ipc_configure()  # back to "what the environment says"
+    for bad in ((3, -1, -1, -1), (-1, 2, -1, -1), (-1, -1, 2, -1), (-1, -1, -1, -2)):
+        assert lib.cfdp_gpu_ipc_configure(g.h, *bad) != 0 and b"out of range" in lib.cfdp_gpu_last_error()
+    assert g.ipc_graph_stats() == {"steps_replayed": 0, "steps_streamed": 0, "captures_failed": 0}
+    g.close()
+    d.free()
