@@ -152,13 +152,15 @@ __device__ __forceinline__ void grad_batch(const uint32_t *__restrict__ inc, int
   }
 #pragma unroll
   for (int i = 0; i < U; i++) {
-    // val = 0.5*(var[p0][eq] + var[p1][eq]) (src/gradients.c:77,99,121); the owned end being
-    // p1 means the contribution is subtracted (:103-105,128-130): folded into the exact
-    // factor +-0.5 (bit 31 of the incidence word is the sign bit of the double)
-    const double sg = __hiloint2double((int)(0x3FE00000u | (w[i] & 0x80000000u)), 0);
+    // val = 0.5*(var[p0][eq] + var[p1][eq]) (src/gradients.c:77,99,121); the owned end being p1 means the contribution
+    // is subtracted (:103-105,128-130).  Neither costs a multiply: the sign goes onto the sum as bit 31 of the incidence
+    // word (= the sign bit of a double), and the 0.5 -- a power of two, it commutes with every rounding -- is applied
+    // once, with 1/pvolume, to the finished sums (grad_tile_compute).  Bit for bit the sums of the factor +-0.5 per face.
+    const int sgn = (int)(w[i] & 0x80000000u);
 #pragma unroll
     for (int j = 0; j < NE; j++) {
-      const double val = sg * (vs[j] + vn[i][j]);
+      const double sum = vs[j] + vn[i][j];
+      const double val = __hiloint2double(__double2hiint(sum) ^ sgn, __double2loint(sum));
       acc[j][0] += n0[i] * val;
       acc[j][1] += n1[i] * val;
       acc[j][2] += n2[i] * val;
@@ -272,7 +274,7 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
       k += 2;
     }
     if (k < ke) grad_batch<1, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
-    tmp = 1.0 / var_l[li * 8 + 7];  // 1/pvolume, src/gradients.c:138
+    tmp = 0.5 / var_l[li * 8 + 7];  // 1/pvolume, src/gradients.c:138, and the face value's 0.5 (grad_batch)
   }
   // this point's row goes to a partner: out of the registers, now (before the tile's own stores: the acknowledgement of a
   // remote store takes longest).  A point without faces is pushed by nobody (such partitions keep the push kernel)
