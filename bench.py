@@ -93,6 +93,46 @@ def kernel_source_tag() -> str:
     return h.hexdigest()[:16]
 
 
+def power_beside(run_chunk, seconds: float = 1.6) -> dict:
+    """socket power and shader clock (rocm-smi, a child process polled from a thread) while run_chunk() -- a few
+    hundred back-to-back launches of one kernel, synchronised -- repeats for `seconds`: the face loops of this path
+    run the socket at its power cap and the governor answers with the shader clock (tools/power_watch.py),
+    so a roofline figure without the two is half the story.  None-valued when rocm-smi is not there or cannot be
+    read as an ordinary user."""
+    import re, statistics, subprocess, threading
+    def smi(*flags):
+        return subprocess.run(["rocm-smi", *flags], capture_output=True, text=True, timeout=15).stdout
+    def sample():
+        out = smi("--showclocks", "--showpower", "--csv").strip().splitlines()
+        d = dict(zip(out[0].split(","), out[1].split(",")))
+        return (int(re.sub(r"\D", "", d["sclk clock speed:"])), float([v for k, v in d.items() if "Power" in k][0]))
+    try:
+        cap = re.search(r"Max Graphics Package Power \(W\): *([0-9.]+)", smi("--showmaxpower"))
+        seen, stop, errs = [], [], []
+        def watch():
+            while not stop:
+                try:
+                    seen.append(sample())
+                except Exception as e:
+                    errs.append(repr(e)[:80]); return
+                time.sleep(0.05)
+        th = threading.Thread(target=watch)
+        t0 = time.time()
+        run_chunk()  # (the power ramps over the first tenths of a second: what is kept starts behind them)
+        th.start()
+        while time.time() - t0 < seconds:
+            run_chunk()
+        stop.append(1)
+        th.join()
+        if not seen:
+            return {"socket_power_w": None, "note": (errs or ["no sample"])[0]}
+        return {"socket_power_w": statistics.median(p for _, p in seen), "socket_power_max_w": max(p for _, p in seen),
+                "shader_clock_mhz": statistics.median(c for c, _ in seen), "power_cap_w": float(cap.group(1)) if cap else None,
+                "samples": len(seen), "how": f"rocm-smi polled while the kernel ran back to back for {seconds} s"}
+    except Exception as e:
+        return {"socket_power_w": None, "note": repr(e)[:120]}
+
+
 def committed_traffic(workload_key: str):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes
     with the gfx950 corrections of MI355X_MICROARCH.md: tools/measure_traffic.py).  PMC passes cannot run
@@ -197,6 +237,7 @@ def main() -> None:
                     help="one kernel per face loop instead of the fused flux(i)+gradients(i+1) pass")
     ap.add_argument("--no-files", action="store_true", help="generate domains in memory (skip the loader)")
     ap.add_argument("--no-finest", action="store_true", help="skip the finest-level single-GPU roofline run")
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock samples of the roofline blocks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--no-loopback", action="store_true",
                     help="skip the loopback measurement of the exchange protocol's own cost (N = 1 only)")
@@ -500,6 +541,8 @@ def main() -> None:
         except Exception as e:
             out["roofline"]["movement_only_us"] = None
             out["roofline"]["movement_only_note"] = str(e)[:160]
+        if world == 1 and not args.no_power:
+            out["roofline"]["power"] = power_beside(lambda: solver.gpu.time_fused(2000))
     out["roofline"]["traffic_source"] = traffic_src
     t_phase = lap("roofline block", t_phase)
 
@@ -560,6 +603,8 @@ def main() -> None:
                     fl["fused"]["exposed_beyond_movement_us"] = (fu1 - mv1) * 1e3
                 except Exception as e:
                     fl["fused"]["movement_only_us"] = None
+                if not args.no_power:
+                    fl["fused"]["power"] = power_beside(lambda: p1.time_fused(300))
             out["finest_level"] = fl
             p1.close()
             d1.free()

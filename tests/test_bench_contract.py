@@ -27,6 +27,10 @@ def test_bench_line(gpu):
     assert 0 < rf["frac_unique"] < rf["frac"] and rf["unique_bytes_per_launch"] < rf["algorithmic_bytes_per_launch"]
     assert 0 < rf["movement_only_us"] < rf["us_per_launch"]  # the pass without its face loops: the data-movement floor
     assert "traffic_source" in rf and (rf["traffic"] is None or rf["traffic_source"]["file"].startswith("profiles/"))
+    # socket power and shader clock beside the dominant kernel (rocm-smi; the face loops run at the power cap: DESIGN 8)
+    pw = rf["power"]
+    assert "socket_power_w" in pw and (pw["socket_power_w"] is None and pw.get("note")
+                                       or 200 < pw["socket_power_w"] <= 1.1 * (pw["power_cap_w"] or 1400) and 400 < pw["shader_clock_mhz"] <= 2500), pw
     assert out["config"]["baseline_config"] == "dualgrid.12" and out["scaling"] == "strong"
     cb = out["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
