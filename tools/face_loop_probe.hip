@@ -19,7 +19,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
+#include <string>
+#include <thread>
+#include <atomic>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -66,19 +70,77 @@ __global__ __launch_bounds__(256) void loop_points(const image_p *img, double *o
     for (int j = 0; j < NNB; j++) {
       const int e = t->pface[p * NNB + j], q = t->prow[p * NNB + j];
       const int f = e & 1023;
-      const double sg = (e >> 15) ? -0.5 : 0.5;
+      const int sgn = (e >> 15) << 31;  // the sign rides on the sum (xor), the 0.5 is applied once at the end
       const double2 w = *reinterpret_cast<const double2 *>(&t->g.var[q][2 * sub]);
       const double n0 = t->g.nrm[f][0], n1 = t->g.nrm[f][1], n2 = t->g.nrm[f][2];
-      const double a0 = (v.x + w.x) * sg, a1 = (v.y + w.y) * sg;
+      const double b0 = v.x + w.x, b1 = v.y + w.y;
+      const double a0 = __hiloint2double(__double2hiint(b0) ^ sgn, __double2loint(b0));
+      const double a1 = __hiloint2double(__double2hiint(b1) ^ sgn, __double2loint(b1));
       a[0] += a0 * n0; a[1] += a0 * n1; a[2] += a0 * n2;
       a[3] += a1 * n0; a[4] += a1 * n1; a[5] += a1 * n2;
     }
 #pragma unroll
-    for (int c = 0; c < 6; c++) acc[c] += a[c];
+    for (int c = 0; c < 6; c++) acc[c] += 0.5 * a[c];
   }
   if (blockIdx.x == 0)
     for (int c = 0; c < 6; c++) out[(p * 4 + sub) * 6 + c] = acc[c] / iters;
   else if (acc[0] == 1.2345e300) out[0] = acc[1];
+}
+
+// S<LPP>: the point's INCIDENCES split over LPP lanes, every lane all eight slots of a row (7 equations + the volume's
+// slot, as the product's row): the word and the normal are read once per incidence instead of once per lane of the point,
+// and the sums of the lanes meet in xor-shuffles at the end (24 values, log2(LPP) steps).  Lanes >= 64 * LPP idle.
+template <int LPP>
+__global__ __launch_bounds__(256) void loop_points_split(const image_p *img, double *out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, p = tid / LPP, sub = tid % LPP;
+  copy_in(smem, img, tid);
+  const image_p *t = reinterpret_cast<const image_p *>(smem);
+  const bool active = p < NPT;
+  double keep[24];
+#pragma unroll
+  for (int c = 0; c < 24; c++) keep[c] = 0.0;
+  for (int it = 0; it < iters; it++) {
+    asm volatile("" ::: "memory");
+    double a[8][3];
+#pragma unroll
+    for (int e = 0; e < 8; e++) a[e][0] = a[e][1] = a[e][2] = 0.0;
+    if (active) {
+      double v[8];
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const double2 x = *reinterpret_cast<const double2 *>(&t->g.var[p][e]);
+        v[e] = x.x; v[e + 1] = x.y;
+      }
+#pragma unroll 2
+      for (int j = sub; j < NNB; j += LPP) {
+        const int e = t->pface[p * NNB + j], q = t->prow[p * NNB + j];
+        const int f = e & 1023, sgn = (e >> 15) << 31;
+        const double n0 = t->g.nrm[f][0], n1 = t->g.nrm[f][1], n2 = t->g.nrm[f][2];
+#pragma unroll
+        for (int h = 0; h < 8; h += 2) {
+          const double2 w = *reinterpret_cast<const double2 *>(&t->g.var[q][h]);
+          const double b0 = v[h] + w.x, b1 = v[h + 1] + w.y;
+          const double a0 = __hiloint2double(__double2hiint(b0) ^ sgn, __double2loint(b0));
+          const double a1 = __hiloint2double(__double2hiint(b1) ^ sgn, __double2loint(b1));
+          a[h][0] += a0 * n0; a[h][1] += a0 * n1; a[h][2] += a0 * n2;
+          a[h + 1][0] += a1 * n0; a[h + 1][1] += a1 * n1; a[h + 1][2] += a1 * n2;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < LPP; m <<= 1)
+#pragma unroll
+      for (int e = 0; e < 8; e++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) a[e][c] += __shfl_xor(a[e][c], m, 64);
+#pragma unroll
+    for (int c = 0; c < 24; c++) keep[c] += 0.5 * a[c / 3][c % 3];
+  }
+  // the same layout as the other forms write: [point][4 lane groups of 2 equations][6]
+  if (blockIdx.x == 0 && active && sub == 0)
+    for (int c = 0; c < 24; c++) out[p * 24 + c] = keep[c] / iters;
+  else if (keep[0] == 1.2345e300) out[0] = keep[1];
 }
 
 template <bool ATOMIC>
@@ -216,6 +278,24 @@ static void build(image_p &P, image_f &T) {
          nrows, faces.size(), inner, faces.size() - inner, NPT * NNB, ncol);
 }
 
+// socket power (W) and shader clock (MHz) right now, from rocm-smi (0 when it cannot be read)
+static void smi(double &watt, double &mhz) {
+  watt = mhz = 0;
+  FILE *f = popen("rocm-smi --showclocks --showpower --csv 2>/dev/null", "r");
+  if (!f) return;
+  char hdr[4096] = "", val[4096] = "";
+  if (fgets(hdr, sizeof hdr, f) && fgets(val, sizeof val, f)) {
+    std::vector<std::string> h, v;
+    for (char *tk = strtok(hdr, ",\n"); tk; tk = strtok(nullptr, ",\n")) h.push_back(tk);
+    for (char *tk = strtok(val, ",\n"); tk; tk = strtok(nullptr, ",\n")) v.push_back(tk);
+    for (size_t i = 0; i < h.size() && i < v.size(); i++) {
+      if (h[i].find("sclk clock speed") != std::string::npos) { std::string d; for (char c : v[i]) if (c >= '0' && c <= '9') d += c; mhz = atof(d.c_str()); }
+      if (h[i].find("Power") != std::string::npos) watt = atof(v[i].c_str());
+    }
+  }
+  pclose(f);
+}
+
 template <typename K, typename IMG> static double run(const char *what, K kern, const IMG *d_img, double *d_out, size_t lds, int occ, int cus,
                                         std::vector<double> &res) {
   const int blocks = cus * occ, iters = 400;
@@ -237,8 +317,25 @@ template <typename K, typename IMG> static double run(const char *what, K kern, 
   res.resize(NPT * 24);
   CK(hipMemcpy(res.data(), d_out, sizeof(double) * NPT * 24, hipMemcpyDeviceToHost));
   const double clk = best * 1e-3 * 2.4e9 / ((double)occ * iters);
-  printf("%-64s %d workgroups per CU (occupancy query %d, %5.1f KiB LDS): %7.0f clk per tile and CU (at 2.4 GHz)\n", what, occ, got,
-         lds / 1024.0, clk);
+  // the same launch back to back for ~3 s with the socket's power read beside it: joules per tile, the quantity the
+  // product's time follows
+  std::atomic<bool> stop{false};
+  std::vector<double> ws, fs;
+  std::thread th([&] { while (!stop) { double w, m; smi(w, m); if (w > 0) { ws.push_back(w); fs.push_back(m); } } });
+  const auto t0 = std::chrono::steady_clock::now();
+  long launches = 0;
+  while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 3.0) {
+    for (int i = 0; i < 20; i++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_img, d_out, iters);
+    CK(hipDeviceSynchronize());
+    launches += 20;
+  }
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  stop = true; th.join();
+  double w = 0, m = 0;
+  if (ws.size() > 2) { std::sort(ws.begin() + 1, ws.end()); std::sort(fs.begin() + 1, fs.end()); w = ws[1 + (ws.size() - 1) / 2]; m = fs[1 + (fs.size() - 1) / 2]; }
+  const double tiles = (double)launches * blocks * iters;
+  printf("%-64s %d workgroups per CU (occupancy query %d, %5.1f KiB LDS): %7.0f clk per tile and CU (at 2.4 GHz); back to back %5.0f W at %4.0f MHz, %6.1f ns and %6.2f uJ per tile above the idle socket\n",
+         what, occ, got, lds / 1024.0, clk, w, m, secs / tiles * 1e9, (w - 239.0) * secs / tiles * 1e6);
   return clk;
 }
 
@@ -258,7 +355,18 @@ int main() {
   for (int occ = 3; occ <= 5; occ++) {
     // occupancy forced by the LDS request (160 KiB per CU): 3 -> 48 KiB, 4 -> 36 KiB, 5 -> 32 KiB
     const size_t want = occ == 3 ? 48 * 1024 : occ == 4 ? 36 * 1024 : 32 * 1024;
-    if (img <= want) run("P point-centric, sums in registers", loop_points, d_p, d_out, want, occ, cus, rp);
+    if (img <= want) run("P point-centric, 4 lanes per point x 2 equations, sums in registers", loop_points, d_p, d_out, want, occ, cus, rp);
+    if (img <= want && occ == 5) {
+      std::vector<double> rs;
+      auto same = [&](const char *nm) {
+        double worst = 0, scale = 0;
+        for (int i = 0; i < NPT * 24; i++) { scale = std::max(scale, fabs(rp[i])); worst = std::max(worst, fabs(rp[i] - rs[i])); }
+        printf("    (%s against P: largest difference %.3g of %.3g)\n", nm, worst, scale);
+      };
+      run("S4 incidences split over 4 lanes per point, all equations per lane", loop_points_split<4>, d_p, d_out, want, occ, cus, rs); same("S4");
+      run("S2 incidences split over 2 lanes per point (half the lanes idle)", loop_points_split<2>, d_p, d_out, want, occ, cus, rs); same("S2");
+      run("S1 one lane per point (three quarters of the lanes idle)", loop_points_split<1>, d_p, d_out, want, occ, cus, rs); same("S1");
+    }
     if (imgf + acc <= want) {
       run("F face-major, coloured, plain read-modify-write, barrier per colour", loop_faces<false>, d_f, d_out, want, occ, cus, rf);
       run("A face-major, ds_add_f64, no colours (order not reproducible)", loop_faces<true>, d_f, d_out, want, occ, cus, ra);
