@@ -9,6 +9,9 @@
 //      barrier per colour (the four waves of a tile are not in lockstep)
 //   A  as F without colours and barriers, the sums by ds_add_f64 (NOT acceptable in the product: the order of an fp64 sum
 //      would differ from run to run -- here as the lower bound of any face-major form)
+//   S4 / S2 / S1  point-centric with the point's INCIDENCES split over 4 / 2 / 1 lanes, every lane all equations, the lanes'
+//      sums meeting in xor-shuffles: a quarter of P's address arithmetic per incidence
+// and, for every form, the socket's power read from rocm-smi while it runs back to back: joules per tile (EXPERIMENTS D.8)
 // on a synthetic tile with the bench mesh's counts: a 4 x 4 x 4 block of points with 14 neighbours each (6 along the axes, 8
 // along the body diagonals): 896 incidences, 252 faces with both ends owned, 392 cut faces, 152 halo rows (bench mesh, per
 // 64-point tile: 870 / 278 / 314 / ~140).  The three kernels compute the same sums (checked, 1e-12 relative).
