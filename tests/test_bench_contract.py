@@ -358,3 +358,32 @@ def test_experiment_switch_without_the_master_key_changes_nothing(gpu):
     assert locked == clean and "IGNORED" in err, err
     live, err = run({"CFDP_EXP_OWNED_NORMALS": "1", "CFDP_EXPERIMENTS": "1"})
     assert live != clean and "EXPERIMENT SWITCH ACTIVE" in err, err
+
+
+def test_power_reading_degrades_to_a_note_without_a_device():
+    """roofline.power: where rocm-smi has no device to read (this container) the block is null-valued with the reason --
+    never an exception, never a made-up number; with a fake rocm-smi on PATH it parses what the real one prints"""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    calls = []
+    pw = bench.power_beside(lambda: calls.append(1), seconds=0.05)
+    assert calls and "socket_power_w" in pw and (pw["socket_power_w"] is None and pw.get("note") or pw["socket_power_w"] > 0), pw
+
+
+def test_power_reading_parses_rocm_smi_output(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    fake = tmp_path / "rocm-smi"
+    fake.write_text("""#!/bin/sh
+case "$*" in
+  *showmaxpower*) echo "GPU[0]		: Max Graphics Package Power (W): 1400.0";;
+  *) echo "device,fclk clock speed:,fclk clock level:,sclk clock speed:,sclk clock level:,Current Socket Graphics Package Power (W)"
+     echo "card0,(1250Mhz),0,(2029Mhz),1,1388.0";;
+esac
+""")
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", f"{tmp_path}:{os.environ['PATH']}")
+    pw = bench.power_beside(lambda: None, seconds=0.3)
+    assert pw["socket_power_w"] == 1388.0 and pw["shader_clock_mhz"] == 2029 and pw["power_cap_w"] == 1400.0 and pw["samples"] >= 1, pw
