@@ -133,6 +133,7 @@ class PlanStruct(C.Structure):
         ("npartners", C.c_int), ("partner", C.POINTER(C.c_int)),
         ("send_off", C.POINTER(C.c_int)), ("send_idx", C.POINTER(C.c_int)),
         ("recv_off", C.POINTER(C.c_int)),
+        ("ngroups", C.c_int), ("group_begin", C.c_int * 5), ("group_class", C.c_int * 4),
     ]
 
 
@@ -712,7 +713,8 @@ class GpuPartition:
         self.stats = dict(ntiles=plan.ntiles, nbtiles=plan.nbtiles, nfaces_used=plan.nfaces_used,
                           nfaces_dup=plan.nfaces_dup, ninc=plan.ninc_total, lds_grad=plan.lds_grad,
                           lds_flux=plan.lds_flux, blob_bytes=plan.blob_bytes, nhalo=plan.nhalo_total,
-                          tile_points=plan.tile_points, plan_stage_seconds=plan.stage_seconds)
+                          tile_points=plan.tile_points, plan_stage_seconds=plan.stage_seconds,
+                          groups=[(plan.group_begin[k], plan.group_begin[k + 1], plan.group_class[k]) for k in range(plan.ngroups)])
         try:
             self._ck(self.lib.cfdp_gpu_upload_plan(self.h, plan.ptr))
         finally:

@@ -100,6 +100,7 @@ struct gg_args {
   // repeats the last one), GG_ROW_STRIDE entries per tile -- a list whose address needs nothing but
   // the tile number, so the gathers of the fused pass do not wait for the tile descriptor first
   const int *rowlist;
+  int rowlist_stride;           // entries per tile (>= the staged rows of every tile that a listed kernel runs, + 1)
   const double *var;            // [nall][8]: 7 variables + the dual volume in slot 7
   gg_grad_view grad;
   double *flux;                 // [nown][3]
@@ -130,7 +131,9 @@ hipError_t gg_launch_pack(const int *send_idx, int nsend, const gg_grad_view &gr
 hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view &grad,
                             hipStream_t stream);
 // xGMI write + notify exchange (see gg_kernels.hip): header words of a rank's IPC block
-enum { GG_ROW_STRIDE = 208 };  // >= 1024 / 5 + 1 rows: every piece index of the 256-thread fused pass
+// entries per tile of the fixed-stride row lists: 208 where every tile stages <= 204 rows (the small image of the 256-thread
+// fused pass: 192), 272 up to 256 rows (its large image); whole 64-byte lines either way
+enum { GG_ROW_STRIDE = 208, GG_ROW_STRIDE_LARGE = 272 };
 enum { GG_DONE_STRIDE = 32 };  // the completion counters of push_tile_done sit on cache lines of their own (atomics of hundreds of tiles)
 // hdr (ints): partner slot s owns the cache line [s * SLOT_STRIDE, (s + 1) * SLOT_STRIDE): word 0 its arrival flag /
 // counter (written by partner s only -- seven devices never store to one line), word GG_IPC_NEED_IN how many of its

@@ -1083,7 +1083,7 @@ template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, int DIAG = 0, b
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
-    const int *__restrict__ halo_idx, const int *__restrict__ rowlist, const double *__restrict__ var /*[nall][8]*/,
+    const int *__restrict__ halo_idx, const int *__restrict__ rowlist, int rl_stride, const double *__restrict__ var /*[nall][8]*/,
     const double *__restrict__ gradA_old /*[nown][10]*/, const double *__restrict__ ghost_old /*[nghost][21]*/,
     double *__restrict__ flux /*[nown][3]*/, int nown,
     gg_grad_view gnew, int dbg,
@@ -1117,18 +1117,19 @@ void gg_fused_split_kernel(
   // descriptor -> blob and row list -> rows are two chains of two round trips instead of one of three
   constexpr bool listed = LISTED;
   if (listed) {
-    const int *rl = rowlist + (size_t)t * GG_ROW_STRIDE;
+    const int *rl = rowlist + (size_t)t * rl_stride;
+    const int rlast = rl_stride - 1;
 #pragma unroll
     for (int k = 0; k < KV; k++) {
       const int r = (tid + k * nthr) >> 2;
-      hv[k] = ld_i32_nowait(rl + (r < GG_ROW_STRIDE - 1 ? r : GG_ROW_STRIDE - 1));
+      hv[k] = ld_i32_nowait(rl + (r < rlast ? r : rlast));
     }
 #pragma unroll
     for (int k = 0; k < KG; k++) {
       const int q = tid + k * nthr;
       rloc[k] = q / PPR;
       part[k] = q - PPR * rloc[k];
-      hg[k] = ld_i32_nowait(rl + (rloc[k] < GG_ROW_STRIDE - 1 ? rloc[k] : GG_ROW_STRIDE - 1));
+      hg[k] = ld_i32_nowait(rl + (rloc[k] < rlast ? rloc[k] : rlast));
     }
   }
   const cfdp_tile_desc td = tiles[t];
@@ -1508,8 +1509,8 @@ template <bool R, int CB, int KV> hipError_t launch_flux_dma(const gg_args &a, b
 template <bool R, bool N, int D, bool L, bool P>
 hipError_t launch_split(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
                         int dbgf, const gg_push_args &pa) {
-  return launch(gg_fused_split_kernel<R, N, 5, 4, 3, 4, D, L, P>, ntiles, block, (size_t)(5 + 4) * block * 16, stream, a.tiles, tile_begin,
-                a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa);
+  return launch(gg_fused_split_kernel<R, N, 6, 4, 3, 4, D, L, P>, ntiles, block, (size_t)(6 + 4) * block * 16, stream, a.tiles, tile_begin,
+                a.blob, a.halo_idx, a.rowlist, a.rowlist_stride, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa);
 }
 template <bool R, bool N>
 hipError_t launch_split_lp(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
@@ -1526,7 +1527,7 @@ template <bool R, bool N, bool L, bool P>
 hipError_t launch_preg(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
                        int dbgf, const gg_push_args &pa) {
   return launch(gg_fused_split_kernel<R, N, 5, 3, 3, 3, 0, L, P>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles, tile_begin,
-                a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa);
+                a.blob, a.halo_idx, a.rowlist, a.rowlist_stride, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa);
 }
 template <bool R, bool N>
 hipError_t launch_preg_lp(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
@@ -1644,12 +1645,12 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
   const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;
   const int kg = ((tile_points + max_halo) * 3 + block - 1) / block;
   if (cb < 1 || kv < 1 || kg < 1) return hipErrorNotSupported;
-  if (gg_fused_split && allow_split && cb <= 5 && kv <= 4 && kg <= 3) {
+  if (gg_fused_split && allow_split && cb <= 6 && kv <= 4 && kg <= 3) {
     if (gg_debug_flags & GG_DBG_STAMP) {  // diagnostic build of the same kernel: phase stamps (tools/phase_stamps.py)
       if (!a.rowlist) return hipErrorNotSupported;  // the stamped instantiation reads the fixed-stride row lists
-      if (gg_fused_split >= 2 && kv <= 3) {  // (at the capacity the real pass of these tiles runs at)
+      if (gg_fused_split >= 2 && cb <= 5 && kv <= 3) {  // (at the capacity the real pass of these tiles runs at)
 #define STAMP_SMALL(N) launch(gg_fused_split_kernel<false, N, 5, 3, 3, 3, 1, true, true>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, \
-                              a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa)
+                              a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.rowlist_stride, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa)
         return nt ? STAMP_SMALL(true) : STAMP_SMALL(false);
 #undef STAMP_SMALL
       }
@@ -1658,20 +1659,20 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
     }
     if (gg_debug_flags & GG_DBG_MOVE) {  // data movement only (cfdp_gpu_time_fused_movement): results are zeros
       if (!a.rowlist) return hipErrorNotSupported;
-      if (gg_fused_split >= 2 && kv <= 3) {  // (at the capacity the real pass of these tiles runs at)
+      if (gg_fused_split >= 2 && cb <= 5 && kv <= 3) {  // (at the capacity the real pass of these tiles runs at)
 #define MOVE_SMALL(N) launch(gg_fused_split_kernel<false, N, 5, 3, 3, 3, 2, true, false>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, \
-                             a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa)
+                             a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.rowlist_stride, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa)
         return nt ? MOVE_SMALL(true) : MOVE_SMALL(false);
 #undef MOVE_SMALL
       }
       return nt ? launch_split<false, true, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                 : launch_split<false, false, 2, true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
     }
-    if ((gg_debug_flags & 0x80000) && kv <= 3 && a.rowlist && !push && !refmode)  // CFDP_EXP_SKIP_PRE (EXPERIMENTS.md D.2)
-      return nt ? launch(gg_fused_split_kernel<false, true, 5, 3, 3, 3, 3, true, false>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa)
-                : launch(gg_fused_split_kernel<false, false, 5, 3, 3, 3, 3, true, false>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa);
+    if ((gg_debug_flags & 0x80000) && cb <= 5 && kv <= 3 && a.rowlist && !push && !refmode)  // CFDP_EXP_SKIP_PRE (EXPERIMENTS.md D.2)
+      return nt ? launch(gg_fused_split_kernel<false, true, 5, 3, 3, 3, 3, true, false>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.rowlist_stride, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa)
+                : launch(gg_fused_split_kernel<false, false, 5, 3, 3, 3, 3, true, false>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.rowlist_stride, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa);
     // tiles of at most 192 staged rows (3 var pieces per thread): the 32-KiB capacity
-    if (gg_fused_split >= 2 && kv <= 3) {
+    if (gg_fused_split >= 2 && cb <= 5 && kv <= 3) {
       if (refmode) return nt ? launch_preg_lp<true, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)
                              : launch_preg_lp<true, false>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa);
       return nt ? launch_preg_lp<false, true>(a, gnew, tile_begin, ntiles, block, stream, dbgf, pa)

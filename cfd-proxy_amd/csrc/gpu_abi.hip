@@ -123,24 +123,43 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   HIP_TRY(hipSetDevice(g->device));
   if (g->uploaded) free_device(g);
   g->nown = p->nown; g->nall = p->nall; g->ntiles = p->ntiles; g->nbtiles = p->nbtiles;
-  g->tp[0] = g->tp[1] = 0;
-  g->max_halo[0] = g->max_halo[1] = 0;
-  g->max_blob[0] = g->max_blob[1] = 0;
-  g->max_rows[0] = g->max_rows[1] = 0;
-  for (int t = 0; t < p->ntiles; t++) {
-    int c = t < p->nbtiles ? 0 : 1;
-    if (p->tiles[t].npts + p->tiles[t].nhalo > g->max_rows[c]) g->max_rows[c] = p->tiles[t].npts + p->tiles[t].nhalo;
-    if (p->tiles[t].npts > g->tp[c]) g->tp[c] = p->tiles[t].npts;
-    if (p->tiles[t].nhalo > g->max_halo[c]) g->max_halo[c] = p->tiles[t].nhalo;
-    if (p->tiles[t].blob_qw > g->max_blob[c]) g->max_blob[c] = p->tiles[t].blob_qw;
+  {  // launch groups: the boundary tiles, then the interior groups of the plan, each with the maxima that pick its kernels
+    g->groups.clear();
+    const int ng = p->ngroups >= 1 && p->ngroups <= 4 && p->group_begin[0] == p->nbtiles && p->group_begin[p->ngroups] == p->ntiles
+                       ? p->ngroups : 0;  // (a plan from a builder that does not know groups: one interior group)
+    auto add = [&](int begin, int end) {
+      cfdp_gpu::tile_group G;
+      G.begin = begin; G.n = end - begin;
+      for (int t = begin; t < end; t++) {
+        const cfdp_tile_desc &td = p->tiles[t];
+        const int rows = td.npts + td.nhalo;
+        const int c = cfdp_tile_class(p->tile_points, rows, (long)td.blob_qw * 16);
+        if (c > G.cls) G.cls = c;
+        if (rows > G.max_rows) G.max_rows = rows;
+        if (td.npts > G.tp) G.tp = td.npts;
+        if (td.nhalo > G.max_halo) G.max_halo = td.nhalo;
+        if (td.blob_qw > G.max_blob) G.max_blob = td.blob_qw;
+        const size_t lg = (size_t)td.blob_qw * 16 + (size_t)rows * 64, lf = (size_t)td.blob_qw * 16 + (size_t)rows * 80;
+        if (lg > G.lds_grad) G.lds_grad = lg;
+        if (lf > G.lds_flux) G.lds_flux = lf;
+      }
+      g->groups.push_back(G);
+    };
+    add(0, p->nbtiles);
+    if (ng) for (int k = 0; k < ng; k++) add(p->group_begin[k], p->group_begin[k + 1]);
+    else add(p->nbtiles, p->ntiles);
+    for (const auto &G : g->groups)
+      if (G.lds_grad > 160 * 1024 || G.lds_flux > 160 * 1024)
+        return fail("tile needs %zu / %zu bytes of LDS (> 160 KiB): use a smaller tile_points", G.lds_grad, G.lds_flux);
+    // the kernels run tile_points x lanes threads per tile (4 / 8 lanes per point by default): refuse here, with a message,
+    // what the first launch would refuse as "invalid configuration argument"
+    int tpmax = 0;
+    for (const auto &G : g->groups) tpmax = G.tp > tpmax ? G.tp : tpmax;
+    const int lanes = g->grad_lanes > g->flux_lanes ? g->grad_lanes : g->flux_lanes;
+    if ((long)tpmax * lanes > 1024)
+      return fail("tiles of up to %d points x %d lanes per point = %ld threads per workgroup (> 1024): build the plan with tile_points <= %d, "
+                  "or lower the lanes per point (cfdp_gpu_set_variant) before the upload", tpmax, lanes, (long)tpmax * lanes, 1024 / lanes);
   }
-  for (int c = 0; c < 2; c++) {
-    g->lds_grad[c] = (size_t)p->lds_grad_cls[c];
-    g->lds_flux[c] = (size_t)p->lds_flux_cls[c];
-  }
-  if (p->lds_grad > 160 * 1024 || p->lds_flux > 160 * 1024)
-    return fail("tile needs %ld / %ld bytes of LDS (> 160 KiB): use a smaller tile_points",
-                p->lds_grad, p->lds_flux);
   g->new2old.assign(p->new2old, p->new2old + p->nall);
   g->h_tiles.assign(p->tiles, p->tiles + p->ntiles);
   g->interior_reads_ghosts = false;
@@ -180,22 +199,33 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
   HIP_TRY(cfdp_memset_sync(g->d_halo, 0, sizeof(int) * (size_t)(p->nhalo_total + 1)));
   if (p->nhalo_total)
     HIP_TRY(hipMemcpy(g->d_halo, p->halo_idx, sizeof(int) * (size_t)p->nhalo_total, hipMemcpyHostToDevice));
-  {  // row lists at a fixed stride, when every tile fits one (the 256-thread fused pass: <= 204 rows)
-    bool fits = p->ntiles > 0 && p->tile_points <= 64;
-    for (int t = 0; t < p->ntiles && fits; t++) fits = p->tiles[t].npts + p->tiles[t].nhalo <= 204 && p->tiles[t].npts > 0;
+  {  // row lists at a fixed stride for the tiles of every group a fixed-capacity kernel can run (GG_ROW_STRIDE at <= 204
+     // staged rows -- the small image --, GG_ROW_STRIDE_LARGE up to 256); the tiles of a generic group never read theirs
+    int maxrows = 0;
+    bool any = false;
+    for (const auto &G : g->groups)
+      if (G.n > 0 && G.cls != CFDP_TILE_GENERIC) { any = true; maxrows = G.max_rows > maxrows ? G.max_rows : maxrows; }
+    bool fits = any && p->tile_points <= 64 && maxrows <= 256;
     if (const char *e = getenv("CFDP_ROWLIST")) fits = fits && atoi(e) != 0;
+    g->rowlist_stride = 0;
     if (fits) {
-      std::vector<int> rl((size_t)p->ntiles * GG_ROW_STRIDE);
-      for (int t = 0; t < p->ntiles; t++) {
-        const cfdp_tile_desc &td = p->tiles[t];
-        int *r = rl.data() + (size_t)t * GG_ROW_STRIDE;
-        const int n = td.npts + td.nhalo;
-        for (int i = 0; i < td.npts; i++) r[i] = td.pstart + i;
-        for (int i = 0; i < td.nhalo; i++) r[td.npts + i] = p->halo_idx[td.halo_off + i];
-        for (int i = n; i < GG_ROW_STRIDE; i++) r[i] = r[n - 1];
+      const int stride = maxrows <= 204 ? GG_ROW_STRIDE : GG_ROW_STRIDE_LARGE;
+      std::vector<int> rl((size_t)p->ntiles * stride, 0);
+      for (const auto &G : g->groups) {
+        if (G.cls == CFDP_TILE_GENERIC) continue;
+        for (int t = G.begin; t < G.begin + G.n; t++) {
+          const cfdp_tile_desc &td = p->tiles[t];
+          int *r = rl.data() + (size_t)t * stride;
+          const int n = td.npts + td.nhalo;
+          if (n <= 0) continue;
+          for (int i = 0; i < td.npts; i++) r[i] = td.pstart + i;
+          for (int i = 0; i < td.nhalo; i++) r[td.npts + i] = p->halo_idx[td.halo_off + i];
+          for (int i = n; i < stride; i++) r[i] = r[n - 1];
+        }
       }
       HIP_TRY(hipMalloc(&g->d_rowlist, rl.size() * sizeof(int)));
       HIP_TRY(hipMemcpy(g->d_rowlist, rl.data(), rl.size() * sizeof(int), hipMemcpyHostToDevice));
+      g->rowlist_stride = stride;
     }
   }
   g->vol.assign(p->vol, p->vol + p->nown);
@@ -417,6 +447,13 @@ int cfdp_gpu_set_variant(cfdp_gpu *g, int grad_lanes, int flux_lanes) {
   if (grad_lanes == 0) grad_lanes = 4;
   if (flux_lanes == 0) flux_lanes = 8;
   if (!ok(grad_lanes) || !ok(flux_lanes)) return fail("lanes per point must be 1, 2, 4 or 8");
+  if (g->uploaded) {  // (the same refusal as at upload: a workgroup has tile points x lanes threads)
+    int tpmax = 0;
+    for (const auto &G : g->groups) tpmax = G.tp > tpmax ? G.tp : tpmax;
+    const int lanes = grad_lanes > flux_lanes ? grad_lanes : flux_lanes;
+    if ((long)tpmax * lanes > 1024)
+      return fail("tiles of up to %d points x %d lanes per point = %ld threads per workgroup (> 1024)", tpmax, lanes, (long)tpmax * lanes);
+  }
   if (g->grad_lanes != grad_lanes || g->flux_lanes != flux_lanes) g->ipc.drop_graph_sets();  // the kernel forms are baked in
   g->grad_lanes = grad_lanes;
   g->flux_lanes = flux_lanes;
@@ -445,37 +482,65 @@ extern "C++" int cfdp_detail::fork_comm(cfdp_gpu *g) {
   return 0;
 }
 
-extern "C++" tile_range cfdp_detail::range_of(const cfdp_gpu *g, int which) {
-  auto cls = [&](int c) {
-    return tile_range{c ? g->nbtiles : 0, c ? g->ntiles - g->nbtiles : g->nbtiles, g->tp[c], g->max_halo[c],
-                      g->max_blob[c], g->max_rows[c], g->lds_grad[c], g->lds_flux[c]};
+// The launches that cover a tile selector.  Boundary tiles (half-size sheets) only get launches of their own when the
+// schedule needs them early; in a launch over ALL tiles they ride with the first interior group, sized for the larger of
+// the two (a separate launch for the few hundred boundary tiles of a rank costs ~15 us of mostly idle device per
+// iteration).  The other groups of the plan -- tiles of another capacity class, kept apart because one launch for all
+// would put every tile into the slower kernel form -- follow as launches of their own.
+extern "C++" std::vector<tile_range> cfdp_detail::segs_of(const cfdp_gpu *g, int which) {
+  auto of = [](const cfdp_gpu::tile_group &G) {
+    return tile_range{G.begin, G.n, G.tp, G.max_halo, G.max_blob, G.max_rows, G.lds_grad, G.lds_flux, G.cls};
   };
-  if (which == CFDP_TILES_BOUNDARY) return cls(0);
-  if (which == CFDP_TILES_INTERIOR) return cls(1);
-  const tile_range b = cls(0), i = cls(1);
-  if (b.n == 0) return i;
-  if (i.n == 0) return b;
-  return tile_range{0, g->ntiles, b.tp > i.tp ? b.tp : i.tp, b.max_halo > i.max_halo ? b.max_halo : i.max_halo,
-                    b.max_blob > i.max_blob ? b.max_blob : i.max_blob, b.max_rows > i.max_rows ? b.max_rows : i.max_rows,
-                    b.lds_grad > i.lds_grad ? b.lds_grad : i.lds_grad, b.lds_flux > i.lds_flux ? b.lds_flux : i.lds_flux};
+  auto join = [](const tile_range &a, const tile_range &b) {
+    return tile_range{a.begin, a.n + b.n, a.tp > b.tp ? a.tp : b.tp, a.max_halo > b.max_halo ? a.max_halo : b.max_halo,
+                      a.max_blob > b.max_blob ? a.max_blob : b.max_blob, a.max_rows > b.max_rows ? a.max_rows : b.max_rows,
+                      a.lds_grad > b.lds_grad ? a.lds_grad : b.lds_grad, a.lds_flux > b.lds_flux ? a.lds_flux : b.lds_flux,
+                      a.cls > b.cls ? a.cls : b.cls};
+  };
+  std::vector<tile_range> out;
+  if (g->groups.empty()) return out;
+  const tile_range b = of(g->groups[0]);
+  if (which == CFDP_TILES_BOUNDARY) { out.push_back(b); return out; }
+  size_t k = 1;
+  if (which == CFDP_TILES_ALL && b.n > 0) {
+    // (a generic group on either side stays apart: the point of the groups is that the others keep their kernels)
+    if (g->groups.size() > 1 && g->groups[1].n > 0 && b.cls != CFDP_TILE_GENERIC && g->groups[1].cls != CFDP_TILE_GENERIC) {
+      out.push_back(join(b, of(g->groups[1])));
+      k = 2;
+    } else {
+      out.push_back(b);
+    }
+  }
+  for (; k < g->groups.size(); k++)
+    if (g->groups[k].n > 0) out.push_back(of(g->groups[k]));
+  if (out.empty()) out.push_back(which == CFDP_TILES_ALL ? b : of(g->groups.back()));  // (no tiles at all: an empty range)
+  return out;
+}
+extern "C++" tile_range cfdp_detail::range_of(const cfdp_gpu *g, int which) {
+  const std::vector<tile_range> s = segs_of(g, which);
+  return s.empty() ? tile_range{0, 0, 0, 0, 0, 0, 0, 0, 0} : s[0];
 }
 
 extern "C++" int cfdp_detail::launch_grad(cfdp_gpu *g, int which, hipStream_t st, const gg_grad_view *into) {
   g->main_marked = false;
   gg_args a = g->args();
   if (into) a.grad = *into;
-  const tile_range r = range_of(g, which);
-  HIP_TRY(gg_launch_gradient(a, g->grad_lanes, r.begin, r.n, r.tp, r.lds_grad, r.row_halo(), r.max_blob, g->streaming, st));
+  for (const tile_range &r : segs_of(g, which))
+    HIP_TRY(gg_launch_gradient(a, g->grad_lanes, r.begin, r.n, r.tp, r.lds_grad, r.row_halo(), r.max_blob, g->streaming, st));
   return 0;
 }
 
+// wait: the boundary tiles wait for the latest exchange themselves -- in the launch that holds them, the first
 extern "C++" int cfdp_detail::launch_flux_tiles(cfdp_gpu *g, int mode, int which, hipStream_t st, const gg_push_args *wait) {
   g->main_marked = false;
   g->last_flux_mode = mode;
   const gg_args a = g->args();
-  const tile_range r = range_of(g, which);
-  HIP_TRY(gg_launch_flux(a, g->flux_lanes, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.lds_flux, r.row_halo(),
-                         r.max_blob, g->streaming, st, wait));
+  bool first = true;
+  for (const tile_range &r : segs_of(g, which)) {
+    HIP_TRY(gg_launch_flux(a, g->flux_lanes, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.lds_flux, r.row_halo(),
+                           r.max_blob, g->streaming, st, first ? wait : nullptr));
+    first = false;
+  }
   return 0;
 }
 
@@ -484,27 +549,35 @@ extern "C++" int cfdp_detail::launch_flux(cfdp_gpu *g, int mode, hipStream_t st,
 }
 
 // the deferred flux (from d_grad) + the next gradients (into d_grad_alt) over the selected tiles
-// in one pass; falls back to the two separate kernels when no fused capacity fits the tiles.
+// in one pass per launch group; a group no fused capacity fits runs the two separate kernels.
 // The caller swaps the buffers (fused_done) once every tile range of the iteration is enqueued.
-// push != nullptr: the tiles push and notify themselves; returns 2 (nothing launched) if no fused
-// kernel fits these tiles, so that the caller can take the separate-kernel path
+// push != nullptr: the boundary tiles push and notify themselves -- in the first launch, which holds them; returns 2
+// (nothing launched) if no fused kernel fits THAT launch, so that the caller can take the separate-kernel path
 extern "C++" int cfdp_detail::launch_fused(cfdp_gpu *g, int which, hipStream_t st, const gg_push_args *push) {
   g->main_marked = false;
   const gg_args a = g->args();
   const gg_grad_view gnew = g->alt_view();
   const int mode = g->flux_pending;
   g->last_flux_mode = mode;
-  const tile_range r = range_of(g, which);
-  if (push && !gg_fused_fits(r.tp, r.row_halo(), r.max_blob)) return 2;
+  const std::vector<tile_range> segs = segs_of(g, which);
+  if (push && (segs.empty() || segs[0].begin != 0 || !gg_fused_fits(segs[0].tp, segs[0].row_halo(), segs[0].max_blob))) return 2;
   const bool reverse = g->alternate && which == CFDP_TILES_ALL && !push && (g->fused_passes++ & 1u);
-  const hipError_t e = gg_launch_fused(a, gnew, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.row_halo(), r.max_blob,
-                                       g->streaming, !g->beside_rccl, st, push, reverse);
-  if (e == hipErrorNotSupported && push) return 2;
-  if (e == hipErrorNotSupported) {
-    if (launch_flux_tiles(g, mode, which, st)) return 1;
-    if (launch_grad(g, which, st, &gnew)) return 1;
-  } else {
-    HIP_TRY(e);
+  bool first = true;
+  for (const tile_range &r : segs) {
+    const gg_push_args *pu = first ? push : nullptr;
+    first = false;
+    const hipError_t e = gg_launch_fused(a, gnew, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.row_halo(), r.max_blob,
+                                         g->streaming, !g->beside_rccl, st, pu, reverse);
+    if (e == hipErrorNotSupported && pu) return 2;
+    if (e == hipErrorNotSupported) {  // this group's tiles fit no fused capacity: flux, then gradients, of these tiles only
+      HIP_TRY(gg_launch_flux(a, g->flux_lanes, mode == CFDP_FLUX_REFERENCE, r.begin, r.n, r.tp, r.lds_flux, r.row_halo(),
+                             r.max_blob, g->streaming, st, nullptr));
+      gg_args an = a;
+      an.grad = gnew;
+      HIP_TRY(gg_launch_gradient(an, g->grad_lanes, r.begin, r.n, r.tp, r.lds_grad, r.row_halo(), r.max_blob, g->streaming, st));
+    } else {
+      HIP_TRY(e);
+    }
   }
   return 0;
 }
@@ -888,8 +961,8 @@ int cfdp_gpu_time_fused_movement(cfdp_gpu *g, int iters, float *ms_pass) {
     const tile_range r = range_of(g, CFDP_TILES_ALL);
     const int block = ((r.tp * 4 + 63) / 64) * 64;
     const int cb = (r.max_blob + block - 1) / block, kv = ((r.tp + r.row_halo()) * 4 + block - 1) / block,
-              kg = ((r.tp + r.row_halo()) * 5 + block - 1) / block;
-    if (!gg_fused_split || g->beside_rccl || block > 1024 || cb > 5 || kv > 4 || kg > 4)
+              kg = ((r.tp + r.row_halo()) * 3 + block - 1) / block;
+    if (!gg_fused_split || g->beside_rccl || block > 1024 || cb > 6 || kv > 4 || kg > 3)
       return fail("the phase-split fused pass would not run on this partition (CFDP_FUSED_SPLIT=0, or tiles beyond its capacity): "
                   "no movement-only form to time");
   }

@@ -62,8 +62,17 @@ struct cfdp_gpu {
              ev_fluxdone = nullptr, ev_fork = nullptr;
   bool uploaded = false;
   int nown = 0, nall = 0, ntiles = 0, nbtiles = 0;
-  int tp[2] = {0, 0};         // max owned points per tile: [0] boundary, [1] interior
-  size_t lds_grad[2] = {0, 0}, lds_flux[2] = {0, 0};
+  // launch groups: [0] the boundary tiles (possibly none), then the interior groups of the plan (cfdp_plan::group_begin) --
+  // contiguous tile ranges, each with the maxima that select its kernel form.  A launch covers one SEGMENT = one group,
+  // or the boundary tiles together with the first interior group (segs_of)
+  struct tile_group {
+    int begin = 0, n = 0, cls = 0;  // cls: the largest capacity class among its tiles (cfdp_tile_class)
+    int tp = 0, max_halo = 0, max_blob = 0, max_rows = 0;  // owned points, halo rows, blob 16-byte units, staged rows (own + halo:
+                                                           // NOT tp + max_halo -- the tile with the most halo rows usually is not one with the most points)
+    size_t lds_grad = 0, lds_flux = 0;                     // the packed image of the register-staged kernels
+  };
+  std::vector<tile_group> groups;
+  int rowlist_stride = 0;      // entries per tile of d_rowlist
   cfdp_tile_desc *d_tiles = nullptr;
   uint4 *d_blob = nullptr;
   int *d_halo = nullptr, *d_sendidx = nullptr;
@@ -185,9 +194,6 @@ struct cfdp_gpu {
   std::vector<int> faceless;           // owned points without faces, device numbering
   bool faceless_send = false;          // some send point has no faces: its stored row travels, no tile computes one
   std::vector<double> vol;     // [nown] dual volumes, device numbering (slot 7 of each var row)
-  int max_halo[2] = {0, 0}, max_blob[2] = {0, 0};  // per tile class: halo rows, blob 16-byte units
-  int max_rows[2] = {0, 0};    // per tile class: rows a tile stages (own + halo) -- NOT tp + max_halo: the tile with
-                               // the most halo rows usually is not one with the most points
   bool streaming = false;      // per-iteration bytes exceed the Infinity Cache: non-temporal blobs/rows
   // fused passes over ALL tiles alternate the direction in which every XCD walks its run of tiles, so
   // that a pass starts on what the previous one left in the Infinity Cache (only worth it when a pass
@@ -276,7 +282,7 @@ struct cfdp_gpu {
   }
   gg_args args() const {
     gg_args a;
-    a.tiles = d_tiles; a.blob = d_blob; a.halo_idx = d_halo; a.rowlist = d_rowlist; a.var = d_var;
+    a.tiles = d_tiles; a.blob = d_blob; a.halo_idx = d_halo; a.rowlist = d_rowlist; a.rowlist_stride = rowlist_stride; a.var = d_var;
     a.grad = grad_view(); a.flux = d_flux; a.nown = nown;
     return a;
   }
@@ -285,6 +291,7 @@ struct cfdp_gpu {
 struct tile_range {
   int begin, n, tp, max_halo, max_blob, max_rows;
   size_t lds_grad, lds_flux;
+  int cls;  // the largest capacity class among its tiles (cfdp_tile_class)
   // what the fixed-capacity kernels size their row regions with: they take (points, halo rows) and add them
   int row_halo() const { return max_rows > tp ? max_rows - tp : 0; }
 };
@@ -297,6 +304,9 @@ int scaled_lag(const cfdp_gpu *g, int with_flux);
 int flush_flux(cfdp_gpu *g, bool record = true, hipStream_t st = nullptr);
 int mark_main(cfdp_gpu *g);
 int fork_comm(cfdp_gpu *g);
+// the launches that cover a tile selector, in order; range_of = the first of them (the one that holds the boundary tiles
+// when the selector includes them)
+__attribute__((visibility("hidden"))) std::vector<tile_range> segs_of(const cfdp_gpu *g, int which);
 __attribute__((visibility("hidden"))) tile_range range_of(const cfdp_gpu *g, int which);
 int launch_grad(cfdp_gpu *g, int which, hipStream_t st, const gg_grad_view *into = nullptr);
 __attribute__((visibility("hidden"))) int launch_flux_tiles(cfdp_gpu *g, int mode, int which, hipStream_t st, const gg_push_args *wait = nullptr);

@@ -59,6 +59,11 @@ typedef struct {
    * otherwise put the whole launch into the next capacity class (fewer workgroups per CU) */
   long blob_cap;
   int rows_cap;
+  /* the NEXT capacity of the kernels (0 = none): a tile that the budgets above would close below fill_min points goes on
+   * under these -- on graphs with more faces and neighbours per point than the lattice stand-ins (unstructured dual
+   * grids) a tile cut to the smallest image keeps a quarter of its lanes idle, which costs more than the larger image */
+  long blob_cap2;
+  int rows_cap2, fill_min;
 } tiler;
 
 static void tiler_open_tile(tiler *T) {
@@ -81,10 +86,14 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
     tiler_open_tile(T);
     int cnt = 0, head = 0, tail = 0, seen = 0, rejected = -1;
     long ninc = 0, ninternal = 0; /* incidences of the tile so far; faces with both ends in it */
+    long bcap = T->blob_cap;     /* this tile's budgets: the smallest image first */
+    int rcap = T->rows_cap, hcap = T->halo_cap, upgraded = 0;
+#define TILE_NEXT_CAPACITY() (!upgraded && T->blob_cap2 > 0 && cnt < T->fill_min && TP >= T->fill_min && \
+                              (upgraded = 1, bcap = T->blob_cap2, rcap = T->rows_cap2, hcap = T->rows_cap2 - TP, 1))
     while (cnt < TP) {
       /* a tile made of leftovers scattered between finished tiles reads ~14 rows per point; close
        * it early rather than let one such tile size the LDS image of the whole launch */
-      if (T->hseen && cnt >= 4 && seen - cnt > T->halo_cap) break;
+      if (T->hseen && cnt >= 4 && seen - cnt > hcap && !(TILE_NEXT_CAPACITY() && seen - cnt <= hcap)) break;
       if (head == tail) { /* need a seed */
         int seed = -1;
         while (T->sq_head < T->sq_tail) {
@@ -114,7 +123,8 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
           if (T->hseen[T->adj_other[e]] != t + 1) newrows++; /* (an upper bound: parallel faces count twice) */
         const long I2 = ninc + (T->xadj[p + 1] - T->xadj[p]), E2 = I2 - (ninternal + internal_add);
         const long blob = cfdp_blob_fn_bytes((int)E2) + cfdp_blob_inc_bytes((int)I2) + cfdp_blob_off_bytes(cnt + 1);
-        if (blob > T->blob_cap || seen + newrows > T->rows_cap) {
+        if ((blob > bcap || seen + newrows > rcap) &&
+            !(TILE_NEXT_CAPACITY() && blob <= bcap && seen + newrows <= rcap)) {
           rejected = p; /* stays un-tiled: it seeds a later tile */
           break;
         }
@@ -145,6 +155,7 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
     T->ntiles++;
     CFDP_ASSERT(cnt > 0);
   }
+#undef TILE_NEXT_CAPACITY
 }
 
 /* EXPERIMENT (CFDP_GROW_FRONTS=M > 1; SURVEY section 8f-1 "tile growth on the device"): the growth a frontier-parallel
@@ -632,13 +643,19 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
    * leaves room for that, 126 + 14 = 140 <= 2.2 * 64; small tiles: only the scattered ones) */
   T.halo_cap = o.tile_points * 2 - 2 < 96 ? 96 : o.tile_points * 2 - 2;
   {
-    /* what the fastest form of the fused pass stages per tile (gg_fused_split_kernel<.., 5, 4, 4, 4>, 4 lanes per
-     * point): 5 sixteen-byte blob pieces per thread, and rows in 4 pieces per thread at 5 pieces per 80-byte row */
+    /* what the two capacities of the fused pass stage per tile (gg_fused_split_kernel, 4 lanes per point, 16-byte pieces
+     * per thread): <5, 3, 3, 3> -- 5 blob pieces, var rows in 3 pieces at 4 per 64-byte row: a 32-KiB image at 64-point
+     * tiles, five workgroups per CU -- and <6, 4, 3, 4> -- 6 blob pieces, 4 row pieces: 40 KiB, four per CU.
+     * cfdp_tile_class() is the same statement for a finished tile. */
     const int block = ((o.tile_points * 4 + 63) / 64) * 64;
     T.blob_cap = (long)5 * block * 16;
-    T.rows_cap = 4 * block / 5;
-    const char *e = getenv("CFDP_TILE_BUDGET"); /* 0: tiles close by point count and the soft halo bound only */
-    if (e && atoi(e) == 0) T.blob_cap = 0;
+    T.rows_cap = 3 * block / 4;
+    T.blob_cap2 = (long)6 * block * 16;
+    T.rows_cap2 = block;
+    T.fill_min = o.tile_points - o.tile_points / 8; /* 7/8 full */
+    const char *e = getenv("CFDP_TILE_BUDGET"); /* 0: tiles close by point count and the soft halo bound only; 1: the small image only */
+    if (e && atoi(e) == 0) T.blob_cap = T.blob_cap2 = 0;
+    if (e && atoi(e) == 1) T.blob_cap2 = 0;
     /* with the hard row budget in force the soft halo bound may go up to it: tiles of meshes with many
      * neighbours per point (15+) then fill up instead of closing at 2/3 of their points */
     if (T.blob_cap > 0 && T.rows_cap - o.tile_points > T.halo_cap) T.halo_cap = T.rows_cap - o.tile_points;
@@ -794,6 +811,136 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
     free(key); free(start); free(seq); free(norder); free(nfirst);
   }
   PLAN_STAGE("supertile order");
+  /* ---- 3e. launch groups of the interior tiles by capacity class (cfdp_plan::group_begin).  The launch-wide maxima pick
+   * the kernel form, so ONE tile beyond the fixed capacities (a hub point with hundreds of faces) used to put every
+   * tile of the partition into the register-staged kernels; such tiles now go last and get a launch of their own.
+   * The reference's blocking does not care what the graph looks like either (colours of <= 96 faces whatever the
+   * degrees, src/rangelist.c:654-703).  The small and the large image are separated only where both sets are big: a
+   * second launch costs a kernel boundary (~5 us), the fifth workgroup per CU it buys the small tiles ~1 % of
+   * their time.  Stable: inside a group the supertile order stays. */
+  P->ngroups = 1;
+  P->group_begin[0] = P->nbtiles;
+  P->group_begin[1] = T.ntiles;
+  P->group_class[0] = CFDP_TILE_SMALL;
+  {
+    const int nt = T.ntiles;
+    unsigned char *cls = cfdp_malloc((size_t)(nt ? nt : 1));
+    int max_inc = 1;
+    for (int t = 0; t < nt; t++) {
+      int n = 0;
+      for (int i = T.tile_first[t]; i < T.tile_first[t + 1]; i++) n += xadj[T.order[i] + 1] - xadj[T.order[i]];
+      if (n > max_inc) max_inc = n;
+    }
+#pragma omp parallel num_threads(cfdp_host_threads())
+    {
+      lmap hmap;
+      lmap_init(&hmap, max_inc);
+#pragma omp for schedule(dynamic, 64)
+      for (int t = 0; t < nt; t++) { /* a tile's rows and blob bytes: the counts of host_blobs, pass 0 */
+        lmap_reset(&hmap);
+        const int np = T.tile_first[t + 1] - T.tile_first[t];
+        int H = 0;
+        long I = 0, internal = 0;
+        for (int i = T.tile_first[t]; i < T.tile_first[t + 1]; i++) {
+          const int p = T.order[i];
+          for (int e = xadj[p]; e < xadj[p + 1]; e++) {
+            const int q = adj_other[e];
+            I++;
+            if (q < nown && T.tile_of[q] == t) internal++; /* an internal face is listed by both ends */
+            else lmap_index(&hmap, q, &H);
+          }
+        }
+        const long E = I - internal / 2;
+        cls[t] = (unsigned char)cfdp_tile_class(o.tile_points, np + H,
+                                                cfdp_blob_fn_bytes((int)E) + cfdp_blob_inc_bytes((int)I) + cfdp_blob_off_bytes(np));
+      }
+      lmap_free(&hmap);
+    }
+    long n_of[3] = {0, 0, 0};
+    for (int t = P->nbtiles; t < nt; t++) n_of[cls[t]]++;
+    const long split_min = getenv("CFDP_CLASS_SPLIT_MIN") ? atol(getenv("CFDP_CLASS_SPLIT_MIN")) : 8192;
+    const int split_sl = n_of[CFDP_TILE_SMALL] >= split_min && n_of[CFDP_TILE_LARGE] >= split_min;
+    /* group of a class */
+    int grp_of[3] = {0, split_sl ? 1 : 0, 0};
+    int ng = split_sl ? 2 : 1;
+    if (n_of[CFDP_TILE_GENERIC] > 0 && n_of[CFDP_TILE_GENERIC] < nt - P->nbtiles) grp_of[CFDP_TILE_GENERIC] = ng++;
+    if (ng > 1) {
+      const int nbt = P->nbtiles, ni = nt - nbt;
+      int *seq = cfdp_malloc((size_t)ni * sizeof(int));
+      int n = 0;
+      for (int g = 0; g < ng; g++) {
+        P->group_begin[g] = nbt + n;
+        for (int t = nbt; t < nt; t++)
+          if (grp_of[cls[t]] == g) seq[n++] = t;
+      }
+      CFDP_ASSERT(n == ni);
+      P->group_begin[ng] = nt;
+      const int p0 = T.tile_first[nbt];
+      int *norder = cfdp_malloc((size_t)(nown - p0 ? nown - p0 : 1) * sizeof(int)), *nfirst = cfdp_malloc((size_t)(ni + 1) * sizeof(int));
+      n = 0;
+      for (int k = 0; k < ni; k++) {
+        nfirst[k] = p0 + n;
+        for (int i = T.tile_first[seq[k]]; i < T.tile_first[seq[k] + 1]; i++) norder[n++] = T.order[i];
+      }
+      CFDP_ASSERT(p0 + n == nown);
+      memcpy(T.order + p0, norder, (size_t)n * sizeof(int));
+      memcpy(T.tile_first + nbt, nfirst, (size_t)ni * sizeof(int));
+      unsigned char *ncls = cfdp_malloc((size_t)ni);
+      for (int k = 0; k < ni; k++) ncls[k] = cls[seq[k]];
+      memcpy(cls + nbt, ncls, (size_t)ni);
+      for (int k = nbt; k < nt; k++)
+        for (int i = T.tile_first[k]; i < T.tile_first[k + 1]; i++) T.tile_of[T.order[i]] = k;
+      free(seq); free(norder); free(nfirst); free(ncls);
+    }
+    P->ngroups = ng;
+    for (int g = 0; g < ng; g++) {
+      int c = CFDP_TILE_SMALL;
+      for (int t = P->group_begin[g]; t < P->group_begin[g + 1]; t++)
+        if (cls[t] > c) c = cls[t];
+      P->group_class[g] = c;
+    }
+    free(cls);
+  }
+  PLAN_STAGE("launch groups");
+  /* ---- 3d. inside a tile: points of like degree next to each other.  A lane walks the incidence list of its point, so a
+   * wave (16 points at 4 lanes each) is busy for as long as its LONGEST list takes: on a lattice every list has 14
+   * entries, on an unstructured dual grid 8 to 30 and more (the reference balances its thread ranges by face degree for
+   * the same reason, src/rangelist.c:320-398, min_size :354).  Sorted by descending degree (stable: growth order among
+   * equals) the lists of a wave differ by one or two entries instead of ten, and a tile's SIMD time is the sum of its
+   * waves' maxima instead of four times the tile's.  The values do not depend on it (a point's faces are added in file
+   * order); on the lattice stand-ins only the tiles at the mesh surface change. */
+  if (!(getenv("CFDP_DEGREE_SORT") && atoi(getenv("CFDP_DEGREE_SORT")) == 0)) {
+    int maxdeg = 0;
+    for (int p = 0; p < nown; p++)
+      if (xadj[p + 1] - xadj[p] > maxdeg) maxdeg = xadj[p + 1] - xadj[p];
+#pragma omp parallel num_threads(cfdp_host_threads())
+    {
+      int *cnt = cfdp_malloc(((size_t)maxdeg + 2) * sizeof(int));
+      int *tmp = cfdp_malloc((size_t)(o.tile_points > 0 ? o.tile_points : 1) * sizeof(int));
+#pragma omp for schedule(static)
+      for (int t = 0; t < T.ntiles; t++) {
+        const int ts = T.tile_first[t], np = T.tile_first[t + 1] - ts;
+        int lo = maxdeg, hi = 0;
+        for (int i = 0; i < np; i++) {
+          const int d = xadj[T.order[ts + i] + 1] - xadj[T.order[ts + i]];
+          if (d < lo) lo = d;
+          if (d > hi) hi = d;
+        }
+        if (hi == lo || np > o.tile_points) continue;
+        memset(cnt + lo, 0, (size_t)(hi - lo + 2) * sizeof(int)); /* counting sort, descending, stable */
+        for (int i = 0; i < np; i++) cnt[xadj[T.order[ts + i] + 1] - xadj[T.order[ts + i]]]++;
+        int at = 0;
+        for (int d = hi; d >= lo; d--) { const int c = cnt[d]; cnt[d] = at; at += c; }
+        for (int i = 0; i < np; i++) {
+          const int p = T.order[ts + i];
+          tmp[cnt[xadj[p + 1] - xadj[p]]++] = p;
+        }
+        memcpy(T.order + ts, tmp, (size_t)np * sizeof(int));
+      }
+      free(cnt); free(tmp);
+    }
+  }
+  PLAN_STAGE("degree order");
   /* ---- 4. renumber: owned points tile-major; ghosts grouped by partner, message order ---- */
   P->new2old = cfdp_malloc((size_t)nall * sizeof(int));
   P->old2new = cfdp_malloc((size_t)nall * sizeof(int));

@@ -144,7 +144,26 @@ typedef struct cfdp_plan {
   int *send_off;           /* [npartners+1]                                                */
   int *send_idx;           /* [send_off[npartners]] NEW ids, message order                 */
   int *recv_off;           /* [npartners+1]; partner s fills rows nown+recv_off[s]...      */
+  /* launch groups of the interior tiles: group k = tiles [group_begin[k], group_begin[k+1]), group_begin[0] == nbtiles,
+   * group_begin[ngroups] == ntiles.  Tiles are grouped by the capacity class of the kernels they fit (cfdp_tile_class):
+   * tiles no fixed-capacity kernel holds (a hub point with hundreds of faces) form the LAST group and get a launch of
+   * their own, so that one such tile does not put every tile of the partition into the slowest kernel form; the small
+   * and the large image are only separated where both sets are big enough to pay for a second launch                 */
+  int ngroups;
+  int group_begin[5];
+  int group_class[4];      /* the largest class in the group                                */
 } cfdp_plan;
+
+/* capacity classes of a tile (its workgroup has block = 4 lanes x tile_points threads, rounded up to whole waves; pieces are
+ * 16 bytes per thread): SMALL fits gg_fused_split_kernel<5, 3, 3, 3> (blob <= 5 pieces, staged rows <= 3 pieces at 4 per
+ * row), LARGE fits <6, 4, 3, 4>, GENERIC needs the kernels that take any tile shape                                  */
+enum { CFDP_TILE_SMALL = 0, CFDP_TILE_LARGE = 1, CFDP_TILE_GENERIC = 2 };
+static inline int cfdp_tile_class(int tile_points, int rows, long blob_bytes) {
+  const long block = (((long)tile_points * 4 + 63) / 64) * 64;
+  if (blob_bytes <= 5 * block * 16 && rows <= 3 * block / 4) return CFDP_TILE_SMALL;
+  if (blob_bytes <= 6 * block * 16 && rows <= block) return CFDP_TILE_LARGE;
+  return CFDP_TILE_GENERIC;
+}
 
 void cfdp_plan_default_opts(cfdp_plan_opts *o);
 cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *o);
