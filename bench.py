@@ -237,6 +237,8 @@ def main() -> None:
                     help="one kernel per face loop instead of the fused flux(i)+gradients(i+1) pass")
     ap.add_argument("--no-files", action="store_true", help="generate domains in memory (skip the loader)")
     ap.add_argument("--no-finest", action="store_true", help="skip the finest-level single-GPU roofline run")
+    ap.add_argument("--no-irregular", action="store_true",
+                    help="skip the irregular-mesh roofline run (the same kernels on an unstructured graph of the bench workload's size)")
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock samples of the roofline blocks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
     ap.add_argument("--no-loopback", action="store_true",
@@ -496,6 +498,9 @@ def main() -> None:
     for k in ("clock_conditioning", "exchange_check", "overlap"):
         if k in res:
             out[k] = res[k]
+    # (the driver's record keeps `config`: what stood in front of the timed region, and the same K steps without it)
+    for k in ("unconditioned_value", "unconditioned_ms_per_step", "untimed_steps_in_front_of_the_timed_region"):
+        out["config"][k] = res["clock_conditioning"][k]
 
     # ---- roofline of the dominant kernel, HIP events on the stream the kernels run on ----
     # three fractions of the 8 TB/s peak side by side:
@@ -608,6 +613,55 @@ def main() -> None:
             out["finest_level"] = fl
             p1.close()
             d1.free()
+        # ---- the same kernels on an IRREGULAR mesh of the bench workload's size: every figure above is on a lattice whose tiles
+        # are all alike -- the best case.  The generator's irregular option (host/dualgrid_gen.c: the edge graph of a random
+        # tetrahedralisation, 8 to 24 incidences per point, hubs of 60+, scrambled file numbering), 12 domain files -> loader
+        # -> merged, as the bench workload goes ----
+        if not args.no_irregular:
+            try:
+                gpi = pkg.gen_params(64, ndomains=12, connectivity=pkg.CONN_IRREGULAR, numbering=1)
+                di, _ = mg.build_rank_partition(gpi, 12, 1, 0, via_files=not args.no_files)
+                pi = pkg.GpuPartition(di, device=device, tile_points=args.tile_points, grad_lanes=args.grad_lanes, flux_lanes=args.flux_lanes)
+                deg = np.bincount(di.fpoint.ravel(), minlength=di.nall)[: di.nown]
+                pi.time_kernels(20)
+                pkg.kernel_forms()
+                gi, fi = pi.time_kernels(500)
+                forms = pkg.kernel_forms()
+                bi, bif = pkg.algo_bytes_grad(di.nfaces, di.nown, 0), pkg.algo_bytes_flux(di.nfaces, di.nown, 0)
+                st = pi.stats
+                im = {"workload": "irregular stand-in of the dualgrid.12 lvl 2 size (64^3 points, random tetrahedralisation + hubs, scrambled "
+                                  "numbering): 12 domain files -> loader -> merged on 1 GPU, no halo exchange",
+                      "points": di.nown, "faces": di.nfaces, "faces_per_point": di.nfaces / di.nown,
+                      "incidences_per_point": {"mean": float(deg.mean()), "min": int(deg.min()), "max": int(deg.max()),
+                                               "points_above_30": int((deg > 30).sum())},
+                      "tiles": st["ntiles"], "points_per_tile": di.nown / st["ntiles"], "halo_rows_per_tile": st["nhalo"] / st["ntiles"],
+                      "face_duplication": st["nfaces_dup"] / st["nfaces_used"], "blob_bytes": st["blob_bytes"],
+                      "launch_groups": [{"tiles": [b, e], "class": ("small", "large", "generic")[c]} for b, e, c in st["groups"]],
+                      "gradient_kernel": fracs(bi, bi, None, gi), "flux_kernel": fracs(bif, bif, None, fi)}
+                if not args.no_fusion:
+                    pi.set_fusion(True)
+                    pi.time_fused(50)
+                    pkg.kernel_forms()
+                    fui = pi.time_fused(1000)
+                    forms += " " + pkg.kernel_forms()
+                    im["iterations_per_s"] = 1e3 / fui
+                    im["fused"] = fracs(bi + bif, bi + bif - 32.0 * di.nfaces, None, fui)
+                    try:
+                        mvi = pi.time_fused_movement(500)
+                        im["fused"]["movement_only_us"] = mvi * 1e3
+                        im["fused"]["exposed_beyond_movement_us"] = (fui - mvi) * 1e3
+                    except Exception as e:
+                        im["fused"]["movement_only_us"] = None
+                        im["fused"]["movement_only_note"] = str(e)[:160]
+                    # the lattice is the best case: by how much (same box, same process, same byte count per unit)
+                    im["lattice_over_irregular"] = {"fused_frac": out["roofline"]["frac"] / im["fused"]["frac"],
+                                                    "gradient_kernel_frac": grad_k["frac"] / im["gradient_kernel"]["frac"]}
+                im["kernel_forms"] = forms.split()
+                out["irregular_mesh"] = im
+                pi.close()
+                di.free()
+            except Exception as e:  # the extra must never cost the line
+                out["irregular_mesh"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_loopback and not args.no_fusion:
         # ---- what the xGMI write + notify protocol itself costs per iteration when no partner is ever late: rank 0's partition
         # of the 8-GPU configs on THIS GPU, every partner slot looped back to the rank's own landing arenas and flag words
@@ -722,7 +776,10 @@ def main() -> None:
             gsamples = sorted(ref.timed(part.var, niter=25, with_flux=False) for _ in range(3))
             ref.close()
             med = samples[len(samples) // 2]
-            host = {"cpu_model": cpu_model(), "threads": cores, "n_median": nsamp, "niter": 25,
+            host = {"cpu_model": cpu_model(), "threads": cores,
+                    # a GPU box grants a share of a bigger host: `cores` is what this process may run on, not the socket
+                    "cores_note": f"cgroup / affinity share of a host that shows {os.cpu_count()} CPUs (not every physical core of it)",
+                    "n_median": nsamp, "niter": 25,
                     "protocol": "N_MEDIAN samples of NITER iterations each, the median sample (src/solver.c:32,40,298; src/hybrid.f6.c:72)"}
             port = {"value": 25.0 / med, "unit": "iterations/s", "cores": cores, "kind": "port", **host,
                     "thread_binding": "none (OMP_PROC_BIND unset)",

@@ -95,6 +95,7 @@ class GenParams(C.Structure):
         ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("ndomains", C.c_int),
         ("connectivity", C.c_int), ("normals", C.c_int), ("volumes", C.c_int),
         ("ghost_faces", C.c_int), ("cdf_version", C.c_int), ("seed", C.c_uint64),
+        ("numbering", C.c_int),
     ]
 
 
@@ -139,6 +140,7 @@ class PlanStruct(C.Structure):
 
 def _declare_host(lib: C.CDLL) -> None:
     P = C.POINTER
+    lib.cfdp_tile_class_of.argtypes = [C.c_int, C.c_int, C.c_long]
     lib.cfdp_gen_domain.argtypes = [P(GenParams), C.c_int, P(SolverData), P(CommData)]
     lib.cfdp_gen_write_domain.argtypes = [P(GenParams), C.c_int, C.c_char_p, C.c_int]
     lib.cfdp_write_domain_file.argtypes = [C.c_char_p, P(SolverData), P(CommData), C.c_int]
@@ -423,11 +425,14 @@ def domain_from_arrays(fpoint, fnormal, pvolume, nown, var=None, ndomains=1, ipr
     return d
 
 
+CONN_IRREGULAR = 62  # cfdproxy_host.h CFDP_CONN_IRREGULAR
+
+
 def gen_params(nx, ny=None, nz=None, ndomains=1, connectivity=7, normals=1, volumes=1,
-               ghost_faces=0, cdf_version=1, seed=20241) -> GenParams:
+               ghost_faces=0, cdf_version=1, seed=20241, numbering=0) -> GenParams:
     ny = nx if ny is None else ny
     nz = nx if nz is None else nz
-    return GenParams(nx, ny, nz, ndomains, connectivity, normals, volumes, ghost_faces, cdf_version, seed)
+    return GenParams(nx, ny, nz, ndomains, connectivity, normals, volumes, ghost_faces, cdf_version, seed, numbering)
 
 
 def gen_domain(gp: GenParams, domain: int) -> Domain:
@@ -599,6 +604,16 @@ def handed_out_rows(stored: np.ndarray) -> np.ndarray:
     return r
 
 
+def kernel_forms() -> str:
+    """the face-loop kernel forms this thread has launched since the last call (cfdp_gpu_kernel_forms); the first call
+    switches the log on and returns ''"""
+    lib = hip_lib()
+    lib.cfdp_gpu_kernel_forms.argtypes = [C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(1024)
+    lib.cfdp_gpu_kernel_forms(buf, 1024)
+    return buf.value.decode()
+
+
 def device_bus_id(device: int) -> str:
     """PCI bus id of a visible device: the same string in every process that sees the same physical device"""
     buf = C.create_string_buffer(64)
@@ -716,10 +731,11 @@ class GpuPartition:
                           tile_points=plan.tile_points, plan_stage_seconds=plan.stage_seconds,
                           groups=[(plan.group_begin[k], plan.group_begin[k + 1], plan.group_class[k]) for k in range(plan.ngroups)])
         try:
+            # (lanes first: the upload refuses tiles whose points x lanes exceed a workgroup)
+            self._ck(self.lib.cfdp_gpu_set_variant(self.h, grad_lanes, flux_lanes))
             self._ck(self.lib.cfdp_gpu_upload_plan(self.h, plan.ptr))
         finally:
             plan.free()
-        self._ck(self.lib.cfdp_gpu_set_variant(self.h, grad_lanes, flux_lanes))
         self.push_fields()
 
     def _ck(self, rc: int) -> None:

@@ -160,6 +160,8 @@ hipError_t gg_launch_validate(double *var, int nall, const double *flux, const d
                               int nown, int lag, bool do_scale, int *state, hipStream_t stream);
 hipError_t gg_launch_scale_var(double *var, int nall, double factor, hipStream_t stream);
 hipError_t gg_launch_var_check(const double *var, const double *var0, int nall, double factor, unsigned long long *bad, hipStream_t stream);
+// the kernel forms the launchers picked (calling thread): "form@first_tile+tiles ..."; see cfdp_gpu_kernel_forms
+int gg_forms_take(char *buf, size_t len);
 extern int gg_debug_flags;
 hipError_t gg_set_stamp_buffer(unsigned long long *dev);  // diagnostics: phase stamps of the split fused pass
 extern int gg_fused_split;

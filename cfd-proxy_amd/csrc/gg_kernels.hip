@@ -266,6 +266,9 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
     const int ke = MOVE ? ks : ke0;
     const double *var_eq0 = var_l + eq0;
     int k = ks;
+    // (each lane runs the chain "sevens, a four, a two, a one" over its OWN list; a wave issues a batch for as long as any
+    // lane has one, but lanes without it are switched off and read nothing from LDS, which is what this loop is short of:
+    // one schedule per wave with lanes sitting out masked batches -- built and measured in round 6 -- was 4-8 % slower)
     if constexpr (NE <= 2)  // few registers per incidence: deeper batches (a point has ~14 incidences)
       for (; k + GG_DEEP_BATCH <= ke; k += GG_DEEP_BATCH) grad_batch<GG_DEEP_BATCH, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
     for (; k + 4 <= ke; k += 4) grad_batch<4, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
@@ -1450,6 +1453,29 @@ namespace {
 
 constexpr size_t LDS_MAX = 160 * 1024;
 
+// which form ran (cfdp_gpu_kernel_forms): bounded, per thread, only while somebody has asked once
+thread_local char g_forms[1024];
+thread_local int g_forms_len = 0, g_forms_n = 0;
+thread_local bool g_forms_on = false;
+void note_form(const char *name, int a, int b, int c, int d, const char *suffix, int tile_begin, int ntiles) {
+  if (!g_forms_on) return;
+  g_forms_n++;
+  char one[96];
+  int n;
+  if (d >= 0) n = snprintf(one, sizeof one, "%s<%d,%d,%d,%d>%s@%d+%d", name, a, b, c, d, suffix, tile_begin, ntiles);
+  else if (c >= 0) n = snprintf(one, sizeof one, "%s<%d,%d,%d>%s@%d+%d", name, a, b, c, suffix, tile_begin, ntiles);
+  else if (b >= 0) n = snprintf(one, sizeof one, "%s<%d,%d>%s@%d+%d", name, a, b, suffix, tile_begin, ntiles);
+  else n = snprintf(one, sizeof one, "%s<%d>%s@%d+%d", name, a, suffix, tile_begin, ntiles);
+  if (n <= 0 || g_forms_len + n + 2 > (int)sizeof g_forms) return;
+  if (g_forms_len) {  // (back-to-back repeats of one launch are logged once)
+    const char *last = g_forms + g_forms_len - n;
+    if (g_forms_len >= n && !memcmp(last, one, (size_t)n) && (g_forms_len == n || last[-1] == ' ')) return;
+    g_forms[g_forms_len++] = ' ';
+  }
+  memcpy(g_forms + g_forms_len, one, (size_t)n + 1);
+  g_forms_len += n;
+}
+
 // raise the dynamic-LDS limit of a kernel to the full 160 KiB, once per kernel and device
 template <typename K> hipError_t allow_lds(K *kernel) {
   static bool done[64] = {false};
@@ -1475,6 +1501,7 @@ hipError_t launch(K *kernel, int grid, int block, size_t lds, hipStream_t stream
 
 template <int L> hipError_t launch_grad_generic(const gg_args &a, bool nt, int tile_begin, int ntiles, int block, size_t lds,
                                                 hipStream_t stream) {
+  note_form("gradient_generic", L, -1, -1, -1, "", tile_begin, ntiles);
   if (nt) return launch(gg_gradient_kernel<L, true>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad);
   return launch(gg_gradient_kernel<L, false>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad);
 }
@@ -1482,12 +1509,14 @@ template <int L> hipError_t launch_grad_generic(const gg_args &a, bool nt, int t
 template <int CB, int KV> hipError_t launch_grad_dma(const gg_args &a, bool nt, int tile_begin, int ntiles, int block,
                                                      size_t stage_bytes, hipStream_t stream) {
   const size_t lds = (size_t)(CB + KV) * block * 16 + stage_bytes;
+  note_form("gradient_dma", CB, KV, -1, -1, "", tile_begin, ntiles);
   if (nt) return launch(gg_gradient_dma_kernel<4, true, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags);
   return launch(gg_gradient_dma_kernel<4, false, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags);
 }
 
 template <int L, bool R> hipError_t launch_flux_generic(const gg_args &a, bool nt, int tile_begin, int ntiles, int block, size_t lds,
                                                         hipStream_t stream) {
+  note_form("flux_generic", L, -1, -1, -1, R ? "ref" : "", tile_begin, ntiles);
   if (nt) return launch(gg_flux_kernel<L, R, true>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown);
   return launch(gg_flux_kernel<L, R, false>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.grad.a, a.grad.ghost, a.flux, a.nown);
 }
@@ -1495,6 +1524,7 @@ template <int L, bool R> hipError_t launch_flux_generic(const gg_args &a, bool n
 template <bool R, int CB, int KV> hipError_t launch_flux_dma(const gg_args &a, bool nt, int tile_begin, int ntiles, int block,
                                                              hipStream_t stream, const gg_push_args *wait) {
   const size_t lds = (size_t)(CB + KV) * block * 16;
+  note_form("flux_dma", CB, KV, -1, -1, wait ? "wait" : "", tile_begin, ntiles);
   gg_push_args pa;
   memset(&pa, 0, sizeof pa);
   if (wait) {
@@ -1509,6 +1539,7 @@ template <bool R, int CB, int KV> hipError_t launch_flux_dma(const gg_args &a, b
 template <bool R, bool N, int D, bool L, bool P>
 hipError_t launch_split(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
                         int dbgf, const gg_push_args &pa) {
+  note_form("fused_split", 6, 4, 3, 4, D == 1 ? "stamp" : D == 2 ? "move" : (L ? (P ? "listed+push" : "listed") : (P ? "push" : "")), tile_begin, ntiles);
   return launch(gg_fused_split_kernel<R, N, 6, 4, 3, 4, D, L, P>, ntiles, block, (size_t)(6 + 4) * block * 16, stream, a.tiles, tile_begin,
                 a.blob, a.halo_idx, a.rowlist, a.rowlist_stride, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa);
 }
@@ -1526,6 +1557,7 @@ hipError_t launch_split_lp(const gg_args &a, const gg_grad_view &gnew, int tile_
 template <bool R, bool N, bool L, bool P>
 hipError_t launch_preg(const gg_args &a, const gg_grad_view &gnew, int tile_begin, int ntiles, int block, hipStream_t stream,
                        int dbgf, const gg_push_args &pa) {
+  note_form("fused_split", 5, 3, 3, 3, L ? (P ? "listed+push" : "listed") : (P ? "push" : ""), tile_begin, ntiles);
   return launch(gg_fused_split_kernel<R, N, 5, 3, 3, 3, 0, L, P>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, a.tiles, tile_begin,
                 a.blob, a.halo_idx, a.rowlist, a.rowlist_stride, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa);
 }
@@ -1543,6 +1575,7 @@ template <int CB, int KV, int KG>
 hipError_t launch_fused_upfront(const gg_args &a, const gg_grad_view &gnew, bool refmode, bool nt, int tile_begin, int ntiles, int block,
                                 hipStream_t stream, int dbgf, const gg_push_args &pa) {
   const size_t lds = (size_t)(CB + KV + KG) * block * 16;
+  note_form("fused_upfront", CB, KV, KG, -1, pa.tile_off ? "push" : "", tile_begin, ntiles);
 #define FUSED_ARGS ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa
   if (refmode) return nt ? launch(gg_fused_dma_kernel<true, true, CB, KV, KG>, FUSED_ARGS) : launch(gg_fused_dma_kernel<true, false, CB, KV, KG>, FUSED_ARGS);
   return nt ? launch(gg_fused_dma_kernel<false, true, CB, KV, KG>, FUSED_ARGS) : launch(gg_fused_dma_kernel<false, false, CB, KV, KG>, FUSED_ARGS);
@@ -1550,6 +1583,19 @@ hipError_t launch_fused_upfront(const gg_args &a, const gg_grad_view &gnew, bool
 }
 
 }  // namespace
+
+int gg_forms_take(char *buf, size_t len) {
+  g_forms_on = true;
+  const int n = g_forms_n;
+  if (buf && len) {
+    const size_t m = (size_t)g_forms_len < len - 1 ? (size_t)g_forms_len : len - 1;
+    memcpy(buf, g_forms, m);
+    buf[m] = 0;
+  }
+  g_forms_len = g_forms_n = 0;
+  g_forms[0] = 0;
+  return n;
+}
 
 hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int ntiles, int tile_points, size_t lds,
                               int max_halo, int max_blob_qw, bool nt, hipStream_t stream) {
@@ -1651,6 +1697,7 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
       if (gg_fused_split >= 2 && cb <= 5 && kv <= 3) {  // (at the capacity the real pass of these tiles runs at)
 #define STAMP_SMALL(N) launch(gg_fused_split_kernel<false, N, 5, 3, 3, 3, 1, true, true>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, \
                               a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.rowlist_stride, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa)
+        note_form("fused_split", 5, 3, 3, 3, "stamp", tile_begin, ntiles);
         return nt ? STAMP_SMALL(true) : STAMP_SMALL(false);
 #undef STAMP_SMALL
       }
@@ -1662,6 +1709,7 @@ hipError_t gg_launch_fused(const gg_args &a, const gg_grad_view &gnew, bool refm
       if (gg_fused_split >= 2 && cb <= 5 && kv <= 3) {  // (at the capacity the real pass of these tiles runs at)
 #define MOVE_SMALL(N) launch(gg_fused_split_kernel<false, N, 5, 3, 3, 3, 2, true, false>, ntiles, block, (size_t)(5 + 3) * block * 16, stream, \
                              a.tiles, tile_begin, a.blob, a.halo_idx, a.rowlist, a.rowlist_stride, a.var, a.grad.a, a.grad.ghost, a.flux, a.nown, gnew, dbgf, pa)
+        note_form("fused_split", 5, 3, 3, 3, "move", tile_begin, ntiles);
         return nt ? MOVE_SMALL(true) : MOVE_SMALL(false);
 #undef MOVE_SMALL
       }

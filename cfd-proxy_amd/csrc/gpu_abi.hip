@@ -441,6 +441,8 @@ int cfdp_gpu_get_flux(cfdp_gpu *g, double *flux) {
   return 0;
 }
 
+int cfdp_gpu_kernel_forms(char *buf, size_t len) { return gg_forms_take(buf, len); }
+
 int cfdp_gpu_set_variant(cfdp_gpu *g, int grad_lanes, int flux_lanes) {
   if (!g) return fail("null context");
   auto ok = [](int l) { return l == 1 || l == 2 || l == 4 || l == 8; };

@@ -12,6 +12,12 @@
  *
  * Everything (normals, volumes) is a pure function of (seed, global id, direction), so a
  * face stored in two domain files is bit-identical in both.
+ *
+ * connectivity = CFDP_CONN_IRREGULAR: the same schema on an IRREGULAR graph -- what an unstructured dual grid looks like
+ * to the face loops, which see point numbers, normals and volumes, never coordinates: the edge graph of a RANDOM
+ * tetrahedralisation of the lattice's cubes (face_exists) with a hub point every 1024 -- 14 incidences per point on
+ * average like the Kuhn lattice (13.6), but 8 to 24 from point to point and 60+ at the hubs, no two tiles alike.
+ * numbering = 1 scrambles the file numbering of every domain's points (a real mesh file is not numbered along x).
  */
 #include "cfdproxy_host.h"
 #include "host_util.h"
@@ -75,6 +81,79 @@ int cfdp_host_threads(void) {
 static const int DIRS[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0},
                                {0, 1, 1}, {1, 0, 1}, {1, 1, 1}};
 
+/* the candidate directions of a generated mesh: the 7 (3) lattice directions, or -- irregular -- the 62 lexicographically
+ * positive offsets of the 5x5x5 neighbourhood, the 13 with no component beyond +-1 first */
+typedef struct { int n, reach, irregular; int d[62][3]; } dirset;
+static void make_dirs(const cfdp_gen_params *gp, dirset *D) {
+  D->irregular = gp->connectivity == CFDP_CONN_IRREGULAR;
+  if (!D->irregular) {
+    D->n = gp->connectivity;
+    D->reach = 1;
+    memcpy(D->d, DIRS, sizeof DIRS);
+    return;
+  }
+  D->n = 0;
+  D->reach = 2;
+  for (int far = 0; far < 2; far++)
+    for (int dz = -2; dz <= 2; dz++)
+      for (int dy = -2; dy <= 2; dy++)
+        for (int dx = -2; dx <= 2; dx++) {
+          if (!(dz > 0 || (dz == 0 && (dy > 0 || (dy == 0 && dx > 0))))) continue;
+          const int is_far = abs(dx) > 1 || abs(dy) > 1 || abs(dz) > 1;
+          if (is_far != far) continue;
+          D->d[D->n][0] = dx; D->d[D->n][1] = dy; D->d[D->n][2] = dz;
+          D->n++;
+        }
+  CFDP_ASSERT(D->n == 62);
+}
+static inline int is_hub(const cfdp_gen_params *gp, long gid) {
+  return (cfdp_mix64(gp->seed * 0xD1B54A32D192ED03ull + 0x77ull + (uint64_t)gid) & 1023u) == 0;
+}
+/* does the face from point gid0 in direction d (to gid1) exist?  Lattice meshes: always.  Irregular: the lattice's unit
+ * cubes are cut into tetrahedra AT RANDOM -- every cube face takes one of its two diagonals, every cube one of its four
+ * body diagonals (a pure function of seed and face / cube), the axis edges always exist: the edge graph of an
+ * unstructured tetrahedral mesh, 14 incidences per point on average like the Kuhn lattice but 8 to 24 from point to
+ * point -- and one point in 1024 is a hub joined to its whole 3x3x3 neighbourhood and a third of the 5x5x5 one. */
+static inline int face_exists(const cfdp_gen_params *gp, const dirset *D, long gid0, long gid1, int d) {
+  if (!D->irregular) return 1;
+  const int hub = is_hub(gp, gid0) || is_hub(gp, gid1);
+  if (d >= 13) /* beyond the 3x3x3 neighbourhood: hubs only */
+    return hub && cfdp_u01(gp->seed * 0xA24BAED4963EE407ull + 0x1234567ull + ((uint64_t)gid0 * 64u + (uint64_t)d)) < 0.355;
+  if (hub) return 1;
+  const int *v = D->d[d];
+  const int nz = (v[0] != 0) + (v[1] != 0) + (v[2] != 0);
+  if (nz == 1) return 1;
+  const long x = gid0 % gp->nx, y = (gid0 / gp->nx) % gp->ny, z = gid0 / ((long)gp->nx * gp->ny);
+  /* the face / cube this diagonal lies in, named by its corner with the smallest coordinates */
+  const long cx = v[0] < 0 ? x - 1 : x, cy = v[1] < 0 ? y - 1 : y, cz = v[2] < 0 ? z - 1 : z;
+  const uint64_t cell = (uint64_t)((cz * gp->ny + cy) * gp->nx + cx);
+  if (nz == 2) {
+    const int plane = v[0] == 0 ? 0 : (v[1] == 0 ? 1 : 2);
+    const int a = plane == 0 ? v[1] : v[0], b = plane == 2 ? v[1] : v[2]; /* the two non-zero components */
+    const int main_diag = (a > 0) == (b > 0);
+    const int pick = (int)(cfdp_mix64(gp->seed * 0x8CB92BA72F3D8DD7ull + 0x1111ull + cell * 4u + (uint64_t)plane) & 1u);
+    return pick == main_diag;
+  }
+  /* a body diagonal: which of the cube's four, by the signs of dx and dy relative to dz (> 0 always) */
+  const int which = (v[0] < 0 ? 1 : 0) | (v[1] < 0 ? 2 : 0);
+  return (int)(cfdp_mix64(gp->seed * 0xC2B2AE3D27D4EB4Full + 0x2222ull + cell) & 3u) == which;
+}
+/* file numbering of a domain's own points: lexicographic in its box, or (numbering = 1) scrambled by an affine
+ * permutation i -> (a*i + b) mod n with gcd(a, n) = 1 -- computable point by point, so a ghost's owner-local id needs no
+ * table of the owner's numbering */
+static inline long scramble_mult(long n) {
+  long a = (long)(0.6180339887 * (double)n) | 1;
+  for (;; a += 2) {
+    long x = a, y = n;
+    while (y) { long t = x % y; x = y; y = t; }
+    if (x == 1) return a;
+  }
+}
+static inline int file_id(const cfdp_gen_params *gp, long lex, long n) {
+  if (!gp->numbering || n < 3) return (int)lex;
+  return (int)((scramble_mult(n) % n * lex + n / 3) % n);
+}
+
 typedef struct { int lo[3], hi[3]; } box_t; /* [lo,hi) */
 
 /* ---- recursive coordinate bisection: domain ids in tree order (spatially coherent) ---- */
@@ -129,7 +208,7 @@ static void face_normal(const cfdp_gen_params *gp, long gid0, int d, double h, d
     for (int c = 0; c < 3; c++) n[c] = h * h * DIRS[d][c];
     return;
   }
-  uint64_t key = gp->seed * 0x100000001B3ull + ((uint64_t)gid0 * 8u + (uint64_t)d) * 4u;
+  uint64_t key = gp->seed * 0x100000001B3ull + ((uint64_t)gid0 * (gp->connectivity == CFDP_CONN_IRREGULAR ? 64u : 8u) + (uint64_t)d) * 4u;
   const double twopi = 6.283185307179586476925286766559;
   double u1 = cfdp_u01(key + 0), u2 = cfdp_u01(key + 1);
   double u3 = cfdp_u01(key + 2), u4 = cfdp_u01(key + 3);
@@ -146,26 +225,29 @@ static double point_volume(const cfdp_gen_params *gp, long gid, double h) {
 }
 
 int cfdp_gen_domain(const cfdp_gen_params *gp, int domain, solver_data *sd, comm_data *cd) {
-  CFDP_ASSERT(gp->connectivity == 7 || gp->connectivity == 3);
+  CFDP_ASSERT(gp->connectivity == 7 || gp->connectivity == 3 || gp->connectivity == CFDP_CONN_IRREGULAR);
   CFDP_ASSERT(domain >= 0 && domain < gp->ndomains);
-  const int ndir = gp->connectivity;
+  dirset D;
+  make_dirs(gp, &D);
+  const int ndir = D.n;
   const double h = 1.0 / (double)gp->nx;
   box_t *boxes = make_boxes(gp);
   const box_t B = boxes[domain];
-  /* expanded box (one layer), clipped to the lattice */
+  /* expanded box (as many layers as the directions reach), clipped to the lattice */
   box_t E = B;
   const int dim[3] = {gp->nx, gp->ny, gp->nz};
   for (int a = 0; a < 3; a++) {
-    if (E.lo[a] > 0) E.lo[a]--;
-    if (E.hi[a] < dim[a]) E.hi[a]++;
+    E.lo[a] = E.lo[a] - D.reach > 0 ? E.lo[a] - D.reach : 0;
+    E.hi[a] = E.hi[a] + D.reach < dim[a] ? E.hi[a] + D.reach : dim[a];
   }
   const int ex = E.hi[0] - E.lo[0], ey = E.hi[1] - E.lo[1], ez = E.hi[2] - E.lo[2];
   const size_t ne = (size_t)ex * ey * ez;
   int *slot = cfdp_malloc(ne * sizeof(int)); /* local id of each expanded-box point or -1 */
 #define EIDX(x, y, z) ((((size_t)(z)-E.lo[2]) * ey + ((y)-E.lo[1])) * ex + ((x)-E.lo[0]))
+#define IN_LATTICE(x, y, z) ((x) >= 0 && (y) >= 0 && (z) >= 0 && (x) < dim[0] && (y) < dim[1] && (z) < dim[2])
   const int nown = (B.hi[0] - B.lo[0]) * (B.hi[1] - B.lo[1]) * (B.hi[2] - B.lo[2]);
 
-  /* pass 1: own points, and ghosts = outside points adjacent (any direction, either
+  /* pass 1: own points, and ghosts = outside points joined by a face (any direction, either
    * orientation) to an own point; ghosts numbered in ascending global id               */
   int nadd = 0;
   for (int z = E.lo[2]; z < E.hi[2]; z++)
@@ -173,12 +255,17 @@ int cfdp_gen_domain(const cfdp_gen_params *gp, int domain, solver_data *sd, comm
       for (int x = E.lo[0]; x < E.hi[0]; x++) {
         int s = -1;
         if (in_box(&B, x, y, z)) {
-          s = box_local(&B, x, y, z);
+          s = file_id(gp, box_local(&B, x, y, z), nown);
         } else if (gp->ndomains > 1) {
           int adj = 0;
+          const long g = gid_of(gp, x, y, z);
           for (int d = 0; d < ndir && !adj; d++)
-            for (int sg = -1; sg <= 1 && !adj; sg += 2)
-              adj = in_box(&B, x + sg * DIRS[d][0], y + sg * DIRS[d][1], z + sg * DIRS[d][2]);
+            for (int sg = -1; sg <= 1 && !adj; sg += 2) {
+              const int x1 = x + sg * D.d[d][0], y1 = y + sg * D.d[d][1], z1 = z + sg * D.d[d][2];
+              if (!in_box(&B, x1, y1, z1)) continue;
+              const long g1 = gid_of(gp, x1, y1, z1);
+              adj = sg > 0 ? face_exists(gp, &D, g, g1, d) : face_exists(gp, &D, g1, g, d);
+            }
           if (adj) s = nown + nadd++;
         }
         slot[EIDX(x, y, z)] = s;
@@ -204,16 +291,18 @@ int cfdp_gen_domain(const cfdp_gen_params *gp, int domain, solver_data *sd, comm
         for (int x = E.lo[0]; x < E.hi[0]; x++) {
           int s0 = slot[EIDX(x, y, z)];
           if (s0 < 0) continue;
+          const long g0 = gid_of(gp, x, y, z);
           for (int d = 0; d < ndir; d++) {
-            int x1 = x + DIRS[d][0], y1 = y + DIRS[d][1], z1 = z + DIRS[d][2];
-            if (x1 >= E.hi[0] || y1 >= E.hi[1] || z1 >= E.hi[2]) continue;
+            int x1 = x + D.d[d][0], y1 = y + D.d[d][1], z1 = z + D.d[d][2];
+            if (x1 < E.lo[0] || y1 < E.lo[1] || x1 >= E.hi[0] || y1 >= E.hi[1] || z1 >= E.hi[2]) continue;
             int s1 = slot[EIDX(x1, y1, z1)];
             if (s1 < 0) continue;
             if (s0 >= nown && s1 >= nown && !gp->ghost_faces) continue;
+            if (!face_exists(gp, &D, g0, gid_of(gp, x1, y1, z1), d)) continue;
             if (pass == 1) {
               sd->fpoint[nf][0] = s0;
               sd->fpoint[nf][1] = s1;
-              face_normal(gp, gid_of(gp, x, y, z), d, h, sd->fnormal[nf]);
+              face_normal(gp, g0, d, h, sd->fnormal[nf]);
             }
             nf++;
           }
@@ -248,26 +337,30 @@ int cfdp_gen_domain(const cfdp_gen_params *gp, int domain, solver_data *sd, comm
           int k = owner_of(boxes, gp->ndomains, x, y, z, hint);
           CFDP_ASSERT(k >= 0 && k != domain);
           hint = k;
+          const box_t *K = &boxes[k];
           cd->addpoint_owner[s - nown] = k;
-          cd->addpoint_id[s - nown] = box_local(&boxes[k], x, y, z);
+          cd->addpoint_id[s - nown] = file_id(gp, box_local(K, x, y, z),
+                                              (long)(K->hi[0] - K->lo[0]) * (K->hi[1] - K->lo[1]) * (K->hi[2] - K->lo[2]));
           cd->recvcount[k]++;
         }
       }
-  /* sendcount[k]: own points adjacent to a point owned by k */
+  /* sendcount[k]: own points joined by a face to a point owned by k */
   if (nadd) {
     for (int z = B.lo[2]; z < B.hi[2]; z++)
       for (int y = B.lo[1]; y < B.hi[1]; y++)
         for (int x = B.lo[0]; x < B.hi[0]; x++) {
-          int interior = x > B.lo[0] && x < B.hi[0] - 1 && y > B.lo[1] && y < B.hi[1] - 1 &&
-                         z > B.lo[2] && z < B.hi[2] - 1;
+          int interior = x >= B.lo[0] + D.reach && x < B.hi[0] - D.reach && y >= B.lo[1] + D.reach && y < B.hi[1] - D.reach &&
+                         z >= B.lo[2] + D.reach && z < B.hi[2] - D.reach;
           if (interior) continue;
-          int seen[14], ns = 0;
+          const long g = gid_of(gp, x, y, z);
+          int seen[124], ns = 0;
           for (int d = 0; d < ndir; d++)
             for (int sg = -1; sg <= 1; sg += 2) {
-              int x1 = x + sg * DIRS[d][0], y1 = y + sg * DIRS[d][1], z1 = z + sg * DIRS[d][2];
-              if (x1 < 0 || y1 < 0 || z1 < 0 || x1 >= dim[0] || y1 >= dim[1] || z1 >= dim[2])
-                continue;
+              int x1 = x + sg * D.d[d][0], y1 = y + sg * D.d[d][1], z1 = z + sg * D.d[d][2];
+              if (!IN_LATTICE(x1, y1, z1)) continue;
               if (in_box(&B, x1, y1, z1)) continue;
+              const long g1 = gid_of(gp, x1, y1, z1);
+              if (!(sg > 0 ? face_exists(gp, &D, g, g1, d) : face_exists(gp, &D, g1, g, d))) continue;
               int k = owner_of(boxes, gp->ndomains, x1, y1, z1, hint);
               hint = k;
               int dup = 0;
@@ -292,14 +385,16 @@ int cfdp_gen_domain(const cfdp_gen_params *gp, int domain, solver_data *sd, comm
 }
 
 int cfdp_gen_global_ids(const cfdp_gen_params *gp, int domain, int *gid) {
-  const int ndir = gp->connectivity;
+  dirset D;
+  make_dirs(gp, &D);
+  const int ndir = D.n;
   box_t *boxes = make_boxes(gp);
   const box_t B = boxes[domain];
   box_t E = B;
   const int dim[3] = {gp->nx, gp->ny, gp->nz};
   for (int a = 0; a < 3; a++) {
-    if (E.lo[a] > 0) E.lo[a]--;
-    if (E.hi[a] < dim[a]) E.hi[a]++;
+    E.lo[a] = E.lo[a] - D.reach > 0 ? E.lo[a] - D.reach : 0;
+    E.hi[a] = E.hi[a] + D.reach < dim[a] ? E.hi[a] + D.reach : dim[a];
   }
   const int nown = (B.hi[0] - B.lo[0]) * (B.hi[1] - B.lo[1]) * (B.hi[2] - B.lo[2]);
   int nadd = 0;
@@ -307,12 +402,17 @@ int cfdp_gen_global_ids(const cfdp_gen_params *gp, int domain, int *gid) {
     for (int y = E.lo[1]; y < E.hi[1]; y++)
       for (int x = E.lo[0]; x < E.hi[0]; x++) {
         if (in_box(&B, x, y, z)) {
-          gid[box_local(&B, x, y, z)] = (int)gid_of(gp, x, y, z);
+          gid[file_id(gp, box_local(&B, x, y, z), nown)] = (int)gid_of(gp, x, y, z);
         } else if (gp->ndomains > 1) {
           int adj = 0;
+          const long g = gid_of(gp, x, y, z);
           for (int d = 0; d < ndir && !adj; d++)
-            for (int sg = -1; sg <= 1 && !adj; sg += 2)
-              adj = in_box(&B, x + sg * DIRS[d][0], y + sg * DIRS[d][1], z + sg * DIRS[d][2]);
+            for (int sg = -1; sg <= 1 && !adj; sg += 2) {
+              const int x1 = x + sg * D.d[d][0], y1 = y + sg * D.d[d][1], z1 = z + sg * D.d[d][2];
+              if (!in_box(&B, x1, y1, z1)) continue;
+              const long g1 = gid_of(gp, x1, y1, z1);
+              adj = sg > 0 ? face_exists(gp, &D, g, g1, d) : face_exists(gp, &D, g1, g, d);
+            }
           if (adj) gid[nown + nadd++] = (int)gid_of(gp, x, y, z);
         }
       }

@@ -30,6 +30,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+int cfdp_tile_class_of(int tile_points, int rows, long blob_bytes) { return cfdp_tile_class(tile_points, rows, blob_bytes); }
+
 void cfdp_plan_default_opts(cfdp_plan_opts *o) {
   o->tile_points = 64;
   o->boundary_first = 1;

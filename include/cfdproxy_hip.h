@@ -302,6 +302,11 @@ int  cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mod
  * the pass; a diagnostic instantiation), timed as cfdp_gpu_time_fused times the real one; ms_pass = milliseconds per
  * pass.  grad / flux hold one correct iteration afterwards.                                                       */
 int  cfdp_gpu_time_fused_movement(cfdp_gpu *g, int iters, float *ms_pass);
+/* which kernel forms ran: every launch of a face-loop kernel made by the calling thread since the last call is appended to a
+ * log, "form@first_tile+tiles" separated by blanks (e.g. "fused_split<6,4,3,4>listed@0+4124 flux_dma<3,2>@4124+5") --
+ * what bench.py prints beside a roofline figure so that a number says which instantiation it belongs to.  Copies the log
+ * into buf (truncated to len - 1 characters), clears it, returns the number of launches it covered.                  */
+int  cfdp_gpu_kernel_forms(char *buf, size_t len);
 /* capture + instantiate the graphs cfdp_gpu_run_iterations(g, iters, ...) will replay; nothing
  * executes (keeps the capture out of a caller's timed region)                                  */
 int  cfdp_gpu_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode);

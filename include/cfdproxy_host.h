@@ -27,13 +27,18 @@ typedef struct {
   int nx, ny, nz;          /* lattice points per axis                                     */
   int ndomains;            /* recursive-coordinate-bisection partitions                    */
   int connectivity;        /* 7: Freudenthal/Kuhn edges (F6-like, ~6.8 faces/point);       */
-                           /* 3: Cartesian edges (known-answer mesh)                       */
+                           /* 3: Cartesian edges (known-answer mesh);                      */
+                           /* CFDP_CONN_IRREGULAR: the edge graph of a random               */
+                           /* tetrahedralisation of the lattice's cubes + a hub point every  */
+                           /* 1024: ~7 faces/point, 8 to 24 incidences per point, hubs of 60 */
   int normals;             /* 0: lattice normals h^2*e_d ; 1: N(0,1)^3 * h^2 (hash-seeded) */
   int volumes;             /* 0: h^3 ; 1: U(0.5,2)*h^3 (hash-seeded)                       */
   int ghost_faces;         /* 1: also store faces between two ghost points                 */
   int cdf_version;         /* 1 or 2                                                       */
   uint64_t seed;
+  int numbering;           /* 0: a domain's points numbered along x, y, z; 1: scrambled      */
 } cfdp_gen_params;
+enum { CFDP_CONN_IRREGULAR = 62 };
 
 /* fill `sd` (mesh arrays, fields = 1.0) and `cd` (halo topology) for one domain, in memory */
 int  cfdp_gen_domain(const cfdp_gen_params *gp, int domain, solver_data *sd, comm_data *cd);
@@ -164,6 +169,7 @@ static inline int cfdp_tile_class(int tile_points, int rows, long blob_bytes) {
   if (blob_bytes <= 6 * block * 16 && rows <= block) return CFDP_TILE_LARGE;
   return CFDP_TILE_GENERIC;
 }
+int cfdp_tile_class_of(int tile_points, int rows, long blob_bytes); /* the same, callable through the ABI */
 
 void cfdp_plan_default_opts(cfdp_plan_opts *o);
 cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *o);

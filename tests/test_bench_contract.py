@@ -55,6 +55,19 @@ def test_bench_line(gpu):
         assert e["flag_notification"]["wait_timeouts"] == 0 and 0.5 < e["flag_notification"]["steps20_ratio"] <= 1.05, e
         r_ = e["rccl_self_sendrecv"]
         assert "error" in r_ or (r_["rccl_nranks"] == 1 and r_["steps20_with_exchange"] > 0), r_
+    # the same kernels on an irregular mesh of the same size (the lattice is the best case): three fractions, the floor, the
+    # tiles the tiler made of it and which kernel instantiations ran
+    im = out["irregular_mesh"]
+    assert "error" not in im, im
+    assert im["points"] == 262144 and 6.5 < im["faces_per_point"] < 7.2 and im["incidences_per_point"]["max"] >= 40, im
+    assert im["points_per_tile"] > 56 and im["tiles"] < 4700 and im["launch_groups"][0]["class"] in ("small", "large"), im
+    assert 0 < im["fused"]["frac_unique"] < im["fused"]["frac"] < 1 and 0 < im["gradient_kernel"]["frac"] < 1, im
+    assert 0 < im["fused"]["movement_only_us"] < im["fused"]["us_per_launch"], im
+    assert any(f.startswith("fused_split<") for f in im["kernel_forms"]) and not any("generic" in f for f in im["kernel_forms"]), im
+    assert 0.9 < im["lattice_over_irregular"]["fused_frac"] < 1.6, im
+    # what stood in front of the timed region is in `config` too (the part of the line a driver's record keeps)
+    assert out["config"]["unconditioned_value"] == cc["unconditioned_value"] and out["config"]["untimed_steps_in_front_of_the_timed_region"] >= 110
+    assert "cgroup" in cb["cores_note"]
     # one rank, one device, nothing shared; the CFDP_* variables the run saw are in the line
     assert out["shared_gpu"] is False and out["config"]["distinct_devices"] == 1 and len(out["config"]["device_of_rank"]) == 1
     assert isinstance(out["config"]["env"], dict) and all(k.startswith("CFDP_") for k in out["config"]["env"])

@@ -291,6 +291,16 @@ def test_abi_error_paths(gpu):
     with pytest.raises(pkg.GpuError):
         part.flux(mode=5)
     part.close()
+    # a tile size the kernels cannot launch (points x lanes per point > 1024 threads) is refused at upload, with a message
+    # that says so -- not as "invalid configuration argument" from the first flux launch
+    for tp, gl, fl in ((256, 4, 8), (192, 0, 0), (216, 8, 4)):
+        with pytest.raises(pkg.GpuError, match="threads per workgroup"):
+            pkg.GpuPartition(dom, tile_points=tp, grad_lanes=gl, flux_lanes=fl)
+    part = pkg.GpuPartition(dom, tile_points=216, grad_lanes=4, flux_lanes=4)  # 216 points x 4 lanes: fine
+    with pytest.raises(pkg.GpuError, match="threads per workgroup"):
+        part.set_variant(4, 8)
+    part.gradients()
+    part.close()
     dom.free()
 
 
@@ -1040,8 +1050,18 @@ def test_hub_point_with_hundreds_of_faces(gpu, orc, nleaf):
     for fusion in (False, True):
         dom = pkg.domain_from_arrays(fp, fn, vol, n, var=var)
         part = pkg.GpuPartition(dom)
+        # the hub's tile is in a launch group of its own, LAST: the chain's tiles keep the fixed-capacity kernels
+        groups = part.stats["groups"]
+        assert len(groups) == 2 and groups[0][2] < 2 and groups[1][2] == 2 and groups[1][1] - groups[1][0] <= 2, groups
         part.set_fusion(fusion)
+        pkg.kernel_forms()
         part.run_iterations(2, True, 0, use_graph=False)
+        forms = pkg.kernel_forms().split()
+        first = [f for f in forms if f"@0+{groups[0][1]}" in f]
+        assert first and all("_dma<" in f or "fused_split<" in f for f in first), forms
+        assert any("generic" in f and f"@{groups[1][0]}+" in f for f in forms), forms
+        if fusion:
+            assert any(f.startswith("fused_split<") for f in first), forms
         part.pull_fields()
         assert rel_err(orc, dom.grad, ref, fp, fn, vol, var, n) <= TOL, fusion
         fref = orc.np_flux(fp, fn, dom.grad, n, mode=0)
@@ -1231,6 +1251,58 @@ def test_unstructured_delaunay_mesh_partitioned_with_halo_exchange(gpu, orc, nd)
             gp_.close()
     for dom in doms:
         dom.free()
+
+
+@pytest.mark.parametrize("G", [1, 2])
+def test_irregular_generator_mesh_against_the_oracle(gpu, orc, G):
+    """the generator's irregular option (host/dualgrid_gen.c: the edge graph of a random tetrahedralisation, 8 to 24
+    incidences per point, hubs of 60+, scrambled file numbering) -- the mesh of bench.py's `irregular_mesh` block -- as 6
+    domain files -> loader -> G merged partitions (+ exchange): own rows, ghost rows and flux against the oracle on the
+    un-partitioned mesh; tiles fill up under the second capacity, the kernels are the fixed-capacity ones"""
+    pkg = gpu
+    dims, nd = (24, 20, 18), 6
+    gp = pkg.gen_params(*dims, ndomains=nd, connectivity=pkg.CONN_IRREGULAR, numbering=1)
+    whole = pkg.gen_domain(pkg.gen_params(*dims, ndomains=1, connectivity=pkg.CONN_IRREGULAR), 0)
+    pkg.fill_var(whole, None, pkg.VAR_HASH, *dims)
+    deg = np.bincount(whole.fpoint.ravel(), minlength=whole.nown)
+    assert 12.0 < deg.mean() < 14.5 and deg.max() >= 40 and deg.min() <= 8  # what "irregular" means here (a small mesh: the surface counts)
+    ref = orc.CpuRef(whole.fpoint, whole.fnormal, whole.pvolume, whole.nown, nthreads=4)
+    truth = ref.gradients(whole.var)
+    ftruth = ref.flux(truth, mode=0)
+    ref.close()
+    wscale = whole_mesh_scale(orc, truth, whole.fpoint, whole.fnormal, whole.pvolume, whole.var)
+    from cfd_proxy_amd import multigpu as mg
+    parts = [mg.build_rank_partition(gp, nd, G, r, via_files=True)[0] for r in range(G)]
+    pkg.merge_link_group(parts)
+    for fusion in (False, True):
+        gparts = [pkg.GpuPartition(p) for p in parts]
+        for gp_ in gparts:
+            gp_.set_fusion(fusion)
+            interior = gp_.stats["ntiles"] - gp_.stats["nbtiles"]
+            assert p_own(gp_) / max(interior, 1) > 40  # tiles fill (the small image alone closes them at ~2/3)
+        pkg.kernel_forms()
+        for _ in range(3):
+            pkg.group_iteration(gparts, with_exchange=True, overlap=True, with_flux=True)
+        pkg.group_sync(gparts)
+        forms = pkg.kernel_forms()
+        assert "generic" not in forms and ("fused_split<" in forms) == fusion, forms
+        for r, (p, gp_) in enumerate(zip(parts, gparts)):
+            gp_.pull_fields()
+            ids = pkg.rank_domain_list(r, nd, G)
+            for dl, d in enumerate(ids):
+                dom = pkg.gen_domain(gp, d)
+                gid = pkg.gen_global_ids(gp, d, dom.nall)
+                back = pkg.merge_scatter(p, dl, dom.nall, p.grad)
+                assert rel_err_rows(back, truth[gid], wscale[gid]) <= TOL, (fusion, r, d)  # ghost rows included
+                fb = pkg.merge_scatter(p, dl, dom.nall, p.psd_flux)
+                assert np.abs(fb[: dom.nown] - ftruth[gid[: dom.nown]]).max() <= TOL * np.abs(ftruth).max(), (fusion, r, d)
+                dom.free()
+            gp_.close()
+    whole.free()
+
+
+def p_own(gpart):
+    return gpart.dom.nown
 
 
 def test_exchange_setup_helpers(gpu):

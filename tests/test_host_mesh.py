@@ -378,3 +378,99 @@ def test_stored_form_of_gradient_rows(pkg):
     # numbers the stress reads are within one more rounding
     again = pkg.stored_rows(back)
     assert np.array_equal(again[:, :3], e[:, :3]) and np.all(np.abs(again[:, 3:6] - e[:, 3:6]) <= ulp)
+
+
+# ------------------------------------------------------------------- irregular meshes (round 6)
+@pytest.mark.parametrize("dims,nd", [((12, 10, 9), 4), ((16, 12, 10), 6)])
+def test_irregular_generator_domains_are_consistent(pkg, orc, dims, nd):
+    """the generator's irregular option (the edge graph of a random tetrahedralisation of the lattice's cubes + hubs,
+    scrambled file numbering): every domain file holds exactly the faces of the whole mesh that touch its own points, with
+    the same normals; ghosts name their owner's point; halos are symmetric; degrees really vary"""
+    gp = pkg.gen_params(*dims, ndomains=nd, connectivity=pkg.CONN_IRREGULAR, numbering=1)
+    whole = pkg.gen_domain(pkg.gen_params(*dims, ndomains=1, connectivity=pkg.CONN_IRREGULAR, numbering=0), 0)
+    wf = {(int(a), int(b)): tuple(n) for (a, b), n in zip(whole.fpoint, whole.fnormal)}
+    deg = np.bincount(whole.fpoint.ravel(), minlength=whole.nown)
+    assert deg.max() - deg.min() >= 12 and 5.5 < whole.nfaces / whole.nown < 7.5  # (small meshes: the surface counts)
+    doms = [pkg.gen_domain(gp, d) for d in range(nd)]
+    gids = [pkg.gen_global_ids(gp, d, doms[d].nall) for d in range(nd)]
+    own_gid = np.concatenate([gids[d][: doms[d].nown] for d in range(nd)])
+    assert len(np.unique(own_gid)) == len(own_gid) == dims[0] * dims[1] * dims[2]
+    scrambled = False
+    for d, dom in enumerate(doms):
+        g = gids[d]
+        scrambled = scrambled or not np.array_equal(g[: dom.nown], np.sort(g[: dom.nown]))
+        mine = {(int(g[a]), int(g[b])): tuple(n) for (a, b), n in zip(dom.fpoint, dom.fnormal)}
+        own = set(int(x) for x in g[: dom.nown])
+        assert mine == {e: n for e, n in wf.items() if e[0] in own or e[1] in own}
+        owner, idx = dom.addpoint_owner(), dom.addpoint_id()
+        for j in range(dom.nall - dom.nown):
+            assert gids[owner[j]][idx[j]] == g[dom.nown + j] and idx[j] < doms[owner[j]].nown
+        for k in range(nd):
+            assert dom.cd.sendcount[k] == doms[k].cd.recvcount[d]
+        assert np.array_equal(dom.pvolume, whole.pvolume[g])
+    assert scrambled
+    for dom in doms:
+        dom.free()
+    whole.free()
+
+
+def test_tiles_of_irregular_meshes_fill_up_and_hub_tiles_go_last(pkg):
+    """two-level tile budgets and launch groups (host/tiling.c 3e): on an irregular graph the small image alone would close
+    tiles at ~2/3 of their points; a tile it closes below 7/8 full goes on under the large image.  A tile no fixed
+    capacity holds (a hub of hundreds of faces) is moved to the end, into a group of its own; the lattice stand-in stays
+    one group of small tiles"""
+    def classes(plan, tp=64):
+        return [pkg.host_lib().cfdp_tile_class_of(tp, plan.tile(t).npts + plan.tile(t).nhalo, plan.tile(t).blob_qw * 16)
+                for t in range(plan.ntiles)]
+    lat = pkg.gen_domain(pkg.gen_params(24, 20, 18, ndomains=1), 0)
+    plan = pkg.Plan(lat)
+    assert plan.ngroups == 1 and plan.group_begin[0] == 0 and plan.group_begin[1] == plan.ntiles and plan.group_class[0] == 0
+    assert set(classes(plan)) == {0}
+    plan.free()
+    lat.free()
+    irr = pkg.gen_domain(pkg.gen_params(32, 32, 32, ndomains=1, connectivity=pkg.CONN_IRREGULAR, numbering=1), 0)
+    plan = pkg.Plan(irr)
+    cls = classes(plan)
+    assert plan.ngroups == 1 and plan.group_class[0] == 1 and 2 not in cls and cls.count(1) > plan.ntiles // 2
+    assert irr.nown / plan.ntiles > 56  # ... and the tiles are full
+    os.environ["CFDP_TILE_BUDGET"] = "1"  # the small image only
+    try:
+        small = pkg.Plan(irr)
+    finally:
+        del os.environ["CFDP_TILE_BUDGET"]
+    assert irr.nown / small.ntiles < 0.9 * irr.nown / plan.ntiles and set(classes(small)) == {0}
+    small.free()
+    plan.free()
+    irr.free()
+    # a star of 300 leaves + a chain through them: the hub's tile fits no fixed capacity
+    n = 301
+    fp = np.concatenate([np.stack([np.zeros(300, np.int32), np.arange(1, n, dtype=np.int32)], 1),
+                         np.stack([np.arange(1, n - 1, dtype=np.int32), np.arange(2, n, dtype=np.int32)], 1)]).astype(np.int32)
+    rng = np.random.default_rng(5)
+    dom = pkg.domain_from_arrays(fp, rng.standard_normal((len(fp), 3)), rng.uniform(0.5, 2.0, n), n)
+    plan = pkg.Plan(dom)
+    cls = classes(plan)
+    assert plan.ngroups == 2 and plan.group_class[1] == 2 and plan.group_class[0] < 2
+    assert plan.group_begin[0] == 0 and plan.group_begin[2] == plan.ntiles
+    assert all(c < 2 for c in cls[: plan.group_begin[1]]) and all(c == 2 for c in cls[plan.group_begin[1]:])
+    cover = np.zeros(n, int)
+    for t in range(plan.ntiles):
+        cover[plan.tile(t).pstart: plan.tile(t).pstart + plan.tile(t).npts] += 1
+    assert (cover == 1).all()
+    plan.free()
+    dom.free()
+
+
+def test_points_of_a_tile_are_ordered_by_degree(pkg):
+    """inside a tile, points of like degree sit next to each other (host/tiling.c 3d): a wave is busy for as long as its
+    longest incidence list takes"""
+    irr = pkg.gen_domain(pkg.gen_params(20, 18, 16, ndomains=1, connectivity=pkg.CONN_IRREGULAR), 0)
+    plan = pkg.Plan(irr)
+    deg = np.ctypeslib.as_array(plan.p.degree, shape=(plan.nown,))
+    for t in range(plan.ntiles):
+        td = plan.tile(t)
+        d = deg[td.pstart: td.pstart + td.npts]
+        assert (np.diff(d) <= 0).all(), t
+    assert np.array_equal(deg, np.bincount(irr.fpoint.ravel(), minlength=irr.nown)[plan.new2old[: irr.nown]])
+    plan.free()
+    irr.free()

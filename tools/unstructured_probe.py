@@ -8,9 +8,11 @@ from __graft_entry__ import load_package
 from unstructured import delaunay_mesh
 m = load_package()
 n = int(os.environ.get("NPTS", "262144"))
-if os.environ.get("LATTICE"):  # the lattice stand-in of that size instead (regression check of a tiler change)
-    nx = int(os.environ["LATTICE"])
-    dom = m.gen_domain(m.gen_params(nx, ndomains=1), 0)
+if os.environ.get("LATTICE") or os.environ.get("IRREGULAR"):  # the lattice stand-in of that size instead (regression check of a
+    # tiler change), or the generator's irregular option (the mesh of bench.py's irregular_mesh block)
+    nx = int(os.environ.get("LATTICE") or os.environ["IRREGULAR"])
+    dom = m.gen_domain(m.gen_params(nx, ndomains=1, connectivity=m.CONN_IRREGULAR if os.environ.get("IRREGULAR") else 7,
+                                    numbering=1 if os.environ.get("IRREGULAR") else 0), 0)
     n = dom.nown
     m.fill_var(dom, None, m.VAR_HASH)
     nfaces = dom.nfaces
