@@ -726,7 +726,7 @@ def main() -> None:
                     g8 = pkg.GpuPartition(parts8[0], device=device)
                     g8.set_fusion(True)
                     rlib = mg.RankSolver.torch_rccl_path()
-                    g8.rccl_init(pkg.GpuPartition.rccl_unique_id(rlib), 1, 0, rank_of_partner=[0] * len(g8.partners()), libpath=rlib)
+                    g8.rccl_init(pkg.GpuPartition.rccl_unique_id(rlib), 1, 0, rank_of_partner=[0] * len(g8.partners()), libpath=rlib, self_exchange=True)
                     run = lambda n, **kw: g8.run_steps_rccl(n, **kw)
                     rfree = lb_time(run, g8.sync, 500, 2, with_exchange=False, overlap=True)
                     rexch = lb_time(run, g8.sync, 500, 2, with_exchange=True, overlap=True)

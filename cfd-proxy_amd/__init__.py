@@ -263,6 +263,7 @@ def _declare_hip(lib: C.CDLL) -> None:
     lib.cfdp_rccl_load.argtypes = [C.c_char_p]
     lib.cfdp_rccl_unique_id.argtypes = [vp]
     lib.cfdp_gpu_rccl_init.argtypes = [vp, vp, C.c_int, C.c_int, P(C.c_int)]
+    lib.cfdp_gpu_rccl_allow_self_exchange.argtypes = [vp, C.c_int]
     lib.cfdp_gpu_rccl_finalize.argtypes = [vp]
     lib.cfdp_gpu_step_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.cfdp_gpu_run_steps_rccl.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -818,8 +819,12 @@ class GpuPartition:
             raise GpuError(lib.cfdp_gpu_last_error().decode())
         return buf.raw
 
-    def rccl_init(self, unique_id: bytes, nranks: int, rank: int, rank_of_partner=None, libpath: str = "") -> None:
+    def rccl_init(self, unique_id: bytes, nranks: int, rank: int, rank_of_partner=None, libpath: str = "",
+                  self_exchange: bool = False) -> None:
+        """self_exchange: measurements / plumbing tests only -- a communicator of ONE rank exchanges with itself
+        (cfdp_gpu_rccl_allow_self_exchange); refused otherwise"""
         self._ck(self.lib.cfdp_rccl_load(libpath.encode()))
+        self._ck(self.lib.cfdp_gpu_rccl_allow_self_exchange(self.h, 1 if self_exchange else 0))
         rp = None
         if rank_of_partner is not None:
             rp = (C.c_int * len(rank_of_partner))(*rank_of_partner)

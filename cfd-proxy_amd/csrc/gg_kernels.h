@@ -136,8 +136,11 @@ hipError_t gg_launch_unpack(const double *recvbuf, int nrecv, const gg_grad_view
 enum { GG_ROW_STRIDE = 208, GG_ROW_STRIDE_LARGE = 272 };
 enum { GG_DONE_STRIDE = 32 };  // the completion counters of push_tile_done sit on cache lines of their own (atomics of hundreds of tiles)
 // hdr (ints): partner slot s owns the cache line [s * SLOT_STRIDE, (s + 1) * SLOT_STRIDE): word 0 its arrival flag /
-// counter (written by partner s only -- seven devices never store to one line), word GG_IPC_NEED_IN how many of its
-// boundary tiles count per exchange (written once by the partner's host at set-up); behind the slot lines [ITER] this
+// counter (written by partner s only -- seven devices never store to one line), word GG_IPC_NEED_IN what that word
+// advances by per exchange: the partner's boundary tiles that count towards this rank when it notifies by counters, 1
+// when it stores its exchange number (written once by the partner at set-up) -- a waiting rank compares the word with
+// exchanges x NEED_IN whatever ITS OWN form of notification is, so neighbours that resolved to different forms (the
+// per-partner protocol depends on a rank's own partition) still understand each other; behind the slot lines [ITER] this
 // rank's exchanges so far (flag notification) and [ERR .. ERR + 4] a wait gave up
 enum { GG_IPC_MAXSLOTS = 48, GG_IPC_SLOT_STRIDE = 32, GG_IPC_NEED_IN = 1, GG_IPC_ITER = GG_IPC_MAXSLOTS * GG_IPC_SLOT_STRIDE,
        GG_IPC_ERR = GG_IPC_ITER + 1, GG_IPC_HDR_BYTES = 8192 };

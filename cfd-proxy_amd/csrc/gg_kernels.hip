@@ -449,8 +449,10 @@ __device__ __forceinline__ void wait_previous_exchange(const gg_push_args &pa, i
   if (mine && !pa.hdr[GG_IPC_ERR]) {
     // flag notification: partner s has stored its exchange number.  Counter notification: s's boundary tiles have each
     // added 1 for every exchange they completed for this rank, NEED_IN of them per exchange (compared wrap-safe)
+    // (what the word must reach is the SENDER's statement -- NEED_IN: its boundary tiles that count per exchange when it
+    // notifies by counters, 1 when it stores its exchange number -- so a rank need not know which form a neighbour resolved to)
     const int *slot = pa.hdr + tid * GG_IPC_SLOT_STRIDE;
-    const int need = pa.counters ? iter0 * __hip_atomic_load(&slot[GG_IPC_NEED_IN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : iter0;
+    const int need = iter0 * __hip_atomic_load(&slot[GG_IPC_NEED_IN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     bool ok = false;
     // RELAXED system-scope polls (global_load_dword ... sc0 sc1, past every cache): an acquire per poll is a cache
     // invalidate per poll (MI355X_MICROARCH.md: polling with acquire loads is 2-3x slower per hop and many pollers cut
@@ -512,7 +514,7 @@ __device__ __forceinline__ void wait_check(const gg_push_args &pa, int tile, int
     const bool mine = pa.wait_polls > 0 && tid < pa.nslots && ((w.mask >> tid) & 1ull);
     if (mine && !w.err) {
       const int *slot = pa.hdr + tid * GG_IPC_SLOT_STRIDE;
-      const int need = pa.counters ? iter0 * nin : iter0;
+      const int need = iter0 * nin;  // nin: what the SENDER says its word advances by per exchange (see wait_previous_exchange)
       bool ok = (int)((unsigned)word - (unsigned)need) >= 0;
       for (long k = 0; k < pa.wait_polls && !ok; k++) {  // the partner IS late: poll on (relaxed, see wait_previous_exchange)
         __builtin_amdgcn_s_sleep(32);
@@ -1282,8 +1284,7 @@ __global__ void gg_wait_kernel(int *__restrict__ hdr, int nslots, long max_polls
   if ((int)threadIdx.x >= nslots) return;
   if (hdr[GG_IPC_ERR]) return;  // a wait has given up before: the run is void anyway, do not stall every step
   int *slot = hdr + threadIdx.x * GG_IPC_SLOT_STRIDE;
-  const int need = tile_iter ? tile_iter[0] * __hip_atomic_load(&slot[GG_IPC_NEED_IN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                             : hdr[GG_IPC_ITER];
+  const int need = (tile_iter ? tile_iter[0] : hdr[GG_IPC_ITER]) * __hip_atomic_load(&slot[GG_IPC_NEED_IN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   for (long k = 0; k < max_polls; k++) {
     if ((int)((unsigned)__hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (unsigned)need) >= 0) return;
     __builtin_amdgcn_s_sleep(32);  // ~1 us between polls: the flag line is not hammered

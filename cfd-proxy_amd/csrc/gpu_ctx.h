@@ -94,6 +94,7 @@ struct cfdp_gpu {
   // one process per GPU: this rank's RCCL communicator and the communicator rank of every partner
   ncclComm_t comm = nullptr;
   int comm_nranks = 0;  // ncclCommCount of `comm`
+  bool rccl_self_exchange = false;  // cfdp_gpu_rccl_allow_self_exchange: a one-rank communicator may exchange with itself (measurements)
   std::vector<int> peer;
   // xGMI write + notify exchange (cfdp_gpu_ipc_*): this rank's IPC block [header | landing arena 0
   // | landing arena 1] -- partners write their rows and their arrival counters into it -- and the

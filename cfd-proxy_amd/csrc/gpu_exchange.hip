@@ -123,13 +123,17 @@ struct rccl_api {
 
 // this iteration's messages: sends from the packed arena, receives into the current ghost block
 int enqueue_exchange(cfdp_gpu *g) {
+  if (g->comm_nranks == 1 && !g->partner.empty() && !g->rccl_self_exchange)
+    return fail("the communicator has ONE rank: this exchange would send every partner's rows to the rank itself (for loopback "
+                "measurements say so first: cfdp_gpu_rccl_allow_self_exchange)");
   RCCL_TRY(rccl.GroupStart());
   for (size_t s = 0; s < g->partner.size(); s++) {
     size_t sb = 0, rb = 0;
     void *sp = cfdp_gpu_send_ptr(g, (int)s, &sb), *rp = cfdp_gpu_recv_ptr(g, (int)s, &rb);
-    // MEASUREMENT ONLY: a communicator of ONE rank exchanges with itself (the fall-back transport priced on one GPU,
-    // bench.py's loopback table; the plumbing test): a send must then meet a receive of its own length
-    if (g->comm_nranks == 1) sb = rb = sb < rb ? sb : rb;
+    // MEASUREMENT ONLY, asked for by name (cfdp_gpu_rccl_allow_self_exchange): a communicator of ONE rank exchanges with
+    // itself (the fall-back transport priced on one GPU, bench.py's loopback table; the plumbing test): a send must then
+    // meet a receive of its own length
+    if (g->comm_nranks == 1 && g->rccl_self_exchange) sb = rb = sb < rb ? sb : rb;
     if (sb) RCCL_TRY(rccl.Send(sp, sb / sizeof(double), ncclDouble, g->peer[s], g->comm, g->s_comm));
     if (rb) RCCL_TRY(rccl.Recv(rp, rb / sizeof(double), ncclDouble, g->peer[s], g->comm, g->s_comm));
   }
@@ -202,6 +206,11 @@ int cfdp_gpu_rccl_init(cfdp_gpu *g, const void *id128, int nranks, int rank, con
 
 // ranks in this context's RCCL communicator as ncclCommCount reports it; 0 without a communicator
 int cfdp_gpu_rccl_nranks(const cfdp_gpu *g) { return g && g->comm ? g->comm_nranks : 0; }
+int cfdp_gpu_rccl_allow_self_exchange(cfdp_gpu *g, int on) {
+  if (!g) return fail("null context");
+  g->rccl_self_exchange = on != 0;
+  return 0;
+}
 
 int cfdp_gpu_rccl_finalize(cfdp_gpu *g) {
   if (!g) return fail("null context");
@@ -556,6 +565,11 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
   HIP_TRY(hipMemcpy(I.d_slot_of_row, slot_of_row.data(), sizeof(int) * slot_of_row.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&I.d_send_off, sizeof(int) * g->send_off.size()));
   HIP_TRY(hipMemcpy(I.d_send_off, g->send_off.data(), sizeof(int) * g->send_off.size(), hipMemcpyHostToDevice));
+  // what this rank's word at partner s advances by per exchange: the boundary tiles that count towards s when it
+  // notifies by counters, 1 when it stores its exchange number (flags, every rung).  The partner's waits multiply by it
+  // whatever THEIR form is: the per-partner protocol depends on a rank's own partition, so neighbours may resolve to
+  // different forms and must still understand each other
+  std::vector<int> advance((size_t)(nslots ? nslots : 1), 1);
   {  // the send rows of every boundary tile: (tile-local point | slot << 16, row in the partner's slice)
     std::vector<int> tile_off((size_t)g->ntiles + 1, 0), ent(nsend ? nsend : 1, 0), ent_row(nsend ? nsend : 1, 0), tile_of(nsend ? nsend : 1, 0);
     bool ok = nslots <= 0x7FFF;
@@ -636,13 +650,7 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       I.counters = I.per_partner && want_counters;
       HIP_TRY(hipMalloc(&I.d_need, sizeof(int) * need.size()));
       HIP_TRY(hipMemcpy(I.d_need, need.data(), sizeof(int) * need.size(), hipMemcpyHostToDevice));
-      // ... and every partner learns how many of this rank's boundary tiles count per exchange towards it: word
-      // NEED_IN + (this rank's slot there) of ITS header, next to the counter word itself.  Written once, here; read by the
-      // partner's waits from its first exchanging step on -- the hosts meet between _ready and that step (every set-up in
-      // this repo validates collectively first; cfdproxy_hip.h says so for other hosts)
-      // (written from THIS device with system-scope stores, like every push: d_rflag / d_need are uploaded above)
-      HIP_TRY(gg_launch_poke(I.d_rflag, I.d_need, GG_IPC_NEED_IN, nslots, g->s_main));
-      HIP_TRY(hipStreamSynchronize(g->s_main));
+      if (I.counters) advance = need;
       HIP_TRY(hipMalloc(&I.d_tile_mask, sizeof(unsigned long long) * (smask.size() + 1)));
       if (!smask.empty())
         HIP_TRY(hipMemcpy(I.d_tile_mask, smask.data(), sizeof(unsigned long long) * smask.size(), hipMemcpyHostToDevice));
@@ -659,6 +667,20 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       I.fault_skip_wait = f && !strcmp(f, "skip_wait");
       if (I.fault_skip_wait) fprintf(stderr, "[cfdp] FAULT INJECTION: boundary tiles do not wait for the previous exchange (CFDP_IPC_FAULT)\n");
     }
+  }
+  if (nslots > 0 && nslots <= 64) {
+    // every partner learns it: word NEED_IN of this rank's slot line in ITS header, next to the arrival word itself.  Written
+    // once, here, from THIS device with system-scope stores like every push; read by the partner's waits from its first
+    // exchanging step on -- the hosts meet between _ready and that step (every set-up in this repo validates collectively
+    // first; cfdproxy_hip.h says so for other hosts)
+    int *d_advance = nullptr;
+    HIP_TRY(hipMalloc(&d_advance, sizeof(int) * advance.size()));
+    HIP_TRY(hipMemcpy(d_advance, advance.data(), sizeof(int) * advance.size(), hipMemcpyHostToDevice));
+    HIP_TRY(gg_launch_poke(I.d_rflag, d_advance, GG_IPC_NEED_IN, nslots, g->s_main));
+    HIP_TRY(hipStreamSynchronize(g->s_main));
+    (void)hipFree(d_advance);
+  } else if (nslots > 64) {
+    return fail("%d partners: the write + notify exchange is built for at most 64", nslots);
   }
   HIP_TRY(hipMalloc(&I.d_done, sizeof(int) * (GG_IPC_MAXSLOTS + 1) * GG_DONE_STRIDE));
   HIP_TRY(cfdp_memset_sync(I.d_done, 0, sizeof(int) * (GG_IPC_MAXSLOTS + 1) * GG_DONE_STRIDE));

@@ -259,6 +259,8 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
   /* attempts 6-8: the conservative rung on the same mappings -- push, notify and wait as kernels of their own with flags
    * (release / acquire at kernel boundaries) -- still ahead of RCCL, whose steps cannot be replayed from a hipGraph in this
    * ROCm (priced in loopback: 53 / 25 us per iteration against 73 / 65 us, dualgrid.384 / .192 partitions) */
+  char tried[9][200]; /* the resolved configurations validated so far, this attach */
+  int ntried = 0;
   for (int attempt = 0; try_ipc && attempt < 9; attempt++) {
     const int separate = attempt >= 6;
     const int mi = separate ? attempt - 6 : attempt / 2, counters = separate ? 0 : attempt % 2 == 0;
@@ -273,6 +275,24 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
       if (r == 0) printf("exchange: HIP IPC setup failed (%s): %s\n", what, cfdp_gpu_last_error());
       ipc_teardown(gpu);
       continue;
+    }
+    { /* what the library RESOLVED (bit 3 of cfdp_gpu_ipc_mode: notification by counters needs the per-partner protocol, which
+       * depends on a rank's own partition): the rung is named by what runs.  Ranks of different forms understand each other
+       * (the sender states what its word advances by, csrc/gg_kernels.h); a rung that resolves to one tried before is skipped */
+      const int mine = (cfdp_gpu_ipc_mode(gpu) >> 3) & 1;
+      int lo = 0, hi = 0;
+      MPI_Allreduce(&mine, &lo, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
+      MPI_Allreduce(&mine, &hi, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
+      snprintf(what, sizeof what, "%s, notification by %s%s", labels[mi], lo == hi ? (hi ? "counters" : "flags") : "counters on some ranks, flags on others",
+               separate ? ", push / notify / wait as kernels of their own" : "");
+      int dup = 0;
+      for (int k = 0; k < ntried; k++) dup |= !strcmp(tried[k], what);
+      if (dup) {
+        if (r == 0) printf("exchange: skipped (%s): resolves to a configuration already tried\n", what);
+        ipc_teardown(gpu);
+        continue;
+      }
+      if (ntried < 9) snprintf(tried[ntried++], sizeof tried[0], "%s", what);
     }
     cfdp_attach_ipc(sd);
     g_use_ipc = 1;

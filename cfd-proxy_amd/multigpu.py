@@ -384,6 +384,20 @@ class RankSolver:
         if not self._all_ok(ok):  # (also the barrier: nobody pushes before everybody is ready)
             self._ipc_off()
             raise RuntimeError("a rank could not map its partners' IPC blocks (%s)" % getattr(self, "_ipc_why", "other rank"))
+        # what the library RESOLVED on every rank (the per-partner protocol -- and with it notification by counters -- depends on
+        # a rank's own partition; neighbours of different forms understand each other: the sender states what its word
+        # advances by, csrc/gg_kernels.h): the rung is recorded under what really runs, and a rung whose resolved
+        # configuration has been tried already is not validated twice
+        forms = [None] * self.world
+        dist.all_gather_object(forms, self.gpu.ipc_mode().get("notify_by", "?").split(" ")[0])
+        resolved = forms[0] if len(set(forms)) == 1 else "mixed: " + ", ".join(f"{f} on rank {r}" for r, f in enumerate(forms))
+        asked = self._validating
+        self._validating = asked.split(",")[0] + f", notification by {resolved}" + (", push / notify / wait as kernels of their own" if "kernels of their own" in asked else "")
+        self.resolved_rungs = getattr(self, "resolved_rungs", [])
+        if self._validating in self.resolved_rungs:
+            self._ipc_off()
+            raise RuntimeError(f"resolves to a configuration already tried ({self._validating})")
+        self.resolved_rungs.append(self._validating)
         self.transport = "ipc"
         if not self.validate_exchange():
             self._ipc_off()

@@ -164,6 +164,11 @@ int  cfdp_gpu_step_post(cfdp_gpu *g, int with_flux, int flux_mode);
 int  cfdp_rccl_load(const char *libpath);
 int  cfdp_rccl_unique_id(void *id128);
 int  cfdp_gpu_rccl_init(cfdp_gpu *g, const void *id128, int nranks, int rank, const int *rank_of_partner);
+/* MEASUREMENT / PLUMBING ONLY: a communicator of ONE rank whose partner slots all map to rank 0 exchanges with ITSELF
+ * (how the RCCL fall-back is priced and its plumbing tested on a 1-GPU box); a send then meets a receive of its own
+ * length -- both are cut to the shorter of the two.  Off by default: an exchange on a one-rank communicator is refused
+ * with a message, not silently truncated.                                                                          */
+int  cfdp_gpu_rccl_allow_self_exchange(cfdp_gpu *g, int on);
 int  cfdp_gpu_rccl_finalize(cfdp_gpu *g);
 int  cfdp_gpu_rccl_nranks(const cfdp_gpu *g); /* ncclCommCount of the context's communicator; 0 without one */
 int  cfdp_gpu_exchange_rccl(cfdp_gpu *g);   /* between cfdp_gpu_step_pre and cfdp_gpu_step_post */

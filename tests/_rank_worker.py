@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--inject-early-read", action="store_true",
                     help="CFDP_IPC_FAULT=skip_wait is set: the comparison of final states must still pass, the scaled-field "
                          "check must see the ghost rows that were read one exchange early")
+    ap.add_argument("--notify-by-rank", default="",
+                    help="comma-separated counter / flag, one per rank: neighbours that resolved to DIFFERENT forms of "
+                         "notification (the per-partner protocol depends on a rank's own partition) must understand each other")
     ap.add_argument("--fail-first-validation", action="store_true",
                     help="the first exchange validation reports failure: the set-up must be torn down and retried")
     args = ap.parse_args()
@@ -50,6 +53,8 @@ def main():
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg, orc = load_package(), load_oracle()
+    if args.notify_by_rank:  # (read when multigpu is imported: a form named in the environment is the only one tried)
+        os.environ["CFDP_IPC_NOTIFY"] = args.notify_by_rank.split(",")[int(os.environ["RANK"])]
     from cfd_proxy_amd import multigpu as mg
 
     dims = tuple(int(x) for x in args.dims.split(","))
@@ -87,9 +92,9 @@ def main():
             env0 = {k: v for k, v in os.environ.items() if k.startswith("CFDP_IPC")}
             solver = mg.RankSolver(part, rank, world, 0, dist, transport="ipc", tile_points=32)
             # the rungs in order: counters then flags on a fine-grained block, then the next memory mode
-            assert solver.transport == "ipc" and calls == ["ipc / fine-grained block, counter notification",
-                                                           "ipc / fine-grained block, flag notification",
-                                                           "ipc / coarse-grained block, counter notification"], (solver.transport, calls)
+            assert solver.transport == "ipc" and calls == ["ipc / fine-grained block, notification by counters",
+                                                           "ipc / fine-grained block, notification by flags",
+                                                           "ipc / coarse-grained block, notification by counters"], (solver.transport, calls)
             m = solver.gpu.ipc_mode()
             assert m["memory"].startswith("coarse") and m["notify_by"].startswith("counters"), m
             # the attempts were configured by argument: the process environment is as the user left it
@@ -162,6 +167,9 @@ def main():
                 dist.destroy_process_group()
                 sys.exit(77)
             assert solver.transport == args.transport, solver.transport  # no silent fallback in the tests
+            if args.notify_by_rank:  # this rank really runs the form it was given; its neighbours run another
+                want = args.notify_by_rank.split(",")[rank]
+                assert solver.gpu.ipc_mode()["notify_by"].startswith("counters" if want == "counter" else "flags"), solver.gpu.ipc_mode()
             if args.transport == "ipc" and not args.mode_may_be_rejected:
                 # ... and no silent fall to a later RUNG either (round 5: a conservative rung behind the in-kernel ones
                 # masked a broken in-kernel push in every multi-rank test): the first rung attempted is the one accepted

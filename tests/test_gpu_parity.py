@@ -772,12 +772,14 @@ def test_driver_binary_vcycle(gpu, tmp_path):
 
 # ------------------------------------------------------------------ RCCL issued from the C library
 @pytest.mark.parametrize("fusion", [False, True])
-def test_rccl_exchange_from_c_library_self_sendrecv(gpu, fusion):
-    """plumbing of cfdp_gpu_step_rccl / cfdp_gpu_run_steps_rccl on ONE GPU: rank 0 of a 2-rank
-    decomposition exchanges with ITSELF (communicator of one rank, partner mapped to rank 0; the
-    cut is symmetric, so its send and receive counts match): its ghost rows must become its own
-    packed send rows -- through the run-time resolved RCCL, the comm stream and both grad buffers
-    of the fused mode"""
+def test_rccl_exchange_from_c_library_self_sendrecv(gpu, orc, fusion):
+    """the RCCL transport (grouped ncclSend / ncclRecv issued by the C library: what replaces exchange_dbl_mpi_send /
+    _post_recv + MPI_Waitall, src/exchange_data_mpi.c:96-166,199-284) on ONE GPU: rank 0 of a 2-rank decomposition exchanges
+    with ITSELF (communicator of one rank, partner mapped to rank 0, asked for by name; the cut is symmetric, so its send and
+    receive counts match).  What arrives in its ghost rows is compared with the ORACLE's gradient rows of its send points --
+    the CPU restatement run on the partition, not the GPU's own rows -- in the form a row is handed out in (stored_rows /
+    handed_out_rows), at the 1e-10 of every parity test; and, as plumbing, bit for bit with the rows the GPU packed --
+    through the run-time resolved RCCL, the comm stream and both grad buffers of the fused mode"""
     import torch
     pkg = gpu
     from cfd_proxy_amd import multigpu as mg
@@ -788,10 +790,21 @@ def test_rccl_exchange_from_c_library_self_sendrecv(gpu, fusion):
         mg.exchange_requests(p, r, 2, None, all_requests=reqs)
     part = parts[0]
     assert part.partners == [1] and len(part.sendindex(1)) == len(part.recvindex(1)) > 0
+    # the oracle on this partition: the gradient rows of its send points are what a partner's ghost rows must hold
+    ref = orc.CpuRef(part.fpoint, part.fnormal, part.pvolume, part.nown, nthreads=2)
+    g_ref = ref.gradients(part.var.copy())
+    ref.close()
+    si = part.sendindex(1)
+    want = pkg.handed_out_rows(pkg.stored_rows(g_ref[si].reshape(len(si), 21))).reshape(len(si), 7, 3)
+    scale = np.maximum(np.abs(g_ref), orc.np_scale(part.fpoint, part.fnormal, part.pvolume, part.var))[si]
     g = pkg.GpuPartition(part, tile_points=32)
     g.set_fusion(fusion)
     lib = mg.RankSolver.torch_rccl_path()
-    g.rccl_init(pkg.GpuPartition.rccl_unique_id(lib), 1, 0, rank_of_partner=[0], libpath=lib)
+    uid = pkg.GpuPartition.rccl_unique_id(lib)
+    g.rccl_init(uid, 1, 0, rank_of_partner=[0], libpath=lib)
+    with pytest.raises(pkg.GpuError, match="ONE rank"):  # not asked for by name: refused, not silently truncated
+        g.step_rccl(True, True, True)
+    g.lib.cfdp_gpu_rccl_allow_self_exchange(g.h, 1)
     for steps, overlap in ((1, True), (3, False), (14, True), (25, True)):
         part.grad[:] = -1.0
         g.push_fields()
@@ -805,6 +818,7 @@ def test_rccl_exchange_from_c_library_self_sendrecv(gpu, fusion):
         got = part.grad[part.recvindex(1)]
         assert np.abs(sent).max() > 0 and not np.any(sent == -1.0)
         assert np.array_equal(got, sent), (steps, overlap)
+        assert rel_err_rows(got, want, np.where(scale > 0, scale, 1.0)) <= TOL, (steps, overlap)  # ... and the oracle's rows
     g.close()
 
 

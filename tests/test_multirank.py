@@ -106,6 +106,19 @@ def test_multirank_xgmi_write_notify_other_rungs(gpu, env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("forms", ["counter,flag,counter", "flag,counter,flag,flag"])
+def test_neighbours_with_different_notification_forms_understand_each_other(gpu, forms):
+    """every rank decides counters or flags on its own (the per-partner protocol depends on its partition) and the two
+    forms store different things in a partner's word: tiles x exchanges, or the exchange number.  What a waiting rank
+    compares the word with is therefore the SENDER's statement (word NEED_IN of the slot line: what the word advances by
+    per exchange) -- mixed neighbourhoods pass every value check and the scaled-field check of every schedule, under skew.
+    (Round 5 only the set-up validation stood between a mixed neighbourhood and a silent stale read -- advisor finding.)"""
+    world = forms.count(",") + 1
+    extra = ["--gpu", "--transport", "ipc", "--notify-by-rank", forms, "--soak", "300"] + (["--dims", "16,16,12", "--ndomains", "8"] if world == 4 else ["--files"])
+    _launch(world, extra, extra_env={"CFDP_IPC_WAIT_INKERNEL": "1", "CFDP_IPC_JITTER_US": "30", "CFDP_EXPERIMENTS": "1"})
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world,mode", [(2, "coarse"), (2, "fine"), (2, "split"), (3, "coarse"), (4, "fine")])
 def test_scaled_field_check_sees_a_ghost_row_read_one_exchange_early(gpu, world, mode):
     """fault injection: CFDP_IPC_FAULT=skip_wait makes the boundary tiles of the fused pass read their ghost rows without

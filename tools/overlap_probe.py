@@ -19,7 +19,7 @@ print("send", len(part.sendindex(1)), "recv", len(part.recvindex(1)), flush=True
 g = pkg.GpuPartition(part)
 g.set_fusion(True)
 lib = mg.RankSolver.torch_rccl_path()
-g.rccl_init(pkg.GpuPartition.rccl_unique_id(lib), 1, 0, rank_of_partner=[0], libpath=lib)
+g.rccl_init(pkg.GpuPartition.rccl_unique_id(lib), 1, 0, rank_of_partner=[0], libpath=lib, self_exchange=True)
 def cost(tag, **kw):
     g.run_steps_rccl(50, **kw); g.sync(); t = time.perf_counter(); g.run_steps_rccl(500, **kw); t1 = time.perf_counter(); g.sync(); t2 = time.perf_counter()
     print("%-28s host %.1f us/step, total %.1f us/step" % (tag, (t1 - t) / 500 * 1e6, (t2 - t) / 500 * 1e6), flush=True)

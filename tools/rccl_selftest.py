@@ -22,7 +22,7 @@ lib = mg.RankSolver.torch_rccl_path()
 log("lib", lib)
 uid = pkg.GpuPartition.rccl_unique_id(lib)
 log("unique id ok")
-g.rccl_init(uid, 1, 0, rank_of_partner=[0], libpath=lib)
+g.rccl_init(uid, 1, 0, rank_of_partner=[0], libpath=lib, self_exchange=True)
 log("comm init ok")
 def check(tag):
     g.pull_fields()
