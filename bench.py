@@ -628,6 +628,7 @@ def main() -> None:
                 gi, fi = pi.time_kernels(500)
                 forms = pkg.kernel_forms()
                 bi, bif = pkg.algo_bytes_grad(di.nfaces, di.nown, 0), pkg.algo_bytes_flux(di.nfaces, di.nown, 0)
+                tri, tri_src = committed_traffic("irregular stand-in of the dualgrid.12 lvl 2 size (64^3 points)")
                 st = pi.stats
                 im = {"workload": "irregular stand-in of the dualgrid.12 lvl 2 size (64^3 points, random tetrahedralisation + hubs, scrambled "
                                   "numbering): 12 domain files -> loader -> merged on 1 GPU, no halo exchange",
@@ -637,7 +638,8 @@ def main() -> None:
                       "tiles": st["ntiles"], "points_per_tile": di.nown / st["ntiles"], "halo_rows_per_tile": st["nhalo"] / st["ntiles"],
                       "face_duplication": st["nfaces_dup"] / st["nfaces_used"], "blob_bytes": st["blob_bytes"],
                       "launch_groups": [{"tiles": [b, e], "class": ("small", "large", "generic")[c]} for b, e, c in st["groups"]],
-                      "gradient_kernel": fracs(bi, bi, None, gi), "flux_kernel": fracs(bif, bif, None, fi)}
+                      "gradient_kernel": fracs(bi, bi, tri.get("gg_gradient"), gi), "flux_kernel": fracs(bif, bif, tri.get("gg_flux"), fi),
+                      "traffic_source": tri_src}
                 if not args.no_fusion:
                     pi.set_fusion(True)
                     pi.time_fused(50)
@@ -645,7 +647,7 @@ def main() -> None:
                     fui = pi.time_fused(1000)
                     forms += " " + pkg.kernel_forms()
                     im["iterations_per_s"] = 1e3 / fui
-                    im["fused"] = fracs(bi + bif, bi + bif - 32.0 * di.nfaces, None, fui)
+                    im["fused"] = fracs(bi + bif, bi + bif - 32.0 * di.nfaces, tri.get("gg_fused"), fui)
                     try:
                         mvi = pi.time_fused_movement(500)
                         im["fused"]["movement_only_us"] = mvi * 1e3
@@ -656,10 +658,27 @@ def main() -> None:
                     # the lattice is the best case: by how much (same box, same process, same byte count per unit)
                     im["lattice_over_irregular"] = {"fused_frac": out["roofline"]["frac"] / im["fused"]["frac"],
                                                     "gradient_kernel_frac": grad_k["frac"] / im["gradient_kernel"]["frac"]}
-                im["kernel_forms"] = forms.split()
-                out["irregular_mesh"] = im
+                im["kernel_forms"] = list(dict.fromkeys(forms.split()))  # (each form once, in the order it first ran)
                 pi.close()
                 di.free()
+                # where part of the distance to the lattice goes: the same mesh WITHOUT its hub points (one point in 1024 with
+                # 60-75 incidences: a lane walks its point's whole list, so a hub's wave -- and the tile that waits for it --
+                # takes five times as long as its neighbours)
+                if not args.no_fusion:
+                    gph = pkg.gen_params(64, ndomains=12, connectivity=pkg.CONN_IRREGULAR, numbering=1, hubs=-1)
+                    dh, _ = mg.build_rank_partition(gph, 12, 1, 0, via_files=not args.no_files)
+                    ph = pkg.GpuPartition(dh, device=device, tile_points=args.tile_points, grad_lanes=args.grad_lanes, flux_lanes=args.flux_lanes)
+                    gh, fh = ph.time_kernels(300)
+                    ph.set_fusion(True)
+                    ph.time_fused(50)
+                    fuh = ph.time_fused(1000)
+                    bh, bhf = pkg.algo_bytes_grad(dh.nfaces, dh.nown, 0), pkg.algo_bytes_flux(dh.nfaces, dh.nown, 0)
+                    im["without_hub_points"] = {"faces": dh.nfaces, "incidences_max": int(np.bincount(dh.fpoint.ravel(), minlength=dh.nall)[: dh.nown].max()),
+                                                "fused_us_per_launch": fuh * 1e3, "fused_frac": (bh + bhf) / (fuh * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                "gradient_kernel_us_per_launch": gh * 1e3, "gradient_kernel_frac": bh / (gh * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    ph.close()
+                    dh.free()
+                out["irregular_mesh"] = im
             except Exception as e:  # the extra must never cost the line
                 out["irregular_mesh"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_loopback and not args.no_fusion:
@@ -719,6 +738,13 @@ def main() -> None:
                 # push, notify and wait as kernels of their own, flags, release / acquire at kernel boundaries
                 sep = loopback("flag", push_inkernel=False)
                 lb[name]["push_notify_wait_kernels"] = {k: sep[k] for k in keys}
+                # ... and MPI_Put's pattern between them (src/exchange_data_mpidma.c:93-127): the send arena packed by a kernel,
+                # one hipMemcpyAsync per partner slice into its landing slice, the notify kernel behind the copies
+                try:
+                    put = loopback("flag", push_inkernel="put")
+                    lb[name]["copy_engine_put"] = dict({k: put[k] for k in keys}, protocol=put["protocol"], graph_replay=put["graph_replay"])
+                except Exception as e:
+                    lb[name]["copy_engine_put"] = {"error": repr(e)[:200]}
                 # the fall-back branch priced on the same partition: grouped ncclSend / ncclRecv issued by the C library from
                 # the streams (RCCL cannot be captured into a hipGraph in this ROCm: replay hangs), a communicator of ONE rank
                 # exchanging with itself -- pack kernel + RCCL kernel + stream launches per iteration, no link crossed

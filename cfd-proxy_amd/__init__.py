@@ -95,7 +95,7 @@ class GenParams(C.Structure):
         ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("ndomains", C.c_int),
         ("connectivity", C.c_int), ("normals", C.c_int), ("volumes", C.c_int),
         ("ghost_faces", C.c_int), ("cdf_version", C.c_int), ("seed", C.c_uint64),
-        ("numbering", C.c_int),
+        ("numbering", C.c_int), ("hubs", C.c_int),
     ]
 
 
@@ -430,10 +430,10 @@ CONN_IRREGULAR = 62  # cfdproxy_host.h CFDP_CONN_IRREGULAR
 
 
 def gen_params(nx, ny=None, nz=None, ndomains=1, connectivity=7, normals=1, volumes=1,
-               ghost_faces=0, cdf_version=1, seed=20241, numbering=0) -> GenParams:
+               ghost_faces=0, cdf_version=1, seed=20241, numbering=0, hubs=0) -> GenParams:
     ny = nx if ny is None else ny
     nz = nx if nz is None else nz
-    return GenParams(nx, ny, nz, ndomains, connectivity, normals, volumes, ghost_faces, cdf_version, seed, numbering)
+    return GenParams(nx, ny, nz, ndomains, connectivity, normals, volumes, ghost_faces, cdf_version, seed, numbering, hubs)
 
 
 def gen_domain(gp: GenParams, domain: int) -> Domain:
@@ -866,7 +866,7 @@ class GpuPartition:
         m = self.lib.cfdp_gpu_ipc_mode(self.h)
         if m < 0:
             return {}
-        return {"push": "in the fused pass" if m & 1 else "push kernel", "wait": "in the fused pass" if m & 2 else "wait kernel",
+        return {"push": "in the fused pass" if m & 1 else ("pack kernel + one copy per partner slice (copy-engine put)" if m & 64 else "push kernel"), "wait": "in the fused pass" if m & 2 else "wait kernel",
                 "notify": "per partner" if m & 4 else "all partners by the last boundary tile",
                 "notify_by": "counters (fire-and-forget atomic adds)" if m & 8 else "flags",
                 "memory": ("coarse-grained", "fine-grained", "split: fine-grained flags, coarse-grained arenas")[(m >> 4) & 3]}
@@ -881,7 +881,7 @@ class GpuPartition:
             self.h, -1 if memory_mode is None else self.IPC_MODES[memory_mode],
             -1 if wait_inkernel is None else int(bool(wait_inkernel)),
             -1 if notify is None else {"counter": 1, "flag": 0}[notify],
-            -1 if push_inkernel is None else int(bool(push_inkernel))))
+            -1 if push_inkernel is None else (2 if push_inkernel == "put" else int(bool(push_inkernel)))))
 
     def ipc_graph_stats(self) -> dict:
         """steps of run_steps_ipc replayed from hipGraphs / launched from the streams, captures abandoned"""

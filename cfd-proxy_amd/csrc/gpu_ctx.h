@@ -132,6 +132,10 @@ struct cfdp_gpu {
     int *d_tile_xoff = nullptr;
     int pt_stride = 64;
     bool inkernel = false;   // the fused pass pushes and notifies by itself
+    // the copy-engine "put" rung (cfdp_gpu_ipc_configure push_inkernel = 2; the reference's MPI_Put variants,
+    // src/exchange_data_mpidma.c:93-127): rows are packed into the send arena by gg_pack_kernel and every partner's slice
+    // leaves as ONE hipMemcpyAsync into its landing slice, the notify kernel behind the copies on the same stream
+    bool put = false;
     // the latest exchange has been started but nothing on the main stream waits for its arrival yet: the
     // boundary tiles of the next pushing pass wait themselves (gg_push_args::wait_polls); anything else that
     // touches ghost rows first enqueues the wait kernel (ipc_settle)

@@ -284,7 +284,7 @@ extern "C++" void cfdp_detail::ipc_release(cfdp_gpu *g) {
   I.d_rng = nullptr; I.jitter_us = 0;
   I.d_pt_first = nullptr; I.d_tile_xoff = nullptr;
   I.d_slot_of_row = I.d_send_off = I.d_tile_off = I.d_ent = I.d_ent_row = nullptr;
-  I.inkernel = false;
+  I.inkernel = false; I.put = false;
   (void)hipFree(I.d_done); (void)hipFree(I.d_need); (void)hipFree(I.d_tile_mask); (void)hipFree(I.d_tile_iter);
   I.d_done = I.d_need = I.d_tile_iter = nullptr; I.d_tile_mask = nullptr; I.per_partner = false; I.counters = false;
   (void)hipFree(I.flags); I.flags = nullptr;
@@ -309,6 +309,24 @@ extern "C++" void cfdp_detail::ipc_push_args(cfdp_gpu *g, int par, gg_push_args 
 }
 
 namespace {
+// the rows of this exchange to the partners, then the notification, on `st`: the push kernel (stores over the IPC mappings),
+// or -- the put rung -- pack kernel + one copy per partner slice; either way the notify kernel behind it in stream order
+int ipc_send_rows(cfdp_gpu *g, const gg_grad_view &src, int par, hipStream_t st) {
+  auto &I = g->ipc;
+  const int nslots = (int)g->partner.size();
+  if (I.put) {
+    HIP_TRY(gg_launch_pack(g->d_sendidx, g->send_off.back(), src, g->d_sendbuf, st));
+    for (int s = 0; s < nslots; s++) {
+      const size_t n = (size_t)(g->send_off[s + 1] - g->send_off[s]) * 21 * sizeof(double);
+      if (n) HIP_TRY(hipMemcpyAsync(I.dst[par][s], g->d_sendbuf + (size_t)g->send_off[s] * 21, n, hipMemcpyDeviceToDevice, st));
+    }
+  } else {
+    HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], st));
+  }
+  HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, I.counters ? I.d_need : nullptr, I.d_tile_iter, g->nbtiles, st));
+  return 0;
+}
+
 int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
   const bool comm = with_exchange && !g->partner.empty();
   if (g->ipc.jitter_us > 0 && g->ipc.d_rng) {
@@ -328,7 +346,7 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
     if (fused) fused_done(g);
   } else {
     auto &I = g->ipc;
-    const int nslots = (int)g->partner.size(), par = (int)((I.xiter + 1) & 1);
+    const int par = (int)((I.xiter + 1) & 1);
     const gg_grad_view src = fused ? g->alt_view() : g->grad_view();  // the buffer this iteration's gradients go to
     int pushed = 0;
     if (fused && I.inkernel) {
@@ -350,15 +368,13 @@ int ipc_pre(cfdp_gpu *g, int with_exchange, int overlap) {
       // the same time (see cfdp_gpu_step_pre); the wait joins them
       if (fork_comm(g)) return 1;  // the comm stream forks off the main stream here
       if (grad_tiles(CFDP_TILES_BOUNDARY, g->s_comm)) return 1;
-      HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_comm));
-      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, I.counters ? I.d_need : nullptr, I.d_tile_iter, g->nbtiles, g->s_comm));
+      if (ipc_send_rows(g, src, par, g->s_comm)) return 1;
       HIP_TRY(hipEventRecord(g->ev_senddone, g->s_comm));
       if (grad_tiles(CFDP_TILES_INTERIOR, g->s_main)) return 1;
       HIP_TRY(hipStreamWaitEvent(g->s_main, g->ev_senddone, 0));
     } else {
       if (grad_tiles(CFDP_TILES_ALL, g->s_main)) return 1;
-      HIP_TRY(gg_launch_push(g->d_sendidx, g->send_off.back(), I.d_slot_of_row, I.d_send_off, src, I.d_dst[par], g->s_main));
-      HIP_TRY(gg_launch_notify(g->ipc_hdr(), I.d_rflag, nslots, I.counters ? I.d_need : nullptr, I.d_tile_iter, g->nbtiles, g->s_main));
+      if (ipc_send_rows(g, src, par, g->s_main)) return 1;
     }
     if (fused) fused_done(g);
     I.xiter++;  // from here on the ghost block is the arena this exchange lands in
@@ -426,11 +442,13 @@ static int ipc_open(cfdp_gpu *g, const void *handle64, unsigned char **base_out)
 //   wait_inkernel  1 the boundary tiles wait themselves, 0 wait kernel (CFDP_IPC_WAIT_INKERNEL; ranks sharing a device: 0)
 //   notify         1 counters (fire-and-forget atomic adds), 0 flags   (CFDP_IPC_NOTIFY=counter|flag)
 //   push_inkernel  1 the fused pass pushes and notifies itself, 0 push / notify / wait are kernels of their own -- the
-//                  conservative rung: release / acquire at kernel boundaries instead of inside a kernel (CFDP_IPC_INKERNEL)
+//                  conservative rung: release / acquire at kernel boundaries instead of inside a kernel (CFDP_IPC_INKERNEL);
+//                  2 the copy-engine put: pack kernel, one hipMemcpyAsync per partner slice into its landing slice, then
+//                  the notify kernel (the reference's MPI_Put variants, src/exchange_data_mpidma.c:93-127)
 int cfdp_gpu_ipc_configure(cfdp_gpu *g, int memory_mode, int wait_inkernel, int notify, int push_inkernel) {
   if (!g) return fail("null context");
   if (memory_mode < -1 || memory_mode > 2 || wait_inkernel < -1 || wait_inkernel > 1 || notify < -1 || notify > 1 ||
-      push_inkernel < -1 || push_inkernel > 1)
+      push_inkernel < -1 || push_inkernel > 2)
     return fail("cfdp_gpu_ipc_configure(%d, %d, %d, %d): out of range", memory_mode, wait_inkernel, notify, push_inkernel);
   g->ipc.cfg_mode = memory_mode;
   g->ipc.cfg_wait_inkernel = wait_inkernel;
@@ -537,11 +555,12 @@ int cfdp_gpu_ipc_connect_loopback(cfdp_gpu *g, int slot) {
 
 // what the exchange set up by cfdp_gpu_ipc_ready does: bit 0 the fused pass pushes and notifies itself, bit 1 its
 // boundary tiles wait themselves, bit 2 per-partner notification and wait masks, bit 3 notification by counters
-// (fire-and-forget atomic adds), bits 4-5 the memory mode (0 coarse, 1 fine, 2 split)
+// (fire-and-forget atomic adds), bits 4-5 the memory mode (0 coarse, 1 fine, 2 split), bit 6 the copy-engine put rung
 int cfdp_gpu_ipc_mode(const cfdp_gpu *g) {
   if (!g || !g->ipc.block) return -1;
   const auto &I = g->ipc;
-  return (I.inkernel ? 1 : 0) | (I.inkernel && I.wait_inkernel ? 2 : 0) | (I.per_partner ? 4 : 0) | (I.counters ? 8 : 0) | (I.mode << 4);
+  return (I.inkernel ? 1 : 0) | (I.inkernel && I.wait_inkernel ? 2 : 0) | (I.per_partner ? 4 : 0) | (I.counters ? 8 : 0) | (I.mode << 4) |
+         (I.put ? 64 : 0);
 }
 
 int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
@@ -626,7 +645,9 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       // the tiles push what they have just computed; a send point WITHOUT faces is computed by nobody
       // and its stored row must travel (as pack / the push kernel send it, and the reference's
       // exchange_dbl_copy_in, src/threads.c:791-813): such partitions keep the separate push kernel
-      I.inkernel = g->nbtiles > 0 && !g->faceless_send && (I.cfg_inkernel >= 0 ? I.cfg_inkernel != 0 : !(e && atoi(e) == 0));
+      const int how = I.cfg_inkernel >= 0 ? I.cfg_inkernel : (e ? atoi(e) : 1);  // 1 in the fused pass, 0 kernels of their own, 2 put
+      I.inkernel = g->nbtiles > 0 && !g->faceless_send && how == 1;
+      I.put = how == 2;
       const char *w = getenv("CFDP_IPC_WAIT_INKERNEL");  // 0: always a separate wait kernel (A/B timing)
       I.wait_inkernel = I.cfg_wait_inkernel >= 0 ? I.cfg_wait_inkernel != 0 : !(w && atoi(w) == 0);
       // per-partner notification needs: every boundary tile reads ghost rows only of partners it sends to (then the

@@ -259,18 +259,22 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
   /* attempts 6-8: the conservative rung on the same mappings -- push, notify and wait as kernels of their own with flags
    * (release / acquire at kernel boundaries) -- still ahead of RCCL, whose steps cannot be replayed from a hipGraph in this
    * ROCm (priced in loopback: 53 / 25 us per iteration against 73 / 65 us, dualgrid.384 / .192 partitions) */
-  char tried[9][200]; /* the resolved configurations validated so far, this attach */
+  char tried[12][200]; /* the resolved configurations validated so far, this attach */
   int ntried = 0;
-  for (int attempt = 0; try_ipc && attempt < 9; attempt++) {
+  /* attempts 9-11: MPI_Put's pattern on the same mappings (src/exchange_data_mpidma.c:93-127) -- pack kernel, one copy per
+   * partner slice into its landing slice, the notify kernel: a shade above RCCL in the same table (0.52 / 0.16), replayed from
+   * hipGraphs, and the one rung that does not depend on a KERNEL's stores reaching a peer's memory */
+  for (int attempt = 0; try_ipc && attempt < 12; attempt++) {
+    const int put = attempt >= 9;
     const int separate = attempt >= 6;
-    const int mi = separate ? attempt - 6 : attempt / 2, counters = separate ? 0 : attempt % 2 == 0;
+    const int mi = put ? attempt - 9 : (separate ? attempt - 6 : attempt / 2), counters = separate ? 0 : attempt % 2 == 0;
     if (preset && *preset && strcmp(preset, modes[mi])) continue;
     if (!separate && npre && *npre && strcmp(npre, counters ? "counter" : "flag")) continue;
     if (separate && getenv("CFDP_IPC_INKERNEL")) continue;
-    (void)cfdp_gpu_ipc_configure(gpu, mode_id[mi], wait_inkernel, counters, separate ? 0 : -1);
+    (void)cfdp_gpu_ipc_configure(gpu, mode_id[mi], wait_inkernel, counters, put ? 2 : (separate ? 0 : -1));
     char what[200];
     snprintf(what, sizeof what, "%s, %s notification%s", labels[mi], counters ? "counter" : "flag",
-             separate ? ", push / notify / wait as kernels of their own" : "");
+             put ? ", copy-engine put" : (separate ? ", push / notify / wait as kernels of their own" : ""));
     if (!ipc_setup(gpu, r, G)) {
       if (r == 0) printf("exchange: HIP IPC setup failed (%s): %s\n", what, cfdp_gpu_last_error());
       ipc_teardown(gpu);
@@ -284,7 +288,7 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
       MPI_Allreduce(&mine, &lo, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
       MPI_Allreduce(&mine, &hi, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
       snprintf(what, sizeof what, "%s, notification by %s%s", labels[mi], lo == hi ? (hi ? "counters" : "flags") : "counters on some ranks, flags on others",
-               separate ? ", push / notify / wait as kernels of their own" : "");
+               put ? ", copy-engine put" : (separate ? ", push / notify / wait as kernels of their own" : ""));
       int dup = 0;
       for (int k = 0; k < ntried; k++) dup |= !strcmp(tried[k], what);
       if (dup) {
@@ -292,7 +296,7 @@ int cfdp_mpi_attach(comm_data *cd, solver_data *sd, int force_rccl) {
         ipc_teardown(gpu);
         continue;
       }
-      if (ntried < 9) snprintf(tried[ntried++], sizeof tried[0], "%s", what);
+      if (ntried < 12) snprintf(tried[ntried++], sizeof tried[0], "%s", what);
     }
     cfdp_attach_ipc(sd);
     g_use_ipc = 1;

@@ -107,6 +107,7 @@ static void make_dirs(const cfdp_gen_params *gp, dirset *D) {
   CFDP_ASSERT(D->n == 62);
 }
 static inline int is_hub(const cfdp_gen_params *gp, long gid) {
+  if (gp->hubs < 0) return 0; /* (irregular meshes without hub points: what the hubs alone cost the kernels) */
   return (cfdp_mix64(gp->seed * 0xD1B54A32D192ED03ull + 0x77ull + (uint64_t)gid) & 1023u) == 0;
 }
 /* does the face from point gid0 in direction d (to gid1) exist?  Lattice meshes: always.  Irregular: the lattice's unit

@@ -644,6 +644,7 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
   /* (a point adds at most 14 halo rows on these meshes and the check precedes the addition: the cap
    * leaves room for that, 126 + 14 = 140 <= 2.2 * 64; small tiles: only the scattered ones) */
   T.halo_cap = o.tile_points * 2 - 2 < 96 ? 96 : o.tile_points * 2 - 2;
+  int two_level_forced = 0;
   {
     /* what the two capacities of the fused pass stage per tile (gg_fused_split_kernel, 4 lanes per point, 16-byte pieces
      * per thread): <5, 3, 3, 3> -- 5 blob pieces, var rows in 3 pieces at 4 per 64-byte row: a 32-KiB image at 64-point
@@ -655,9 +656,11 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
     T.blob_cap2 = (long)6 * block * 16;
     T.rows_cap2 = block;
     T.fill_min = o.tile_points - o.tile_points / 8; /* 7/8 full */
-    const char *e = getenv("CFDP_TILE_BUDGET"); /* 0: tiles close by point count and the soft halo bound only; 1: the small image only */
+    const char *e = getenv("CFDP_TILE_BUDGET"); /* 0: tiles close by point count and the soft halo bound only; 1: the small
+                                                   image only; 2: both levels whatever the mesh; default: decided below */
     if (e && atoi(e) == 0) T.blob_cap = T.blob_cap2 = 0;
     if (e && atoi(e) == 1) T.blob_cap2 = 0;
+    two_level_forced = e && atoi(e) == 2;
     /* with the hard row budget in force the soft halo bound may go up to it: tiles of meshes with many
      * neighbours per point (15+) then fill up instead of closing at 2/3 of their points */
     if (T.blob_cap > 0 && T.rows_cap - o.tile_points > T.halo_cap) T.halo_cap = T.rows_cap - o.tile_points;
@@ -669,6 +672,16 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
     const char *e = getenv("CFDP_GROW_FRONTS");
     if (e && atoi(e) > 1) grow_fronts = atoi(e);
   }
+  /* Which budgets?  The second level is for meshes whose tiles the small image closes early -- 2/3 full on an unstructured
+   * graph with 15 incidences per point, a quarter of the lanes idle.  On the lattice stand-ins the small image holds full
+   * tiles, and the few leftover tiles that WOULD go on under the large image put the whole launch into it (the launch-wide
+   * maxima pick the kernel form: four workgroups per CU instead of five, longer row lists; measured on the rank partitions
+   * of the 8-GPU configs: +1 to +3 % per iteration).  So: grow under the small image alone, look at the fill of the
+   * interior tiles, and grow again with both levels only if they stayed below 7/8 full on average.  Growth is the cheap
+   * part of the plan (0.02 s at 64^3). */
+  const long blob_cap2 = T.blob_cap2;
+  for (int attempt = 0;; attempt++) {
+  if (attempt == 0 && !two_level_forced) T.blob_cap2 = 0;
   if (any_send && o.boundary_first) {
     int btp = o.tile_points / 2 < 8 ? 8 : o.tile_points / 2; /* sheets have big halos */
     tiler_pass(&T, is_send, 1, btp);
@@ -685,6 +698,22 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
     if (grow_fronts > 1) tiler_pass_multifront(&T, NULL, 0, o.tile_points, grow_fronts);
     else tiler_pass(&T, NULL, 0, o.tile_points);
     P->nbtiles = 0;
+  }
+  if (attempt == 0 && !two_level_forced && blob_cap2 > 0 && T.ntiles > P->nbtiles) {
+    const long interior_points = nown - T.tile_first[P->nbtiles], interior_tiles = T.ntiles - P->nbtiles;
+    if (interior_points * 8 < interior_tiles * (long)o.tile_points * 7 && interior_tiles > 1) { /* below 7/8 full: again, both levels */
+      T.blob_cap2 = blob_cap2;
+      for (int p = 0; p < nown; p++) T.tile_of[p] = -1;
+      memset(T.stamp, 0, (size_t)nown * sizeof(int));
+      memset(T.seeded, 0, (size_t)nown);
+      memset(T.hseen, 0, (size_t)nall * sizeof(int));
+      T.sq_head = T.sq_tail = 0;
+      T.norder = 0;
+      T.ntiles = 0;
+      continue;
+    }
+  }
+  break;
   }
   CFDP_ASSERT(T.norder == nown);
   T.tile_first[T.ntiles] = nown;

@@ -301,11 +301,17 @@ class RankSolver:
             rungs = [(m, n, None) for m in ipc_mode_attempts() for n in ipc_notify_attempts()]
             if "CFDP_IPC_INKERNEL" not in os.environ:
                 rungs += [(m, "flag", False) for m in ipc_mode_attempts()]
+                # ... and behind it MPI_Put's pattern (src/exchange_data_mpidma.c:93-127): the send arena packed by a kernel, one
+                # copy per partner slice into its landing slice, the notify kernel.  Priced in the same table: 0.52 / 0.16 of
+                # comm-free -- a shade above stream-launched RCCL (0.49 / 0.15), graph-replayed, and the one rung that does not
+                # depend on a KERNEL's stores reaching a peer's memory
+                rungs += [(m, "flag", "put") for m in ipc_mode_attempts()]
             for mode, notify, push_in in rungs:
                 self.gpu.ipc_configure(memory_mode=mode, wait_inkernel=wait_in, notify=notify, push_inkernel=push_in)
                 self._ipc_mode_now = mode
                 self._validating = (f"ipc / {IPC_MODE_LABEL[mode]}, {IPC_NOTIFY_LABEL[notify]}"
-                                    + (", push / notify / wait as kernels of their own" if push_in is False else ""))
+                                    + (", push / notify / wait as kernels of their own" if push_in is False else "")
+                                    + (", copy-engine put" if push_in == "put" else ""))
                 try:
                     self._init_ipc()
                     self.available.append("ipc")
@@ -392,7 +398,9 @@ class RankSolver:
         dist.all_gather_object(forms, self.gpu.ipc_mode().get("notify_by", "?").split(" ")[0])
         resolved = forms[0] if len(set(forms)) == 1 else "mixed: " + ", ".join(f"{f} on rank {r}" for r, f in enumerate(forms))
         asked = self._validating
-        self._validating = asked.split(",")[0] + f", notification by {resolved}" + (", push / notify / wait as kernels of their own" if "kernels of their own" in asked else "")
+        self._validating = (asked.split(",")[0] + f", notification by {resolved}"
+                            + (", push / notify / wait as kernels of their own" if "kernels of their own" in asked else "")
+                            + (", copy-engine put" if "copy-engine put" in asked else ""))
         self.resolved_rungs = getattr(self, "resolved_rungs", [])
         if self._validating in self.resolved_rungs:
             self._ipc_off()

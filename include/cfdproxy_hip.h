@@ -232,7 +232,10 @@ int  cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int over
  *                           memory_mode 0 coarse | 1 fine | 2 split; wait_inkernel 1 | 0 (ranks sharing a device: 0);
  *                           notify 1 counters | 0 flags; push_inkernel 1 the fused pass pushes and notifies itself |
  *                           0 push, notify and wait are kernels of their own (release / acquire at kernel boundaries:
- *                           the conservative rung).  Takes effect at the next _export / _ready.                        */
+ *                           the conservative rung) | 2 the copy-engine put: the send arena packed by a kernel, one
+ *                           hipMemcpyAsync per partner slice into its landing slice, the notify kernel behind the copies
+ *                           (MPI_Put's pattern, src/exchange_data_mpidma.c:93-127).  Takes effect at the next _export /
+ *                           _ready.                                                                                   */
 #define CFDP_IPC_HEADER_BYTES 8192
 int  cfdp_gpu_ipc_header_bytes(void);
 size_t cfdp_gpu_ipc_flag_offset(int slot); /* flag_off of cfdp_gpu_ipc_connect[_flags]: one cache line per partner slot */

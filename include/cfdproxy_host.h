@@ -37,6 +37,7 @@ typedef struct {
   int cdf_version;         /* 1 or 2                                                       */
   uint64_t seed;
   int numbering;           /* 0: a domain's points numbered along x, y, z; 1: scrambled      */
+  int hubs;                /* irregular meshes: 0 a hub point every 1024 (default), -1 none  */
 } cfdp_gen_params;
 enum { CFDP_CONN_IRREGULAR = 62 };
 

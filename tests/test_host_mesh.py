@@ -378,6 +378,18 @@ def test_stored_form_of_gradient_rows(pkg):
     # numbers the stress reads are within one more rounding
     again = pkg.stored_rows(back)
     assert np.array_equal(again[:, :3], e[:, :3]) and np.all(np.abs(again[:, 3:6] - e[:, 3:6]) <= ulp)
+    # the contract under cancellation: the error of an upper off-diagonal is one rounding of the
+    # PAIR'S SUM -- absolute -- so a component far smaller than its partner loses its relative precision: 1e-20 beside 1
+    # comes back as 0; the partner, the diagonal and everything the flux reads are exact
+    tiny = np.zeros((3, 7, 3))
+    tiny[:, 0, 1], tiny[:, 1, 0] = [1e-20, -3e-17, 0.75], [1.0, 1.0, 1e-20]   # g1 beside g3
+    tiny[:, 0, 2], tiny[:, 2, 0] = [5e-18, 1e-30, 2.0], [-1.0, 4.0, -2.0]     # g2 beside g6
+    out = pkg.handed_out_rows(pkg.stored_rows(tiny)).reshape(3, 7, 3)
+    assert np.array_equal(out[:, 1, 0], tiny[:, 1, 0]) and np.array_equal(out[:, 2, 0], tiny[:, 2, 0])  # the partners: exact
+    assert out[0, 0, 1] == 0.0 and out[1, 0, 1] == 0.0 and out[2, 0, 1] == 0.75   # 1e-20, -3e-17 beside 1: gone; 0.75 beside 1e-20: exact
+    assert out[0, 0, 2] == 0.0 and out[1, 0, 2] == 0.0 and out[2, 0, 2] == 2.0
+    bound = np.spacing(np.abs(tiny[:, 0, 1] + tiny[:, 1, 0]))
+    assert np.all(np.abs(out[:, 0, 1] - tiny[:, 0, 1]) <= bound)
 
 
 # ------------------------------------------------------------------- irregular meshes (round 6)

@@ -95,13 +95,15 @@ def test_multirank_xgmi_write_notify_under_random_skew(gpu):
 @pytest.mark.parametrize("env", [{"CFDP_IPC_MODE": "split"}, {"CFDP_IPC_MODE": "fine"}, {"CFDP_IPC_PER_PARTNER": "0"},
                                  {"CFDP_IPC_WAIT_INKERNEL": "0"}, {"CFDP_IPC_INKERNEL": "0"}, {"CFDP_IPC_NOTIFY": "flag"},
                                  {"CFDP_IPC_NOTIFY": "flag", "CFDP_IPC_WAIT_INKERNEL": "0"},
-                                 {"CFDP_IPC_NOTIFY": "counter", "CFDP_IPC_INKERNEL": "0"}])
+                                 {"CFDP_IPC_NOTIFY": "counter", "CFDP_IPC_INKERNEL": "0"},
+                                 {"CFDP_IPC_NOTIFY": "flag", "CFDP_IPC_INKERNEL": "2"}, {"CFDP_IPC_INKERNEL": "2", "CFDP_IPC_MODE": "coarse"}])
 def test_multirank_xgmi_write_notify_other_rungs(gpu, env):
     """the same value checks (and the scaled-field check of every schedule) on the other rungs of the exchange: flags in a
     fine-grained block of their own with the arenas coarse-grained and an explicit invalidate ("split"), everything
     fine-grained, one completion counter for all partners instead of one per partner, the wait as a kernel of its own,
     push / notify as kernels of their own, notification by flags instead of counters (with either wait), counters raised
-    by the notify kernel"""
+    by the notify kernel, and the copy-engine put (pack kernel + one copy per partner slice into its landing slice + the
+    notify kernel: MPI_Put's pattern, src/exchange_data_mpidma.c:93-127)"""
     _launch(3, ["--gpu", "--transport", "ipc", "--files"], extra_env=dict({"CFDP_IPC_WAIT_INKERNEL": "1"}, **env))
 
 

@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-sizes = [int(a) for a in sys.argv[2:]] or [64, 128]
+sizes = sys.argv[2:] or ["64", "128"]  # "64i": the generator's irregular option at that size
 out_dir = os.path.join(ROOT, "gpurun_out", f"sq_{tag}")
 os.makedirs(out_dir, exist_ok=True)
 PASSES = [
@@ -31,7 +31,7 @@ for n in sizes:
         d = os.path.join(out_dir, f"n{n}_{counters[0]}")
         cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                "python3", os.path.join(ROOT, "tools", "prof_one.py")]
-        e = dict(os.environ, TMPDIR="/tmp", N=str(n), TP="0", L="0", PIPE="-1", ITERS="5")
+        e = dict(os.environ, TMPDIR="/tmp", N=str(n).rstrip("i"), TP="0", L="0", PIPE="-1", ITERS="5", IRREGULAR="1" if str(n).endswith("i") else "0")
         r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
         f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
         if not f:

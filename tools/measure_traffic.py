@@ -25,13 +25,15 @@ os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
 result = {}
 rows_out = []
-for n, label in ((64, "dualgrid.12 lvl 2 stand-in (64^3)"), (128, "dualgrid.384 finest-level stand-in (128^3)")):
+for n, label in ((64, "dualgrid.12 lvl 2 stand-in (64^3)"), (128, "dualgrid.384 finest-level stand-in (128^3)"),
+                 (64, "irregular stand-in of the dualgrid.12 lvl 2 size (64^3 points)")):
     per_kernel = collections.defaultdict(dict)
     for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"]):
-        d = os.path.join(out_dir, f"n{n}_{counters[0]}")
+        irr = label.startswith("irregular")
+        d = os.path.join(out_dir, f"n{n}{'i' if irr else ''}_{counters[0]}")
         cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
                "python3", os.path.join(ROOT, "tools", "prof_one.py")]
-        e = dict(env, N=str(n), TP="0", L="0", ITERS="5")
+        e = dict(env, N=str(n), TP="0", L="0", ITERS="5", IRREGULAR="1" if irr else "0")
         r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
         print(r.stdout[-300:], flush=True)
         f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
