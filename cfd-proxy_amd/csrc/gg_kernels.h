@@ -168,5 +168,6 @@ int gg_forms_take(char *buf, size_t len);
 extern int gg_debug_flags;
 hipError_t gg_set_stamp_buffer(unsigned long long *dev);  // diagnostics: phase stamps of the split fused pass
 extern int gg_fused_split;
+extern int gg_grad_alias;
 
 #endif

@@ -686,7 +686,10 @@ __device__ __forceinline__ void dma_stage_tile(unsigned char *buf, const cfdp_ti
   }
 }
 
-template <int LPP, bool NT, int CB, int KV>
+// ALIAS: the store slab of the last phase lies ON the var rows (as in the fused pass: the waves meet once between the
+// face loop and the stores) instead of behind them -- 5.25 KiB less per tile, which is a workgroup per CU more at the
+// capacities it is used for (<5,3>: 32 KiB, five instead of four; <6,4>: 40 KiB, four instead of three)
+template <int LPP, bool NT, int CB, int KV, bool ALIAS = false>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LPP == 8 ? GG_WAVES_EU : LPP == 4 ? 4 : 2)))
 void gg_gradient_dma_kernel(
     const cfdp_tile_desc *__restrict__ tiles, int tile_begin, const uint4 *__restrict__ blob,
@@ -699,8 +702,8 @@ void gg_gradient_dma_kernel(
   dma_stage_tile<NT, CB, KV>(smem, td, blob, reinterpret_cast<const uint4 *>(var), halo_idx, tid, nthr);
   __syncthreads();  // vmcnt(0) + barrier: every wave's pieces have landed
   const int var_off = CB * nthr * 16;
-  double *stage = reinterpret_cast<double *>(smem + (size_t)(CB + KV) * nthr * 16);
-  grad_tile_compute<LPP, NT>(smem, td, tid, gout, stage, dbg, var_off);
+  double *stage = reinterpret_cast<double *>(smem + (size_t)(ALIAS ? CB : CB + KV) * nthr * 16);
+  grad_tile_compute<LPP, NT, ALIAS>(smem, td, tid, gout, stage, dbg, var_off);
 }
 
 // LDS-DMA: global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs, asynchronous (vmcnt)
@@ -1448,6 +1451,10 @@ hipError_t gg_set_stamp_buffer(unsigned long long *dev) {
 // fused pass: 0 everything staged up front; 1 the phase-split form at its large capacity only (36 KiB, 4 workgroups per
 // CU); 2 (default) its small capacity where the tiles allow it (32 KiB, 5 workgroups per CU)
 int gg_fused_split = 2;
+// the gradient kernel's store slab ON its var rows (one more workgroup per CU): bit 0 at the small capacity (measured +-0 on the
+// lattice stand-ins: off), bit 1 at the large one (<6,4>: four workgroups per CU instead of three: -8.5 % on the irregular
+// stand-in: on).  CFDP_GRAD_ALIAS overrides (development).
+int gg_grad_alias = 2;
 int gg_debug_flags = 0;  // 16: register-staged kernels only; 64: per-lane row stores; GG_DBG_STAMP: phase stamps
 
 namespace {
@@ -1507,12 +1514,12 @@ template <int L> hipError_t launch_grad_generic(const gg_args &a, bool nt, int t
   return launch(gg_gradient_kernel<L, false>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad);
 }
 
-template <int CB, int KV> hipError_t launch_grad_dma(const gg_args &a, bool nt, int tile_begin, int ntiles, int block,
-                                                     size_t stage_bytes, hipStream_t stream) {
-  const size_t lds = (size_t)(CB + KV) * block * 16 + stage_bytes;
-  note_form("gradient_dma", CB, KV, -1, -1, "", tile_begin, ntiles);
-  if (nt) return launch(gg_gradient_dma_kernel<4, true, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags);
-  return launch(gg_gradient_dma_kernel<4, false, CB, KV>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags);
+template <int CB, int KV, bool ALIAS = false> hipError_t launch_grad_dma(const gg_args &a, bool nt, int tile_begin, int ntiles, int block,
+                                                                         size_t stage_bytes, hipStream_t stream) {
+  const size_t lds = (size_t)(CB + KV) * block * 16 + (ALIAS ? 0 : stage_bytes);
+  note_form("gradient_dma", CB, KV, -1, -1, ALIAS ? "alias" : "", tile_begin, ntiles);
+  if (nt) return launch(gg_gradient_dma_kernel<4, true, CB, KV, ALIAS>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags);
+  return launch(gg_gradient_dma_kernel<4, false, CB, KV, ALIAS>, ntiles, block, lds, stream, a.tiles, tile_begin, a.blob, a.halo_idx, a.var, a.grad, gg_debug_flags);
 }
 
 template <int L, bool R> hipError_t launch_flux_generic(const gg_args &a, bool nt, int tile_begin, int ntiles, int block, size_t lds,
@@ -1609,7 +1616,11 @@ hipError_t gg_launch_gradient(const gg_args &a, int lanes, int tile_begin, int n
     const int cb = (max_blob_qw + block - 1) / block;                    // blob pieces per thread
     const int kv = ((tile_points + max_halo) * 4 + block - 1) / block;  // var-row pieces per thread
     if (cb >= 1 && kv >= 1) {
+      const int alias = gg_grad_alias;  // bit 0: the small capacity, bit 1: the large one
+      // (the slab must fit the var rows it lies on: 8 rows of 168 bytes per wave <= KV pieces per thread)
+      if (cb <= 5 && kv <= 3 && (alias & 1) && stage_bytes <= (size_t)3 * block * 16) return launch_grad_dma<5, 3, true>(a, nt, tile_begin, ntiles, block, stage_bytes, stream);
       if (cb <= 5 && kv <= 3) return launch_grad_dma<5, 3>(a, nt, tile_begin, ntiles, block, stage_bytes, stream);
+      if (cb <= 6 && kv <= 4 && (alias & 2) && stage_bytes <= (size_t)4 * block * 16) return launch_grad_dma<6, 4, true>(a, nt, tile_begin, ntiles, block, stage_bytes, stream);
       if (cb <= 5 && kv <= 4) return launch_grad_dma<5, 4>(a, nt, tile_begin, ntiles, block, stage_bytes, stream);
       if (cb <= 6 && kv <= 5) return launch_grad_dma<6, 5>(a, nt, tile_begin, ntiles, block, stage_bytes, stream);
       if (cb <= 8 && kv <= 6 && (size_t)(8 + 6) * block * 16 + stage_bytes <= LDS_MAX)

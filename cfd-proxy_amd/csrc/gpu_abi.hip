@@ -64,6 +64,7 @@ int cfdp_gpu_create(int device, cfdp_gpu **out) {
   if (const char *e = cfdp_experiment_getenv("CFDP_EXP_SKIP_PRE"))  // timing experiment, values WRONG (EXPERIMENTS.md D.2)
     gg_debug_flags = (gg_debug_flags & ~0x80000) | (atoi(e) ? 0x80000 : 0);
   if (const char *e = getenv("CFDP_FUSED_SPLIT")) gg_fused_split = atoi(e);
+  if (const char *e = getenv("CFDP_GRAD_ALIAS")) gg_grad_alias = atoi(e);
   HIP_TRY(hipStreamCreateWithFlags(&g->s_main, hipStreamNonBlocking));
   {
     // the comm stream carries the latency chain of an iteration (boundary tiles -> pack/push ->
