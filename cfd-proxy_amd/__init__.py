@@ -696,7 +696,7 @@ class Plan:
         incb = (td.ninc * 4 + 15) & ~15
         fn = np.stack([blob[b0 + c * plane: b0 + c * plane + td.nfaces * 8].view(np.float64) for c in range(3)], 1)
         inc = blob[b0 + fnb:b0 + fnb + td.ninc * 4].view(np.uint32)
-        ioff = blob[b0 + fnb + incb:b0 + fnb + incb + (td.npts + 1) * 4].view(np.uint32)
+        ioff = blob[b0 + fnb + incb:b0 + fnb + incb + (td.npts + 1) * 4].view(np.uint32) & np.uint32(0xFFFFFF)  # (bits 24-31: chunks of a long list - 1)
         halo = np.ctypeslib.as_array(self.p.halo_idx, shape=(max(self.p.nhalo_total, 1),))[
             td.halo_off:td.halo_off + td.nhalo]
         return fn, inc, ioff, halo

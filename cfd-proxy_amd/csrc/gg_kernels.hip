@@ -228,6 +228,37 @@ __device__ __forceinline__ void push_from_registers(double *row, int eq0, const 
   }
 }
 
+// Long incidence lists cut into chunks (cfdproxy_host.h): the helper table of a tile image, behind its offsets -- present only
+// in tiles that have helpers (nhelp = 0: nothing behind the offsets, the blob ends there).  Uniform per workgroup.
+struct gg_helpers {
+  int n;                  // helper lane groups: tile-local slots npts .. npts + n - 1 (they own no row)
+  const uint32_t *tab;    // [n] target li | chunk << 16, in (point, chunk) order
+  double *scratch;        // [n][24] partial sums on their way to the point's own lanes
+};
+__device__ __forceinline__ gg_helpers tile_helpers(const unsigned char *buf, const cfdp_tile_desc &td, int plane, int inc_bytes) {
+  gg_helpers h;
+  const int base = 3 * plane + inc_bytes + (((td.npts + 1) * 4 + 15) & ~15);
+  h.n = td.blob_qw * 16 > base ? (int)*reinterpret_cast<const uint32_t *>(buf + base) : 0;
+  h.tab = reinterpret_cast<const uint32_t *>(buf + base) + 1;
+  h.scratch = reinterpret_cast<double *>(const_cast<unsigned char *>(buf) + base + (((1 + h.n) * 4 + 15) & ~15));
+  return h;
+}
+// the part [ks, ke) of its list a lane group walks: the whole list, or -- a list cut into nchunks -- chunk c of it
+__device__ __forceinline__ void list_chunk(const uint32_t *ioff, int li, int chunk, int &ks, int &ke, int &ks0, int &ke0, int &nchunks) {
+  const uint32_t w0 = ioff[li], w1 = ioff[li + 1];
+  ks0 = (int)(w0 & 0xFFFFFFu);
+  ke0 = (int)(w1 & 0xFFFFFFu);
+  nchunks = (int)(w0 >> 24) + 1;
+  ks = ks0;
+  ke = ke0;
+  if (nchunks > 1) {
+    const int len = (ke0 - ks0 + nchunks - 1) / nchunks;
+    ks = ks0 + chunk * len;
+    ke = ks + len < ke0 ? ks + len : ke0;
+    if (ks > ke0) ks = ke = ke0;
+  }
+}
+
 // The finished rows are stored 8 bytes per lane in contiguous runs (NT: non-temporal).
 // MOVE (the data-movement floor, a diagnostic instantiation): no incidence is walked -- every row is stored as zeros
 // through the same slab and the same store instructions.
@@ -256,16 +287,25 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
   double vs[NE], acc[NE][3];
 #pragma unroll
   for (int j = 0; j < NE; j++) acc[j][0] = acc[j][1] = acc[j][2] = 0.0;
-  int ks = 0, ke0 = 0;
+  // (a long list is walked in chunks: this lane group takes the first -- or, a HELPER group in a slot behind the tile's points,
+  // another chunk of some point's list, with that point's var row; its sums join the point's below)
+  const gg_helpers hp = tile_helpers(buf, td, plane, inc_bytes);
+  const bool helper = !active && li < td.npts + hp.n;
+  int src = li, chunk = 0;
+  if (helper) {
+    const uint32_t hw = hp.tab[li - td.npts];
+    src = (int)(hw & 0xFFFFu);
+    chunk = (int)(hw >> 16);
+  }
+  int ks = 0, ke0 = 0, nchunks = 1;  // [ks, ke0): the point's WHOLE list (faceless / push decisions below)
   double tmp = 0.0;
-  if (active) {
+  if (active || helper) {
 #pragma unroll
-    for (int j = 0; j < NE; j++) vs[j] = var_l[li * 8 + eq0 + j];
-    ks = (int)ioff[li];
-    ke0 = (int)ioff[li + 1];
-    const int ke = MOVE ? ks : ke0;
+    for (int j = 0; j < NE; j++) vs[j] = var_l[src * 8 + eq0 + j];
+    int k, kend;
+    list_chunk(ioff, src, chunk, k, kend, ks, ke0, nchunks);
+    const int ke = MOVE ? k : kend;
     const double *var_eq0 = var_l + eq0;
-    int k = ks;
     // (each lane runs the chain "sevens, a four, a two, a one" over its OWN list; a wave issues a batch for as long as any
     // lane has one, but lanes without it are switched off and read nothing from LDS, which is what this loop is short of:
     // one schedule per wave with lanes sitting out masked batches -- built and measured in round 6 -- was 4-8 % slower)
@@ -277,7 +317,28 @@ __device__ __forceinline__ void grad_tile_compute(const unsigned char *buf, cons
       k += 2;
     }
     if (k < ke) grad_batch<1, NE>(inc, k, nx, ny, nz, var_eq0, vs, acc);
-    tmp = 0.5 / var_l[li * 8 + 7];  // 1/pvolume, src/gradients.c:138, and the face value's 0.5 (grad_batch)
+    if (active) tmp = 0.5 / var_l[li * 8 + 7];  // 1/pvolume, src/gradients.c:138, and the face value's 0.5 (grad_batch)
+  }
+  if (hp.n) {  // (uniform per workgroup) the helpers' sums join their points': through LDS, in chunk order
+    if (helper) {
+#pragma unroll
+      for (int j = 0; j < NE; j++)
+        if (eq0 + j < 8) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) hp.scratch[(li - td.npts) * 24 + (eq0 + j) * 3 + c] = acc[j][c];
+        }
+    }
+    __syncthreads();
+    if (active && nchunks > 1)
+      for (int h = 0; h < hp.n; h++)
+        if ((int)(hp.tab[h] & 0xFFFFu) == li) {
+#pragma unroll
+          for (int j = 0; j < NE; j++)
+            if (eq0 + j < 8) {
+#pragma unroll
+              for (int c = 0; c < 3; c++) acc[j][c] += hp.scratch[h * 24 + (eq0 + j) * 3 + c];
+            }
+        }
   }
   // this point's row goes to a partner: out of the registers, now (before the tile's own stores: the acknowledgement of a
   // remote store takes longest).  A point without faces is pushed by nobody (such partitions keep the push kernel)
@@ -789,13 +850,21 @@ __device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, dou
   const uint32_t *ioff = reinterpret_cast<const uint32_t *>(smem + 3 * plane + inc_bytes);
 
   double f0 = 0.0, f1 = 0.0, f2 = 0.0;
-  int ks = 0, ke = 0;
-  if (active) {
-    ks = (int)ioff[li];
-    ke = (int)ioff[li + 1];
+  // (long lists in chunks, as in grad_tile_compute: helper lane groups behind the tile's points take the further chunks)
+  const gg_helpers hp = tile_helpers(smem, td, plane, inc_bytes);
+  const bool helper = !active && li < npts + hp.n;
+  int src = li, chunk = 0;
+  if (helper) {
+    const uint32_t hw = hp.tab[li - npts];
+    src = (int)(hw & 0xFFFFu);
+    chunk = (int)(hw >> 16);
+  }
+  int ks = 0, ke = 0, ks0 = 0, ke0 = 0, nchunks = 1;
+  if (active || helper) {
+    list_chunk(ioff, src, chunk, ks, ke, ks0, ke0, nchunks);
     double ps[6];
 #pragma unroll
-    for (int c = 0; c < 6; c++) ps[c] = g_l[li * GS + c];
+    for (int c = 0; c < 6; c++) ps[c] = g_l[src * GS + c];
     // U of this lane's incidences per batch: all incidence words, then all operands, then the
     // FMAs, so the lane pays the LDS round trips once per batch (as in grad_batch).  With few
     // lanes per point a lane has ~4 incidences and runs in a workgroup of few waves: U = 4.
@@ -846,7 +915,21 @@ __device__ __forceinline__ void flux_tile_compute(const unsigned char *smem, dou
     f1 += __shfl_xor(f1, m, 64);
     f2 += __shfl_xor(f2, m, 64);
   }
-  if (active && sub == 0 && ke > ks) {
+  if (hp.n) {  // (uniform per workgroup)
+    if (helper && sub == 0) {
+      double *sc = hp.scratch + (li - npts) * 24;
+      sc[0] = f0; sc[1] = f1; sc[2] = f2;
+    }
+    __syncthreads();
+    if (active && sub == 0 && nchunks > 1)
+      for (int h = 0; h < hp.n; h++)
+        if ((int)(hp.tab[h] & 0xFFFFu) == li) {
+          const double *sc = hp.scratch + h * 24;
+          f0 += sc[0]; f1 += sc[1]; f2 += sc[2];
+        }
+    __syncthreads();  // (the gradient phase of a fused pass uses the same scratch)
+  }
+  if (active && sub == 0 && ke0 > ks0) {
     double *o = flux + (size_t)(td.pstart + li) * 3;
     o[0] = f0; o[1] = f1; o[2] = f2;
   }

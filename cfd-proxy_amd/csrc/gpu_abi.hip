@@ -137,7 +137,18 @@ int cfdp_gpu_upload_plan(cfdp_gpu *g, const cfdp_plan *p) {
         const int c = cfdp_tile_class(p->tile_points, rows, (long)td.blob_qw * 16);
         if (c > G.cls) G.cls = c;
         if (rows > G.max_rows) G.max_rows = rows;
-        if (td.npts > G.tp) G.tp = td.npts;
+        // lane groups the tile needs: its points and the helper groups of its long lists (cfdproxy_host.h: the helper table
+        // sits behind the offsets of a blob that has one)
+        int groups = td.npts;
+        {
+          const long plane = cfdp_blob_plane_bytes(td.nfaces), base = 3 * plane + cfdp_blob_inc_bytes(td.ninc) + cfdp_blob_off_bytes(td.npts);
+          if ((long)td.blob_qw * 16 > base) {
+            unsigned nh = 0;
+            memcpy(&nh, p->blob + (size_t)td.blob_off * 16 + base, sizeof nh);
+            groups += (int)nh;
+          }
+        }
+        if (groups > G.tp) G.tp = groups;
         if (td.nhalo > G.max_halo) G.max_halo = td.nhalo;
         if (td.blob_qw > G.max_blob) G.max_blob = td.blob_qw;
         const size_t lg = (size_t)td.blob_qw * 16 + (size_t)rows * 64, lf = (size_t)td.blob_qw * 16 + (size_t)rows * 80;

@@ -614,6 +614,7 @@ int cfdp_gpu_ipc_ready(cfdp_gpu *g) {
       // a boundary tile's workgroup reads its group's entry, also the groups beyond the tile's points)
       int tpmax = 1;
       for (int t = 0; t < g->ntiles; t++) tpmax = g->h_tiles[t].npts > tpmax ? g->h_tiles[t].npts : tpmax;
+      for (const auto &G : g->groups) tpmax = G.tp > tpmax ? G.tp : tpmax;  // (lane groups: points + the helper groups of long lists)
       I.pt_stride = (tpmax + 63) & ~63;
       std::vector<int2> pt_first((size_t)(g->nbtiles ? g->nbtiles : 1) * I.pt_stride, make_int2(-1, 0));
       std::vector<int> tile_xoff((size_t)g->ntiles + 1, 0), nfirst((size_t)g->ntiles, 0);

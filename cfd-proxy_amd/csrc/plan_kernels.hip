@@ -170,7 +170,20 @@ struct blob_args {
   int *halo_idx;
   int max_inc, cap;                        // LDS sizing: incidences per tile, hash capacity (power of two)
   int *bad;
+  // long incidence lists cut into chunks (cfdproxy_host.h): helper lane groups per tile (0: no list of the tile is cut) and
+  // the plan's tile_points (the cap on chunks per list)
+  const int *nhelp;                        // [ntiles] (pass B)
+  int tile_points;
 };
+
+// cfdp_list_chunks (cfdproxy_host.h), for the device
+__device__ __forceinline__ int dev_list_chunks(int deg, int tile_points) {
+  if (deg <= CFDP_LONG_LIST) return 1;
+  int cap = tile_points / 4 < CFDP_MAX_CHUNKS ? tile_points / 4 : CFDP_MAX_CHUNKS;
+  if (cap < 1) cap = 1;
+  const int n = (deg + CFDP_LIST_CHUNK - 1) / CFDP_LIST_CHUNK;
+  return n > cap ? cap : n;
+}
 
 constexpr int BLOB_T = 256;
 constexpr int EMPTY_KEY = -1;
@@ -287,7 +300,21 @@ __global__ __launch_bounds__(BLOB_T) void k_tile_blobs(blob_args a, int np_max) 
   uint32_t *inc = reinterpret_cast<uint32_t *>(bp + b_fn);
   uint32_t *io = reinterpret_cast<uint32_t *>(bp + b_fn + b_inc);
   int *hp = a.halo_idx + a.hoff[t];
-  for (int li = tid; li <= np; li += BLOB_T) io[li] = (uint32_t)ioff[li];
+  const int nh = a.nhelp[t];  // helper lane groups of this tile: > 0 = its long lists are cut into chunks
+  for (int li = tid; li <= np; li += BLOB_T) {
+    const int nch = nh && li < np ? dev_list_chunks(ioff[li + 1] - ioff[li], a.tile_points) : 1;
+    io[li] = (uint32_t)ioff[li] | ((uint32_t)(nch - 1) << 24);
+  }
+  if (nh && tid == 0) {  // the helper table behind the offsets, in (point, chunk) order (a few entries in a tile in a hundred)
+    uint32_t *htab = reinterpret_cast<uint32_t *>(bp + b_fn + b_inc + ((((long)np + 1) * 4 + 15) & ~15L));
+    htab[0] = (uint32_t)nh;
+    int fill = 0;
+    for (int li = 0; li < np; li++) {
+      const int nch = dev_list_chunks(ioff[li + 1] - ioff[li], a.tile_points);
+      for (int c = 1; c < nch; c++) htab[1 + fill++] = (uint32_t)li | ((uint32_t)c << 16);
+    }
+    if (fill != nh) atomicExch(a.bad, 1);
+  }
   {
     int li = k0 < k1 ? point_of(k0) : 0;
     for (int k = k0; k < k1; k++) {
@@ -460,7 +487,7 @@ int stage_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P, void
     return cfdp_set_error("hipMalloc failed: out of memory (injected by CFDP_PLAN_FAIL_STAGE)");
   }
   if (lds > 160 * 1024 || np_max > 4 * BLOB_T) return 2;  // a tile too big for the LDS hash: the host stage takes over
-  dev_buf<int> order, tile_first, tile_of, old2new, cntE, cntH, cntI, bad, halo;
+  dev_buf<int> order, tile_first, tile_of, old2new, cntE, cntH, cntI, bad, halo, nhelp;
   dev_buf<double> fnormal;
   dev_buf<long> boff, hoff;
   dev_buf<unsigned char> blob;
@@ -513,13 +540,22 @@ int stage_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P, void
   P->tiles = static_cast<cfdp_tile_desc *>(calloc((size_t)nt, sizeof(cfdp_tile_desc)));
   if (!P->tiles) return cfdp_set_error("out of memory");
   std::vector<long> h_boff((size_t)nt + 1, 0), h_hoff((size_t)nt + 1, 0);
+  std::vector<int> h_nhelp((size_t)(nt ? nt : 1), 0);
+  const bool split_lists = !(getenv("CFDP_SPLIT_LISTS") && atoi(getenv("CFDP_SPLIT_LISTS")) == 0);
   long lds_g[2] = {0, 0}, lds_f[2] = {0, 0}, dup_total = 0, inc_total = 0;
   for (int t = 0; t < nt; t++) {
     cfdp_tile_desc *td = &P->tiles[t];
     const int np = tl->tile_first[t + 1] - tl->tile_first[t];
     td->pstart = tl->tile_first[t]; td->npts = np;
     td->nhalo = H[t]; td->nfaces = E[t]; td->ninc = I[t];
-    const long bytes = cfdp_blob_fn_bytes(E[t]) + cfdp_blob_inc_bytes(I[t]) + cfdp_blob_off_bytes(np);
+    {  // helper lane groups of the tile's long lists -- or none where points and helpers do not fit its lane groups (as the host stage)
+      int nh = 0;
+      if (split_lists)
+        for (int i = tl->tile_first[t]; i < tl->tile_first[t + 1]; i++)
+          nh += cfdp_list_chunks(tl->xadj[tl->order[i] + 1] - tl->xadj[tl->order[i]], P->tile_points) - 1;
+      h_nhelp[t] = np + nh <= P->tile_points ? nh : 0;
+    }
+    const long bytes = cfdp_blob_fn_bytes(E[t]) + cfdp_blob_inc_bytes(I[t]) + cfdp_blob_off_bytes(np) + cfdp_blob_help_bytes(h_nhelp[t]);
     td->blob_qw = (int)(bytes / 16);
     td->blob_off = (int)(h_boff[t] / 16);
     td->halo_off = (int)h_hoff[t];
@@ -541,7 +577,9 @@ int stage_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P, void
   PK_TRY(hipMemset(blob.p, 0, (size_t)(P->blob_bytes ? P->blob_bytes : 1)));  // alignment padding is defined
   PK_TRY(hipMemcpy(boff.p, h_boff.data(), sizeof(long) * ((size_t)nt + 1), hipMemcpyHostToDevice));
   PK_TRY(hipMemcpy(hoff.p, h_hoff.data(), sizeof(long) * ((size_t)nt + 1), hipMemcpyHostToDevice));
-  a.boff = boff.p; a.hoff = hoff.p; a.blob = blob.p; a.halo_idx = halo.p;
+  PK_TRY(nhelp.alloc((size_t)(nt ? nt : 1)));
+  PK_TRY(hipMemcpy(nhelp.p, h_nhelp.data(), sizeof(int) * (size_t)(nt ? nt : 1), hipMemcpyHostToDevice));
+  a.boff = boff.p; a.hoff = hoff.p; a.blob = blob.p; a.halo_idx = halo.p; a.nhelp = nhelp.p; a.tile_points = P->tile_points;
   hipLaunchKernelGGL(k_tile_blobs<true>, dim3(nt), dim3(BLOB_T), lds, 0, a, np_max);
   PK_TRY(hipGetLastError());
   P->blob = static_cast<unsigned char *>(malloc((size_t)(P->blob_bytes ? P->blob_bytes : 16)));

@@ -31,6 +31,7 @@
 #include <string.h>
 
 int cfdp_tile_class_of(int tile_points, int rows, long blob_bytes) { return cfdp_tile_class(tile_points, rows, blob_bytes); }
+int cfdp_list_chunks_of(int deg, int tile_points) { return cfdp_list_chunks(deg, tile_points); }
 
 void cfdp_plan_default_opts(cfdp_plan_opts *o) {
   o->tile_points = 64;
@@ -66,6 +67,8 @@ typedef struct {
    * grids) a tile cut to the smallest image keeps a quarter of its lanes idle, which costs more than the larger image */
   long blob_cap2;
   int rows_cap2, fill_min;
+  int tile_points; /* of the plan (boundary tiles are grown to half of it) */
+  int split_lists; /* long incidence lists are cut into chunks that helper lane groups of the tile walk (cfdproxy_host.h) */
 } tiler;
 
 static void tiler_open_tile(tiler *T) {
@@ -87,12 +90,13 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
     const int t = T->ntiles;
     tiler_open_tile(T);
     int cnt = 0, head = 0, tail = 0, seen = 0, rejected = -1;
+    int nhelp = 0; /* helper lane groups the tile's long lists take (cfdproxy_host.h): they share the tile's TP groups */
     long ninc = 0, ninternal = 0; /* incidences of the tile so far; faces with both ends in it */
     long bcap = T->blob_cap;     /* this tile's budgets: the smallest image first */
     int rcap = T->rows_cap, hcap = T->halo_cap, upgraded = 0;
 #define TILE_NEXT_CAPACITY() (!upgraded && T->blob_cap2 > 0 && cnt < T->fill_min && TP >= T->fill_min && \
                               (upgraded = 1, bcap = T->blob_cap2, rcap = T->rows_cap2, hcap = T->rows_cap2 - TP, 1))
-    while (cnt < TP) {
+    while (cnt + nhelp < TP) {
       /* a tile made of leftovers scattered between finished tiles reads ~14 rows per point; close
        * it early rather than let one such tile size the LDS image of the whole launch */
       if (T->hseen && cnt >= 4 && seen - cnt > hcap && !(TILE_NEXT_CAPACITY() && seen - cnt <= hcap)) break;
@@ -114,6 +118,11 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
         T->lq[tail++] = seed;
       }
       int p = T->lq[head];
+      const int help_add = T->split_lists ? cfdp_list_chunks(T->xadj[p + 1] - T->xadj[p], T->tile_points) - 1 : 0;
+      if (cnt >= 1 && cnt + 1 + nhelp + help_add > TP) { /* no lane groups left for this point's chunks: it seeds a later tile */
+        rejected = p;
+        break;
+      }
       int internal_add = 0;
       for (int e = T->xadj[p]; e < T->xadj[p + 1]; e++) {
         int q = T->adj_other[e];
@@ -124,7 +133,8 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
         for (int e = T->xadj[p]; e < T->xadj[p + 1]; e++)
           if (T->hseen[T->adj_other[e]] != t + 1) newrows++; /* (an upper bound: parallel faces count twice) */
         const long I2 = ninc + (T->xadj[p + 1] - T->xadj[p]), E2 = I2 - (ninternal + internal_add);
-        const long blob = cfdp_blob_fn_bytes((int)E2) + cfdp_blob_inc_bytes((int)I2) + cfdp_blob_off_bytes(cnt + 1);
+        const long blob = cfdp_blob_fn_bytes((int)E2) + cfdp_blob_inc_bytes((int)I2) + cfdp_blob_off_bytes(cnt + 1) +
+                          cfdp_blob_help_bytes(nhelp + help_add);
         if ((blob > bcap || seen + newrows > rcap) &&
             !(TILE_NEXT_CAPACITY() && blob <= bcap && seen + newrows <= rcap)) {
           rejected = p; /* stays un-tiled: it seeds a later tile */
@@ -135,6 +145,7 @@ static void tiler_pass(tiler *T, const unsigned char *mask, int want, int TP) {
       T->tile_of[p] = t;
       T->order[T->norder++] = p;
       cnt++;
+      nhelp += help_add;
       remaining--;
       ninc += T->xadj[p + 1] - T->xadj[p];
       ninternal += internal_add;
@@ -397,6 +408,18 @@ static int host_csr(const solver_data *sd, int **xadj_out, int **adj_face_out, i
   return 0;
 }
 
+/* helper lane groups of a tile (cfdproxy_host.h, long incidence lists): the chunks beyond the first of every long list -- or
+ * none at all where points and helpers together do not fit the tile's lane groups */
+static int tile_helpers(const cfdp_tiling *tl, int tile_points, int ts, int np, int split_lists) {
+  if (!split_lists) return 0;
+  int nh = 0;
+  for (int li = 0; li < np; li++) {
+    const int p = tl->order[ts + li];
+    nh += cfdp_list_chunks(tl->xadj[p + 1] - tl->xadj[p], tile_points) - 1;
+  }
+  return np + nh <= tile_points ? nh : 0;
+}
+
 /* stage 5 on the host.  Tiles are independent: pass A sizes every tile, a prefix sum places its blob and its halo
  * list, pass B fills them -- both passes in parallel over tiles.  The tile-local numbering of faces and halo
  * points (first touch, walking the tile's points and their faces in file order) lives in small per-thread hash
@@ -421,6 +444,7 @@ static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P
    * are stored with ONE of them (the lower tile id); the other tile's planes simply do not hold them (its incidence
    * words point past its planes).  What the fused pass and its movement floor take then is an UPPER BOUND on what
    * "cut-face normals owned by one tile, fetched by the other through L2" can gain: the fetch itself is free here. */
+  const int split_lists = !(getenv("CFDP_SPLIT_LISTS") && atoi(getenv("CFDP_SPLIT_LISTS")) == 0);
   const char *exp_owned_s = cfdp_experiment_getenv("CFDP_EXP_OWNED_NORMALS"); /* honoured only with CFDP_EXPERIMENTS=1 */
   const int exp_owned = exp_owned_s && atoi(exp_owned_s) != 0;
   for (int pass = 0; pass < 2; pass++) {
@@ -466,13 +490,14 @@ static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P
               if (!in_tile) lmap_index(&hmap, q, &H);
             }
           }
-          if (np + H > 65535 || E > 32767) bad = 1;
+          if (np + H > 65535 || E > 32767 || I >= (1 << 24)) bad = 1;
           E -= E_foreign; /* (experiment: the planes hold the owned faces only) */
           td->pstart = ts; td->npts = np;
           td->nhalo = H; td->nfaces = E; td->ninc = I;
           const long b_fn = cfdp_blob_fn_bytes(E), b_inc = cfdp_blob_inc_bytes(I), b_off = cfdp_blob_off_bytes(np);
-          td->blob_qw = (int)((b_fn + b_inc + b_off) / 16);
-          boff[t + 1] = b_fn + b_inc + b_off;
+          const long b_help = cfdp_blob_help_bytes(tile_helpers(tl, P->tile_points, ts, np, split_lists));
+          td->blob_qw = (int)((b_fn + b_inc + b_off + b_help) / 16);
+          boff[t + 1] = b_fn + b_inc + b_off + b_help;
           hoff[t + 1] = H;
           dup_total += E;
           inc_total += I;
@@ -515,10 +540,18 @@ static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P
                 if (q < nown && tl->tile_of[q] != t && tl->tile_of[q] < t) lmap_index(&fmap, tl->adj_face[e] & 0x7FFFFFFF, &Eall);
               }
             }
+          /* long lists cut into chunks (cfdproxy_host.h): the table of helper lane groups behind the offsets, one entry per
+           * chunk beyond a point's first, in (point, chunk) order; the scratch behind it stays zero */
+          const int nh = tile_helpers(tl, P->tile_points, ts, np, split_lists);
+          uint32_t *htab = (uint32_t *)(bp + b_fn + b_inc + cfdp_blob_off_bytes(np));
+          int hfill = 0;
+          if (nh) htab[0] = (uint32_t)nh;
           int Ic = 0;
           for (int li = 0; li < np; li++) {
             int p = tl->order[ts + li];
-            ioff[li] = (uint32_t)Ic;
+            const int nch = nh ? cfdp_list_chunks(tl->xadj[p + 1] - tl->xadj[p], P->tile_points) : 1;
+            ioff[li] = (uint32_t)Ic | ((uint32_t)(nch - 1) << 24);
+            for (int c = 1; c < nch; c++) htab[1 + hfill++] = (uint32_t)li | ((uint32_t)c << 16);
             for (int e = tl->xadj[p]; e < tl->xadj[p + 1]; e++) {
               int q = tl->adj_other[e];
               int f = tl->adj_face[e] & 0x7FFFFFFF;
@@ -543,7 +576,7 @@ static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P
             }
           }
           ioff[np] = (uint32_t)Ic;
-          if (Ic != td->ninc || En != E || Hn != td->nhalo) bad = 1;
+          if (Ic != td->ninc || En != E || Hn != td->nhalo || hfill != nh) bad = 1;
         }
       }
 #pragma omp critical
@@ -644,6 +677,8 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
   /* (a point adds at most 14 halo rows on these meshes and the check precedes the addition: the cap
    * leaves room for that, 126 + 14 = 140 <= 2.2 * 64; small tiles: only the scattered ones) */
   T.halo_cap = o.tile_points * 2 - 2 < 96 ? 96 : o.tile_points * 2 - 2;
+  T.split_lists = !(getenv("CFDP_SPLIT_LISTS") && atoi(getenv("CFDP_SPLIT_LISTS")) == 0);
+  T.tile_points = o.tile_points;
   int two_level_forced = 0;
   {
     /* what the two capacities of the fused pass stage per tile (gg_fused_split_kernel, 4 lanes per point, 16-byte pieces
@@ -882,8 +917,10 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
           }
         }
         const long E = I - internal / 2;
+        const cfdp_tiling tl0 = {xadj, NULL, adj_other, T.order, T.tile_first, T.tile_of};
         cls[t] = (unsigned char)cfdp_tile_class(o.tile_points, np + H,
-                                                cfdp_blob_fn_bytes((int)E) + cfdp_blob_inc_bytes((int)I) + cfdp_blob_off_bytes(np));
+                                                cfdp_blob_fn_bytes((int)E) + cfdp_blob_inc_bytes((int)I) + cfdp_blob_off_bytes(np) +
+                                                    cfdp_blob_help_bytes(tile_helpers(&tl0, o.tile_points, T.tile_first[t], np, T.split_lists)));
       }
       lmap_free(&hmap);
     }

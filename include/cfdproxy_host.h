@@ -205,6 +205,27 @@ static inline long cfdp_blob_plane_bytes(int nfaces) { return ((long)nfaces * 8 
 static inline long cfdp_blob_fn_bytes(int nfaces) { return 3 * cfdp_blob_plane_bytes(nfaces); }
 static inline long cfdp_blob_inc_bytes(int ninc) { return ((long)ninc * 4 + 15) & ~15L; }
 static inline long cfdp_blob_off_bytes(int npts) { return ((long)(npts + 1) * 4 + 15) & ~15L; }
+/* LONG INCIDENCE LISTS (round 6).  A lane group walks its point's whole list, batch after batch of dependent LDS round trips, so
+ * a point with 60-75 faces (one in a thousand on an unstructured mesh) keeps its wave -- and the tile that waits for it --
+ * busy five times as long as its neighbours.  A list of more than CFDP_LONG_LIST entries is therefore cut into nchunks =
+ * ceil(deg / CFDP_LIST_CHUNK) (<= CFDP_MAX_CHUNKS) chunks of ceil(deg / nchunks) entries: the point's own lane group takes the
+ * first, HELPER lane groups of the same tile -- tile-local slots npts .. npts + nhelp - 1, which own no row -- take the others
+ * at the same time, and the partial sums are added to the point's in LDS in chunk order (deterministic; every kernel form of
+ * a plan shares the chunking).  In the blob: offsets word li = offset | (nchunks - 1) << 24; behind the offsets, only in tiles
+ * that have helpers, [nhelp | helper h: target li | chunk << 16 | ... pad 16][192 bytes of scratch per helper].  A tile whose
+ * points and helpers together exceed tile_points (a tiler that did not plan for them) simply has no list cut.              */
+enum { CFDP_LONG_LIST = 32, CFDP_LIST_CHUNK = 28, CFDP_MAX_CHUNKS = 16 };
+static inline int cfdp_list_chunks(int deg, int tile_points) { /* (a tile has tile_points lane groups: at most a quarter per list) */
+  if (deg <= CFDP_LONG_LIST) return 1;
+  int cap = tile_points / 4 < CFDP_MAX_CHUNKS ? tile_points / 4 : CFDP_MAX_CHUNKS;
+  if (cap < 1) cap = 1;
+  const int n = (deg + CFDP_LIST_CHUNK - 1) / CFDP_LIST_CHUNK;
+  return n > cap ? cap : n;
+}
+int cfdp_list_chunks_of(int deg, int tile_points); /* the same, callable through the ABI */
+static inline long cfdp_blob_help_bytes(int nhelp) { return nhelp > 0 ? (((long)(1 + nhelp) * 4 + 15) & ~15L) + 192L * nhelp : 0; }
+#define CFDP_OFF_START(w)  ((w) & 0xFFFFFFu)
+#define CFDP_OFF_CHUNKS(w) (((w) >> 24) + 1u)
 /* algorithmic bytes of one gradient / flux pass */
 double cfdp_algo_bytes_grad(long nfaces, long nown, long nadd);
 double cfdp_algo_bytes_flux(long nfaces, long nown, long nadd);

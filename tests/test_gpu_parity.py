@@ -1123,6 +1123,9 @@ def test_device_built_plan_equals_host_plan(gpu, which):
     hub = pkg.domain_from_arrays(fp, rng.normal(size=(nleaf, 3)), rng.uniform(0.5, 2.0, nleaf + 1), nleaf + 1,
                                  var=rng.normal(size=(nleaf + 1, 7)))
     cases += [(hub, 64)]
+    # long incidence lists cut into chunks (chunk counts in the offsets words, helper tables behind them): the irregular stand-in
+    irr = pkg.gen_domain(pkg.gen_params(24, 20, 18, ndomains=1, connectivity=pkg.CONN_IRREGULAR, numbering=1), 0)
+    cases += [(irr, 64), (irr, 32)]
     for dom, tp in cases:
         host = pkg.Plan(dom, tile_points=tp)
         dev = pkg.Plan(dom, tile_points=tp, device_stages=which)
@@ -1133,7 +1136,7 @@ def test_device_built_plan_equals_host_plan(gpu, which):
         assert dev.stage_seconds[1] != -1.0  # the device stage did the blobs itself
         host.free()
         dev.free()
-    for dom in [d, hub] + doms:
+    for dom in [d, hub, irr] + doms:
         dom.free()
 
 

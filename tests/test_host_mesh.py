@@ -486,3 +486,54 @@ def test_points_of_a_tile_are_ordered_by_degree(pkg):
     assert np.array_equal(deg, np.bincount(irr.fpoint.ravel(), minlength=irr.nown)[plan.new2old[: irr.nown]])
     plan.free()
     irr.free()
+
+
+def test_long_incidence_lists_are_cut_into_chunks_for_helper_lane_groups(pkg):
+    """cfdproxy_host.h, long incidence lists: a list of more than 32 entries is cut into chunks of <= 28, the point's own lane group
+    takes the first, helper lane groups of the same tile (slots behind its points, which own no row) the others.  In the blob:
+    the chunk count in the top byte of the point's offsets word, a helper table + scratch behind the offsets of a tile that has
+    helpers and nothing behind the offsets of one that has none; points + helpers fit the tile's lane groups; the chunks of a
+    list cover it exactly once"""
+    irr = pkg.gen_domain(pkg.gen_params(24, 20, 18, ndomains=1, connectivity=pkg.CONN_IRREGULAR, numbering=1), 0)
+    deg_file = np.bincount(irr.fpoint.ravel(), minlength=irr.nown)
+    assert (deg_file > 32).sum() >= 4
+    plan = pkg.Plan(irr)
+    blob = np.ctypeslib.as_array(plan.p.blob, shape=(plan.blob_bytes,))
+    pad16 = lambda n: (n + 15) & ~15
+    cut = 0
+    for t in range(plan.ntiles):
+        td = plan.tile(t)
+        plane = pad16(td.nfaces * 8)
+        base = td.blob_off * 16 + 3 * plane + pad16(td.ninc * 4)
+        raw = blob[base: base + (td.npts + 1) * 4].view(np.uint32)
+        start, nch = raw & 0xFFFFFF, (raw >> 24) + 1
+        deg = np.diff(start.astype(np.int64))
+        assert np.array_equal(deg, deg_file[plan.new2old[td.pstart: td.pstart + td.npts]])
+        behind = td.blob_qw * 16 - (3 * plane + pad16(td.ninc * 4) + pad16((td.npts + 1) * 4))
+        want = [pkg.host_lib().cfdp_list_chunks_of(int(d), 64) for d in deg]
+        nh = sum(want) - td.npts
+        if nh == 0:
+            assert behind == 0 and (nch[:-1] == 1).all()
+            continue
+        assert td.npts + nh <= 64 and list(nch[:-1]) == want and behind == pad16(4 * (1 + nh)) + 192 * nh
+        tab = blob[base + pad16((td.npts + 1) * 4):][: 4 * (1 + nh)].view(np.uint32)
+        assert tab[0] == nh
+        seen = {}
+        for w in tab[1:]:
+            li, c = int(w & 0xFFFF), int(w >> 16)
+            assert 0 <= li < td.npts and 1 <= c < want[li]
+            seen.setdefault(li, []).append(c)
+        for li, cs in seen.items():
+            assert cs == list(range(1, want[li])) and want[li] <= 16 and -(-int(deg[li]) // want[li]) <= 28
+        assert not blob[base + pad16((td.npts + 1) * 4) + pad16(4 * (1 + nh)): td.blob_off * 16 + td.blob_qw * 16].any()  # the scratch: zeros
+        cut += len(seen)
+    assert cut == (deg_file > 32).sum()
+    os.environ["CFDP_SPLIT_LISTS"] = "0"
+    try:
+        whole = pkg.Plan(irr)
+    finally:
+        del os.environ["CFDP_SPLIT_LISTS"]
+    assert whole.blob_bytes < plan.blob_bytes
+    whole.free()
+    plan.free()
+    irr.free()
