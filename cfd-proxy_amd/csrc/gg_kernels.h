@@ -167,6 +167,9 @@ hipError_t gg_launch_var_check(const double *var, const double *var0, int nall, 
 int gg_forms_take(char *buf, size_t len);
 extern int gg_debug_flags;
 hipError_t gg_set_stamp_buffer(unsigned long long *dev);  // diagnostics: phase stamps of the split fused pass
+// the diagnostic instantiations of the fused pass live in lib/libcfdproxy_diag.so (csrc/gg_diag.hip), loaded on demand:
+// nullptr when they are available, else the reason (what the diagnostic entry points of the ABI report)
+const char *gg_diag_available();
 extern int gg_fused_split;
 extern int gg_grad_alias;
 

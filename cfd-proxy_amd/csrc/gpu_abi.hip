@@ -970,6 +970,7 @@ int cfdp_gpu_time_fused_movement(cfdp_gpu *g, int iters, float *ms_pass) {
   if (iters < 1) return fail("iters must be >= 1");
   if (!g->fusion || !g->d_grad_alt) return fail("fusion is off");
   if (!g->d_rowlist) return fail("no fixed-stride row lists: the movement-only instantiation needs them");
+  if (const char *why = gg_diag_available()) return fail("%s", why);  // (a diagnostic instantiation: lib/libcfdproxy_diag.so)
   {  // the movement-only kernel is an instantiation of the phase-split form: refuse where that form would not run (the
      // launch would otherwise fall back to the two REAL kernels and their time be reported as the floor)
     const tile_range r = range_of(g, CFDP_TILES_ALL);
@@ -1196,6 +1197,7 @@ int cfdp_gpu_refresh_graphs(cfdp_gpu *g) {
 int cfdp_gpu_debug_phase_stamps(cfdp_gpu *g, int passes, unsigned long long *stamps) {
   NEED_UPLOAD(g);
   if (!g->fusion || !g->d_grad_alt || passes < 1 || !stamps) return fail("fusion must be on");
+  if (const char *why = gg_diag_available()) return fail("%s", why);  // (a diagnostic instantiation: lib/libcfdproxy_diag.so)
   if (flush_flux(g)) return 1;
   unsigned long long *d = nullptr;
   const size_t n = (size_t)g->ntiles * 24;  // 8 per tile, then 4 x 4 per wave

@@ -178,3 +178,23 @@ def test_calls_from_omp_single_sections_are_never_lost_silently(pkg, tmp_path):
         (r.returncode == 1 and "not by every thread of the team" in r.stderr and "CFDP_CALL_MODE=every" in r.stderr), r.stdout + r.stderr
     r = subprocess.run([exe, "single"], capture_output=True, text=True, timeout=120, env=dict(env, CFDP_CALL_MODE="every"))
     assert r.returncode == 0 and "performed 80 of 80" in r.stdout, r.stdout + r.stderr
+
+
+def test_product_library_holds_no_diagnostic_kernel(pkg):
+    """the diagnostic instantiations of the fused pass (DIAG = 1 phase stamps, 2 data movement only, 3 the skip-pre timing
+    experiment: csrc/gg_diag.hip) live in lib/libcfdproxy_diag.so, which the product library loads only when a diagnostic is
+    asked for: libcfdproxy_hip.so holds the kernels a timed run can execute and nothing else"""
+    import re
+    libdir = os.path.join(ROOT, "cfd-proxy_amd", "lib")
+
+    def fused_forms(lib):
+        out = subprocess.run(["nm", "-C", "--defined-only", os.path.join(libdir, lib)], capture_output=True, text=True, check=True).stdout
+        return set(re.findall(r"gg_fused_split_kernel<([^>]*)>", out))
+
+    product, diag = fused_forms("libcfdproxy_hip.so"), fused_forms("libcfdproxy_diag.so")
+    assert product and all(f.split(", ")[6] == "0" for f in product), sorted(product)
+    assert diag and {f.split(", ")[6] for f in diag} == {"1", "2", "3"}, sorted(diag)
+    # both capacities of the real pass, with and without the exchange riding in it, with and without row lists
+    assert {tuple(f.split(", ")[2:6]) for f in product} == {("5", "3", "3", "3"), ("6", "4", "3", "4")}
+    d = ctypes.CDLL(os.path.join(libdir, "libcfdproxy_diag.so"))
+    assert d.gg_diag_launch_fused and d.gg_diag_set_stamp_buffer
