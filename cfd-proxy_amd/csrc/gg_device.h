@@ -1111,16 +1111,17 @@ __device__ __forceinline__ void gg_stamp_wave(int dbg, int ntiles, int tile, int
 
 // Phase-split form of the fused pass: ONE row region of LDS holds the gradient rows during the flux
 // phase and the var rows during the gradient phase, so a tile occupies CB + KX pieces per thread instead
-// of CB + KV + KG: 36 KiB instead of 48 KiB for 64-point tiles = FOUR workgroups per CU.  The var rows
+// of CB + KV + KG: 32 KiB instead of 44 KiB for 64-point tiles = FIVE workgroups per CU.  The var rows
 // are requested together with the gradient rows, into registers, and wait out the flux phase there.
 // LISTED: the fixed-stride row lists exist (gg_args::rowlist); PUSH: an exchange rides in the pass (the boundary
 // tiles wait for the previous exchange, push their rows, notify) -- both compile-time, so the pass that runs one
 // partition on one GPU carries neither the other path's code nor its registers
 // DIAG: 0 = the timed kernel; 1 = phase stamps (tools/phase_stamps.py); 2 = data movement only: every load and every
 // store of the pass, neither face loop (cfdp_gpu_time_fused_movement: the floor bench.py reports beside the pass)
-// Two capacities are instantiated: CB = 5, KV = 4, KG = 3, KX = 4 (tiles of up to 256 staged rows: 36 KiB, four workgroups
-// per CU) and CB = 5, KV = KG = KX = 3 (up to 192 staged rows -- every tile of the 64-point lattice plans: 32 KiB, FIVE
-// workgroups per CU).  The flux phase stages the first 48 bytes of every row (A1: the six numbers the stress needs).
+// Two capacities are instantiated -- the two budget levels of the tiler (cfdp_tile_class, cfdproxy_host.h): CB = 5, KV = KG =
+// KX = 3 (blob <= 20 KiB, up to 192 staged rows -- every tile of the lattice plans: 32 KiB, FIVE workgroups per CU) and CB = 6,
+// KV = 4, KG = 3, KX = 4 (blob <= 24 KiB, up to 256 staged rows -- the full tiles of an unstructured mesh: 40 KiB, four per
+// CU).  The flux phase stages the first 48 bytes of every row (A1: the six numbers the stress needs).
 template <bool REFMODE, bool NT, int CB, int KV, int KG, int KX, int DIAG = 0, bool LISTED = true, bool PUSH = true>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 void gg_fused_split_kernel(

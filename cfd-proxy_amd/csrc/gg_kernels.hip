@@ -265,8 +265,10 @@ hipError_t gg_launch_wait(int *hdr, int nslots, long max_polls, const int *tile_
 //             gg_gradient_kernel<LPP, NT>             register-staged, any tile shape, LPP in {1,2,4,8} (fallback)
 //   flux      gg_flux_dma_kernel<8, REF, NT, CB, KV>  fixed-count LDS-DMA staging, 8 lanes per point (default)
 //             gg_flux_kernel<LPP, REF, NT>            register-staged, any tile shape (fallback)
-//   fused     gg_fused_split_kernel<REF, NT, 5,4,4,4> one shared row region, 4 workgroups per CU (default)
+//   fused     gg_fused_split_kernel<REF, NT, 5,3,3,3> one shared row region, 5 workgroups per CU (default); <6,4,3,4>: the
+//                                                     large image (full tiles of unstructured meshes), 4 per CU
 //             gg_fused_dma_kernel<REF, NT, CB,KV,KG>  everything staged up front (beside an RCCL kernel; larger tiles)
+// (the diagnostic instantiations of the fused pass: gg_diag.hip, a library of their own)
 // The diagnostic instantiations of the fused pass (phase stamps, data movement only, skip-pre) live in a library of their
 // own, lib/libcfdproxy_diag.so (csrc/gg_diag.hip), looked for beside this one and loaded at the first diagnostic.
 namespace {
