@@ -58,11 +58,11 @@ export CFDP_SHARED_GPU=1
 for what in ${@:-6as8 4as8 2 4}; do
   S=$(date +%s)
   if [ "$what" = 6as8 ]; then
-    CFDP_BENCH_AS_GPUS=8 timeout -k 10 900 python bench.py --gpus 6 --steps 20 --warmup 5 > gpurun_out/r5_rehearsal_n6_as8.json 2> gpurun_out/r5_rehearsal_n6_as8.err
+    CFDP_BENCH_AS_GPUS=8 timeout -k 10 900 python bench.py --gpus 6 --steps 20 --warmup 5 > gpurun_out/r6_rehearsal_n6_as8.json 2> gpurun_out/r6_rehearsal_n6_as8.err
   elif [ "$what" = 4as8 ]; then
-    CFDP_BENCH_AS_GPUS=8 timeout -k 10 900 python bench.py --gpus 4 --steps 20 --warmup 5 > gpurun_out/r5_rehearsal_n4_as8.json 2> gpurun_out/r5_rehearsal_n4_as8.err
+    CFDP_BENCH_AS_GPUS=8 timeout -k 10 900 python bench.py --gpus 4 --steps 20 --warmup 5 > gpurun_out/r6_rehearsal_n4_as8.json 2> gpurun_out/r6_rehearsal_n4_as8.err
   else
-    timeout -k 10 600 python bench.py --gpus $what --steps 20 --warmup 5 > gpurun_out/r5_rehearsal_n$what.json 2> gpurun_out/r5_rehearsal_n$what.err
+    timeout -k 10 600 python bench.py --gpus $what --steps 20 --warmup 5 > gpurun_out/r6_rehearsal_n$what.json 2> gpurun_out/r6_rehearsal_n$what.err
   fi
-  echo "$what: rc=$? wall_s=$(( $(date +%s) - S ))" | tee -a gpurun_out/r5_rehearsal.wall
+  echo "$what: rc=$? wall_s=$(( $(date +%s) - S ))" | tee -a gpurun_out/r6_rehearsal.wall
 done
