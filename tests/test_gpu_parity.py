@@ -1322,6 +1322,47 @@ def p_own(gpart):
     return gpart.dom.nown
 
 
+def test_small_and_large_tiles_in_launches_of_their_own(gpu, orc):
+    """launch groups by capacity class (host/tiling.c 3e, csrc/gpu_abi.hip segs_of): where a plan has many tiles of the small AND
+    of the large image the two get launches of their own (CFDP_CLASS_SPLIT_MIN lowered so that a small mesh splits): the tiles
+    of the small image first, then those of the large one, each launch at ITS capacity -- and the values are those of the
+    one-launch plan, bit for bit (a point's faces are added in file order whatever the tile order), in un-fused and fused
+    iterations"""
+    pkg = gpu
+    irr = pkg.gen_domain(pkg.gen_params(32, 32, 32, ndomains=1, connectivity=pkg.CONN_IRREGULAR, numbering=1), 0)
+    pkg.fill_var(irr, None, pkg.VAR_HASH)
+
+    def run(fused):
+        part = pkg.GpuPartition(irr)
+        part.set_fusion(fused)
+        pkg.kernel_forms()
+        part.run_iterations(3, True, 0, use_graph=fused)
+        forms = pkg.kernel_forms().split()
+        part.pull_fields()
+        out = (irr.grad.copy(), irr.psd_flux.copy(), part.stats["groups"], forms)
+        part.close()
+        return out
+
+    one = [run(f) for f in (False, True)]
+    assert len(one[0][2]) == 1
+    os.environ["CFDP_CLASS_SPLIT_MIN"] = "16"
+    try:
+        two = [run(f) for f in (False, True)]
+    finally:
+        del os.environ["CFDP_CLASS_SPLIT_MIN"]
+    groups = two[0][2]
+    assert len(groups) == 2 and groups[0][2] == 0 and groups[1][2] == 1 and groups[0][1] == groups[1][0], groups
+    for (g1, f1, _, _), (g2, f2, _, forms) in zip(one, two):
+        assert np.array_equal(g1, g2) and np.array_equal(f1, f2)
+        assert any(f.startswith(("fused_split<5,3,3,3>", "gradient_dma<5,3>")) and f"@0+{groups[0][1]}" in f for f in forms), forms
+        assert any(f.startswith(("fused_split<6,4,3,4>", "gradient_dma<6,4>")) and f"@{groups[1][0]}+" in f for f in forms), forms
+    ref = orc.CpuRef(irr.fpoint, irr.fnormal, irr.pvolume, irr.nown, nthreads=4)
+    g_ref = ref.gradients(irr.var.copy())
+    ref.close()
+    assert rel_err(orc, two[1][0], g_ref, irr.fpoint, irr.fnormal, irr.pvolume, irr.var, irr.nown) <= TOL
+    irr.free()
+
+
 def test_exchange_setup_helpers(gpu):
     """the small things a host builds an exchange from: the PCI bus id ranks compare to find out whether they share a
     device, the header geometry hosts must not hard-code (a cache line per partner slot), and the per-context configuration
