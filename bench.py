@@ -646,6 +646,7 @@ def main() -> None:
                     pkg.kernel_forms()
                     fui = pi.time_fused(1000)
                     forms += " " + pkg.kernel_forms()
+                    pkg.kernel_forms_off()
                     im["iterations_per_s"] = 1e3 / fui
                     im["fused"] = fracs(bi + bif, bi + bif - 32.0 * di.nfaces, tri.get("gg_fused"), fui)
                     try:

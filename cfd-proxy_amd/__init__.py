@@ -615,6 +615,13 @@ def kernel_forms() -> str:
     return buf.value.decode()
 
 
+def kernel_forms_off() -> None:
+    """switch the log of kernel_forms() off again"""
+    lib = hip_lib()
+    lib.cfdp_gpu_kernel_forms.argtypes = [C.c_char_p, C.c_size_t]
+    lib.cfdp_gpu_kernel_forms(None, 0)
+
+
 def device_bus_id(device: int) -> str:
     """PCI bus id of a visible device: the same string in every process that sees the same physical device"""
     buf = C.create_string_buffer(64)

@@ -455,7 +455,7 @@ hipError_t launch_fused_upfront(const gg_args &a, const gg_grad_view &gnew, bool
 }  // namespace
 
 int gg_forms_take(char *buf, size_t len) {
-  g_forms_on = true;
+  g_forms_on = buf != nullptr;  // (a null buffer switches the log off again: launchers then note nothing)
   const int n = g_forms_n;
   if (buf && len) {
     const size_t m = (size_t)g_forms_len < len - 1 ? (size_t)g_forms_len : len - 1;

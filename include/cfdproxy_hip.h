@@ -313,7 +313,8 @@ int  cfdp_gpu_time_fused_movement(cfdp_gpu *g, int iters, float *ms_pass);
 /* which kernel forms ran: every launch of a face-loop kernel made by the calling thread since the last call is appended to a
  * log, "form@first_tile+tiles" separated by blanks (e.g. "fused_split<6,4,3,4>listed@0+4124 flux_dma<3,2>@4124+5") --
  * what bench.py prints beside a roofline figure so that a number says which instantiation it belongs to.  Copies the log
- * into buf (truncated to len - 1 characters), clears it, returns the number of launches it covered.                  */
+ * into buf (truncated to len - 1 characters), clears it, returns the number of launches it covered.  The first call switches
+ * the log on (and returns nothing); buf = NULL switches it off again.                                                 */
 int  cfdp_gpu_kernel_forms(char *buf, size_t len);
 /* capture + instantiate the graphs cfdp_gpu_run_iterations(g, iters, ...) will replay; nothing
  * executes (keeps the capture out of a caller's timed region)                                  */
