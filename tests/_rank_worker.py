@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--inject-early-read", action="store_true",
                     help="CFDP_IPC_FAULT=skip_wait is set: the comparison of final states must still pass, the scaled-field "
                          "check must see the ghost rows that were read one exchange early")
+    ap.add_argument("--irregular", action="store_true",
+                    help="the generator's irregular option (random tetrahedralisation + hub points, scrambled numbering): tiles of "
+                         "the large image, long incidence lists in chunks -- also in boundary tiles that push from registers")
     ap.add_argument("--notify-by-rank", default="",
                     help="comma-separated counter / flag, one per rank: neighbours that resolved to DIFFERENT forms of "
                          "notification (the per-partner protocol depends on a rank's own partition) must understand each other")
@@ -58,12 +61,13 @@ def main():
     from cfd_proxy_amd import multigpu as mg
 
     dims = tuple(int(x) for x in args.dims.split(","))
-    gp = pkg.gen_params(*dims, ndomains=args.ndomains)
+    mesh_kw = dict(connectivity=pkg.CONN_IRREGULAR, numbering=1) if args.irregular else {}
+    gp = pkg.gen_params(*dims, ndomains=args.ndomains, **mesh_kw)
     part, st = mg.build_rank_partition(gp, args.ndomains, world, rank, via_files=args.files)
     mg.exchange_requests(part, rank, world, dist)
 
     # global truth from the un-partitioned mesh
-    g1 = pkg.gen_params(*dims, ndomains=1)
+    g1 = pkg.gen_params(*dims, ndomains=1, **({"connectivity": pkg.CONN_IRREGULAR} if args.irregular else {}))
     whole = pkg.gen_domain(g1, 0)
     pkg.fill_var(whole, None, pkg.VAR_HASH, *dims)
     truth = orc.np_gradients(whole.fpoint, whole.fnormal, whole.pvolume, whole.var, whole.nown)

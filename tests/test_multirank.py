@@ -108,6 +108,18 @@ def test_multirank_xgmi_write_notify_other_rungs(gpu, env):
 
 
 @pytest.mark.gpu
+def test_multirank_xgmi_write_notify_on_an_irregular_mesh(gpu):
+    """the same flow on the generator's irregular mesh (random tetrahedralisation, hub points of 50-75 faces, scrambled
+    numbering): tiles of the large image, incidence lists cut into chunks for helper lane groups -- also in BOUNDARY tiles,
+    whose send rows leave from the registers of the point's own lanes after the helpers' sums have joined them -- values of
+    every rank against the un-partitioned mesh and the scaled-field check of every schedule, between processes over real IPC
+    mappings"""
+    _launch(3, ["--gpu", "--transport", "ipc", "--irregular", "--dims", "20,18,16", "--ndomains", "6", "--files", "--soak", "200"],
+            extra_env={"CFDP_IPC_WAIT_INKERNEL": "1"})
+    _launch(2, ["--gpu", "--transport", "staged", "--irregular", "--dims", "20,18,16", "--ndomains", "4"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("forms", ["counter,flag,counter", "flag,counter,flag,flag"])
 def test_neighbours_with_different_notification_forms_understand_each_other(gpu, forms):
     """every rank decides counters or flags on its own (the per-partner protocol depends on its partition) and the two
