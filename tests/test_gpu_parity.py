@@ -1322,6 +1322,46 @@ def p_own(gpart):
     return gpart.dom.nown
 
 
+@pytest.mark.parametrize("tile_points", [16, 64, 128])
+def test_random_multigraph_with_long_lists(gpu, orc, tile_points):
+    """a graph no mesh generator made: random faces, isolated points, parallel faces, a dozen points of 40-90 faces whose
+    lists are cut into chunks for helper lane groups (at 16-point tiles: at most 4 chunks per list) -- separate kernels in
+    two lanes-per-point forms and fused iterations from hipGraphs against the numpy statement, and fused == un-fused bit for bit"""
+    pkg = gpu
+    rng = np.random.default_rng(23)
+    n = 3000
+    deg_target = rng.integers(0, 12, n)
+    deg_target[rng.choice(n, 12, replace=False)] = rng.integers(40, 90, 12)
+    ends = np.repeat(np.arange(n), deg_target)
+    rng.shuffle(ends)
+    fp = np.stack([ends, rng.integers(0, n, len(ends))], 1).astype(np.int32)
+    fp = fp[fp[:, 0] != fp[:, 1]]
+    fn_, vol, var = rng.standard_normal((len(fp), 3)), rng.uniform(0.5, 2.0, n), rng.standard_normal((n, 7)) + 2.0
+    dom = pkg.domain_from_arrays(fp, fn_, vol, n, var=var)
+    g_ref = orc.np_gradients(fp, fn_, vol, var, n)
+    has = np.bincount(fp.ravel(), minlength=n) > 0
+    for lanes in (4, 8):
+        g, f = run_partition(pkg, dom, tile_points, lanes)
+        assert rel_err(orc, g[has], g_ref[has], fp, fn_, vol, var, int(has.sum())) <= TOL or \
+            np.abs(g[has] - g_ref[has]).max() <= TOL * np.abs(g_ref[has]).max(), (tile_points, lanes)
+    part = pkg.GpuPartition(dom, tile_points=tile_points)
+    part.run_iterations(2, True, 0, use_graph=False)
+    part.pull_fields()
+    g_sep, f_sep = dom.grad.copy(), dom.psd_flux.copy()
+    part.set_fusion(True)
+    dom.grad[:] = 1.0
+    dom.psd_flux[:] = 1.0
+    part.push_fields()
+    part.run_iterations(21, True, 0, use_graph=True)
+    part.pull_fields()
+    assert np.array_equal(dom.grad[has], g_sep[has]) and np.array_equal(dom.psd_flux[has], f_sep[has])
+    assert np.abs(dom.grad[has] - g_ref[has]).max() <= TOL * np.abs(g_ref[has]).max()
+    f_ref = orc.np_flux(fp, fn_, dom.grad, n, mode=0)
+    assert np.abs(dom.psd_flux[has] - f_ref[has]).max() <= 1e-11 * np.abs(f_ref[has]).max()
+    part.close()
+    dom.free()
+
+
 def test_small_and_large_tiles_in_launches_of_their_own(gpu, orc):
     """launch groups by capacity class (host/tiling.c 3e, csrc/gpu_abi.hip segs_of): where a plan has many tiles of the small AND
     of the large image the two get launches of their own (CFDP_CLASS_SPLIT_MIN lowered so that a small mesh splits): the tiles

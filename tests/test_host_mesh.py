@@ -537,3 +537,64 @@ def test_long_incidence_lists_are_cut_into_chunks_for_helper_lane_groups(pkg):
     whole.free()
     plan.free()
     irr.free()
+
+
+@pytest.mark.parametrize("tile_points", [8, 16, 32, 64, 128])
+def test_plans_of_irregular_graphs_at_every_tile_size(pkg, orc, tile_points):
+    """the tiler on graphs that are not lattices -- the generator's irregular mesh (with hubs) and a random multigraph with
+    isolated points, parallel faces and a few points of 40-90 faces -- at every tile size: every owned point in exactly one
+    tile, points + helper lane groups within the tile's lane groups, launch groups contiguous and classed as their tiles
+    are, the chunks of a long list covering it exactly once, and the plan INTERPRETED in numpy (tile by tile, incidence word
+    by incidence word) equal to the gradient of the mesh"""
+    rng = np.random.default_rng(17 + tile_points)
+    n = 1500
+    deg_target = rng.integers(0, 12, n)
+    deg_target[rng.choice(n, 12, replace=False)] = rng.integers(40, 90, 12)
+    ends = np.repeat(np.arange(n), deg_target)
+    rng.shuffle(ends)
+    fp = np.stack([ends, rng.integers(0, n, len(ends))], 1).astype(np.int32)
+    fp = fp[fp[:, 0] != fp[:, 1]]
+    rnd = pkg.domain_from_arrays(fp, rng.standard_normal((len(fp), 3)), rng.uniform(0.5, 2.0, n), n, var=rng.standard_normal((n, 7)) + 2.0)
+    irr = pkg.gen_domain(pkg.gen_params(14, 12, 10, ndomains=1, connectivity=pkg.CONN_IRREGULAR, numbering=1), 0)
+    pkg.fill_var(irr, None, pkg.VAR_HASH)
+    pad16 = lambda x: (x + 15) & ~15
+    for dom in (rnd, irr):
+        plan = pkg.Plan(dom, tile_points=tile_points)
+        n2o = plan.new2old
+        deg = np.bincount(dom.fpoint.ravel(), minlength=dom.nall)
+        blob = np.ctypeslib.as_array(plan.p.blob, shape=(plan.blob_bytes,))
+        cover = np.zeros(dom.nown, int)
+        cls = []
+        for t in range(plan.ntiles):
+            td = plan.tile(t)
+            cover[td.pstart: td.pstart + td.npts] += 1
+            plane = pad16(td.nfaces * 8)
+            base = td.blob_off * 16 + 3 * plane + pad16(td.ninc * 4)
+            raw = blob[base: base + (td.npts + 1) * 4].view(np.uint32)
+            nch = (raw[:-1] >> 24).astype(int) + 1
+            d = np.diff((raw & 0xFFFFFF).astype(np.int64))
+            assert np.array_equal(d, deg[n2o[td.pstart: td.pstart + td.npts]])
+            nh = int(nch.sum() - td.npts)
+            assert 0 < td.npts and td.npts + nh <= tile_points
+            behind = td.blob_qw * 16 - (3 * plane + pad16(td.ninc * 4) + pad16((td.npts + 1) * 4))
+            assert behind == (pad16(4 * (1 + nh)) + 192 * nh if nh else 0)
+            for li in np.nonzero(nch > 1)[0]:
+                L = -(-int(d[li]) // int(nch[li]))  # chunk length: the chunks [c L, min((c + 1) L, deg)) cover the list once
+                assert d[li] > 32 and (nch[li] - 1) * L < d[li] <= nch[li] * L
+            cls.append(pkg.host_lib().cfdp_tile_class_of(tile_points, td.npts + td.nhalo, td.blob_qw * 16))
+        assert (cover == 1).all()
+        gb = list(plan.group_begin)[: plan.ngroups + 1]
+        assert gb[0] == plan.nbtiles and gb[-1] == plan.ntiles and gb == sorted(gb)
+        for k in range(plan.ngroups):
+            assert max(cls[gb[k]: gb[k + 1]], default=0) == plan.group_class[k]
+        if plan.ngroups > 1:  # tiles no fixed capacity holds go last
+            assert plan.group_class[plan.ngroups - 1] == 2 and all(c < 2 for c in cls[gb[0]: gb[plan.ngroups - 1]])
+        g = interpret_plan(plan, dom.var[n2o], dom.pvolume[n2o])
+        back = np.empty_like(g)
+        back[n2o] = g
+        ref = orc.np_gradients(dom.fpoint, dom.fnormal, dom.pvolume, dom.var, dom.nown)
+        has = deg[: dom.nown] > 0
+        assert np.abs(back[: dom.nown][has] - ref[: dom.nown][has]).max() <= 1e-12 * np.abs(ref[: dom.nown][has]).max()
+        plan.free()
+    rnd.free()
+    irr.free()
