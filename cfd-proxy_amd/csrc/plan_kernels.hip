@@ -173,15 +173,15 @@ struct blob_args {
   // long incidence lists cut into chunks (cfdproxy_host.h): helper lane groups per tile (0: no list of the tile is cut) and
   // the plan's tile_points (the cap on chunks per list)
   const int *nhelp;                        // [ntiles] (pass B)
-  int tile_points;
+  int tile_points, long_list, list_chunk;  // (cfdp_long_list(), cfdp_list_chunk())
 };
 
 // cfdp_list_chunks (cfdproxy_host.h), for the device
-__device__ __forceinline__ int dev_list_chunks(int deg, int tile_points) {
-  if (deg <= CFDP_LONG_LIST) return 1;
+__device__ __forceinline__ int dev_list_chunks(int deg, int tile_points, int long_list, int list_chunk) {
+  if (deg <= long_list) return 1;
   int cap = tile_points / 4 < CFDP_MAX_CHUNKS ? tile_points / 4 : CFDP_MAX_CHUNKS;
   if (cap < 1) cap = 1;
-  const int n = (deg + CFDP_LIST_CHUNK - 1) / CFDP_LIST_CHUNK;
+  const int n = (deg + list_chunk - 1) / list_chunk;
   return n > cap ? cap : n;
 }
 
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(BLOB_T) void k_tile_blobs(blob_args a, int np_max) 
   int *hp = a.halo_idx + a.hoff[t];
   const int nh = a.nhelp[t];  // helper lane groups of this tile: > 0 = its long lists are cut into chunks
   for (int li = tid; li <= np; li += BLOB_T) {
-    const int nch = nh && li < np ? dev_list_chunks(ioff[li + 1] - ioff[li], a.tile_points) : 1;
+    const int nch = nh && li < np ? dev_list_chunks(ioff[li + 1] - ioff[li], a.tile_points, a.long_list, a.list_chunk) : 1;
     io[li] = (uint32_t)ioff[li] | ((uint32_t)(nch - 1) << 24);
   }
   if (nh && tid == 0) {  // the helper table behind the offsets, in (point, chunk) order (a few entries in a tile in a hundred)
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(BLOB_T) void k_tile_blobs(blob_args a, int np_max) 
     htab[0] = (uint32_t)nh;
     int fill = 0;
     for (int li = 0; li < np; li++) {
-      const int nch = dev_list_chunks(ioff[li + 1] - ioff[li], a.tile_points);
+      const int nch = dev_list_chunks(ioff[li + 1] - ioff[li], a.tile_points, a.long_list, a.list_chunk);
       for (int c = 1; c < nch; c++) htab[1 + fill++] = (uint32_t)li | ((uint32_t)c << 16);
     }
     if (fill != nh) atomicExch(a.bad, 1);
@@ -579,7 +579,7 @@ int stage_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P, void
   PK_TRY(hipMemcpy(hoff.p, h_hoff.data(), sizeof(long) * ((size_t)nt + 1), hipMemcpyHostToDevice));
   PK_TRY(nhelp.alloc((size_t)(nt ? nt : 1)));
   PK_TRY(hipMemcpy(nhelp.p, h_nhelp.data(), sizeof(int) * (size_t)(nt ? nt : 1), hipMemcpyHostToDevice));
-  a.boff = boff.p; a.hoff = hoff.p; a.blob = blob.p; a.halo_idx = halo.p; a.nhelp = nhelp.p; a.tile_points = P->tile_points;
+  a.boff = boff.p; a.hoff = hoff.p; a.blob = blob.p; a.halo_idx = halo.p; a.nhelp = nhelp.p; a.tile_points = P->tile_points; a.long_list = cfdp_long_list(); a.list_chunk = cfdp_list_chunk();
   hipLaunchKernelGGL(k_tile_blobs<true>, dim3(nt), dim3(BLOB_T), lds, 0, a, np_max);
   PK_TRY(hipGetLastError());
   P->blob = static_cast<unsigned char *>(malloc((size_t)(P->blob_bytes ? P->blob_bytes : 16)));

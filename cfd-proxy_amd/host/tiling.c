@@ -32,6 +32,14 @@
 
 int cfdp_tile_class_of(int tile_points, int rows, long blob_bytes) { return cfdp_tile_class(tile_points, rows, blob_bytes); }
 int cfdp_list_chunks_of(int deg, int tile_points) { return cfdp_list_chunks(deg, tile_points); }
+static int g_long_list = CFDP_LONG_LIST, g_list_chunk = CFDP_LIST_CHUNK;
+int cfdp_long_list(void) { return g_long_list; }
+int cfdp_list_chunk(void) { return g_list_chunk; }
+static void list_thresholds_from_env(void) { /* at the start of every plan build (development: CFDP_LONG_LIST, CFDP_LIST_CHUNK) */
+  const char *a = getenv("CFDP_LONG_LIST"), *b = getenv("CFDP_LIST_CHUNK");
+  g_long_list = a && atoi(a) >= 4 ? atoi(a) : CFDP_LONG_LIST;
+  g_list_chunk = b && atoi(b) >= 2 ? atoi(b) : CFDP_LIST_CHUNK;
+}
 
 void cfdp_plan_default_opts(cfdp_plan_opts *o) {
   o->tile_points = 64;
@@ -612,6 +620,7 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
   cfdp_plan_opts o;
   if (opts) o = *opts; else cfdp_plan_default_opts(&o);
   CFDP_ASSERT(o.tile_points >= 8 && o.tile_points <= 1024);
+  list_thresholds_from_env();
   const int nown = sd->nownpoints, nall = sd->nallpoints;
   CFDP_ASSERT(nown > 0 && nall >= nown);
   const int has_comm = cd && cd->ndomains > 1 && cd->ncommdomains > 0;

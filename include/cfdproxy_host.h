@@ -215,11 +215,15 @@ static inline long cfdp_blob_off_bytes(int npts) { return ((long)(npts + 1) * 4 
  * that have helpers, [nhelp | helper h: target li | chunk << 16 | ... pad 16][192 bytes of scratch per helper].  A tile whose
  * points and helpers together exceed tile_points (a tiler that did not plan for them) simply has no list cut.              */
 enum { CFDP_LONG_LIST = 32, CFDP_LIST_CHUNK = 28, CFDP_MAX_CHUNKS = 16 };
+/* (the two thresholds as the library uses them: the constants above unless CFDP_LONG_LIST / CFDP_LIST_CHUNK in the environment say
+ * otherwise -- development; read once, host/tiling.c) */
+int cfdp_long_list(void);
+int cfdp_list_chunk(void);
 static inline int cfdp_list_chunks(int deg, int tile_points) { /* (a tile has tile_points lane groups: at most a quarter per list) */
-  if (deg <= CFDP_LONG_LIST) return 1;
+  if (deg <= cfdp_long_list()) return 1;
   int cap = tile_points / 4 < CFDP_MAX_CHUNKS ? tile_points / 4 : CFDP_MAX_CHUNKS;
   if (cap < 1) cap = 1;
-  const int n = (deg + CFDP_LIST_CHUNK - 1) / CFDP_LIST_CHUNK;
+  const int n = (deg + cfdp_list_chunk() - 1) / cfdp_list_chunk();
   return n > cap ? cap : n;
 }
 int cfdp_list_chunks_of(int deg, int tile_points); /* the same, callable through the ABI */
