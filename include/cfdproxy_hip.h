@@ -219,15 +219,18 @@ int  cfdp_gpu_run_steps_rccl(cfdp_gpu *g, int steps, int with_exchange, int over
  * CFDP_IPC_PER_PARTNER=0, the last boundary tile raises all flags and every tile waits for all).
  *   cfdp_gpu_ipc_mode     bit 0 the fused pass pushes / notifies, bit 1 its tiles wait themselves, bit 2 per-partner
  *                         notification, bit 3 notification by counters, bits 4-5 memory mode (0 coarse, 1 fine,
- *                         2 split); -1 without a block                                                                */
+ *                         2 split), bit 6 the copy-engine put rung; -1 without a block                                */
 /* A rank's block starts with CFDP_IPC_HEADER_BYTES of flag / counter words; landing arena 0 follows, then arena 1.
  * Notification (CFDP_IPC_NOTIFY, cfdp_gpu_ipc_configure): "counter" (default where the per-partner protocol holds) -- a
  * partner's word counts the boundary tiles that have completed their rows for it, raised by fire-and-forget system-scope
  * atomic adds (nothing returns to the tile; the reference's notification travels with the write as well,
  * src/exchange_data_gaspi.c:134-145), a waiter compares it with tiles-per-exchange x exchanges; "flag" -- the tile that
  * completes a partner's rows stores the exchange number (two dependent device-scope atomics decide which tile that is).
- * cfdp_gpu_ipc_ready writes into every partner's header how many of this rank's tiles count per exchange: the hosts must
- * meet (a barrier, a collective) between _ready on every rank and the first exchanging step.
+ * cfdp_gpu_ipc_ready writes into every partner's header what this rank's word advances by per exchange -- its boundary tiles
+ * that count towards that partner when it notifies by counters, 1 when it stores its exchange number -- and every wait
+ * compares a word with exchanges x THAT, whatever the waiting rank's own form: neighbours that resolved to different forms
+ * (the per-partner protocol depends on a rank's own partition) understand each other.  The hosts must meet (a barrier, a
+ * collective) between _ready on every rank and the first exchanging step.
  *   cfdp_gpu_ipc_configure  per context, by argument instead of through the environment (-1 = environment / default):
  *                           memory_mode 0 coarse | 1 fine | 2 split; wait_inkernel 1 | 0 (ranks sharing a device: 0);
  *                           notify 1 counters | 0 flags; push_inkernel 1 the fused pass pushes and notifies itself |
