@@ -613,6 +613,37 @@ cfdp_plan *cfdp_plan_build(const solver_data *sd, const comm_data *cd, const cfd
   return cfdp_plan_build_with(sd, cd, opts, NULL);
 }
 
+/* every owned point into a tile: the boundary sheet first (when there is one to put in front), then the interior.
+ * Returns the number of boundary tiles. */
+static int grow_all(tiler *T, const unsigned char *is_send, const cfdp_plan_opts *o, int grow_fronts) {
+  int nbtiles = 0;
+  if (is_send) {
+    int btp = o->tile_points / 2 < 8 ? 8 : o->tile_points / 2; /* sheets have big halos */
+    tiler_pass(T, is_send, 1, btp);
+    nbtiles = T->ntiles;
+    /* the interior grows from ONE seed, layer by layer, like an un-partitioned mesh: seeding it
+     * from the whole inner side of the boundary sheet makes fronts collide everywhere and leaves
+     * ragged tiles (mean halo 130 instead of 113 rows, maximum 187 instead of 122 -- enough to
+     * push the kernels into the next LDS capacity class and down to 2 workgroups per CU) */
+    memset(T->seeded, 0, (size_t)T->nown);
+    T->sq_head = T->sq_tail = 0;
+  }
+  if (grow_fronts > 1) tiler_pass_multifront(T, is_send, 0, o->tile_points, grow_fronts);
+  else tiler_pass(T, is_send, 0, o->tile_points);
+  return nbtiles;
+}
+
+/* forget the tiles grown so far (growth is run again under other budgets) */
+static void tiler_restart(tiler *T, int nall) {
+  for (int p = 0; p < T->nown; p++) T->tile_of[p] = -1;
+  memset(T->stamp, 0, (size_t)T->nown * sizeof(int));
+  memset(T->seeded, 0, (size_t)T->nown);
+  memset(T->hseen, 0, (size_t)nall * sizeof(int));
+  T->sq_head = T->sq_tail = 0;
+  T->norder = 0;
+  T->ntiles = 0;
+}
+
 /* the plan with stage 1 (point->face CSR) and / or stage 5 (tile blobs) done by `stages` -- e.g. on the device
  * (csrc/plan_kernels.hip) -- and everything else (tile growth, tile order, renumbering, pack lists) here */
 cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, const cfdp_plan_opts *opts,
@@ -724,40 +755,15 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
    * interior tiles, and grow again with both levels only if they stayed below 7/8 full on average.  Growth is the cheap
    * part of the plan (0.02 s at 64^3). */
   const long blob_cap2 = T.blob_cap2;
-  for (int attempt = 0;; attempt++) {
-  if (attempt == 0 && !two_level_forced) T.blob_cap2 = 0;
-  if (any_send && o.boundary_first) {
-    int btp = o.tile_points / 2 < 8 ? 8 : o.tile_points / 2; /* sheets have big halos */
-    tiler_pass(&T, is_send, 1, btp);
-    P->nbtiles = T.ntiles;
-    /* the interior grows from ONE seed, layer by layer, like an un-partitioned mesh: seeding it
-     * from the whole inner side of the boundary sheet makes fronts collide everywhere and leaves
-     * ragged tiles (mean halo 130 instead of 113 rows, maximum 187 instead of 122 -- enough to
-     * push the kernels into the next LDS capacity class and down to 2 workgroups per CU) */
-    memset(T.seeded, 0, (size_t)nown);
-    T.sq_head = T.sq_tail = 0;
-    if (grow_fronts > 1) tiler_pass_multifront(&T, is_send, 0, o.tile_points, grow_fronts);
-    else tiler_pass(&T, is_send, 0, o.tile_points);
-  } else {
-    if (grow_fronts > 1) tiler_pass_multifront(&T, NULL, 0, o.tile_points, grow_fronts);
-    else tiler_pass(&T, NULL, 0, o.tile_points);
-    P->nbtiles = 0;
-  }
-  if (attempt == 0 && !two_level_forced && blob_cap2 > 0 && T.ntiles > P->nbtiles) {
+  if (!two_level_forced) T.blob_cap2 = 0;
+  P->nbtiles = grow_all(&T, any_send && o.boundary_first ? is_send : NULL, &o, grow_fronts);
+  if (!two_level_forced && blob_cap2 > 0 && T.ntiles > P->nbtiles + 1) {
     const long interior_points = nown - T.tile_first[P->nbtiles], interior_tiles = T.ntiles - P->nbtiles;
-    if (interior_points * 8 < interior_tiles * (long)o.tile_points * 7 && interior_tiles > 1) { /* below 7/8 full: again, both levels */
+    if (interior_points * 8 < interior_tiles * (long)o.tile_points * 7) { /* below 7/8 full: again, both levels */
+      tiler_restart(&T, nall);
       T.blob_cap2 = blob_cap2;
-      for (int p = 0; p < nown; p++) T.tile_of[p] = -1;
-      memset(T.stamp, 0, (size_t)nown * sizeof(int));
-      memset(T.seeded, 0, (size_t)nown);
-      memset(T.hseen, 0, (size_t)nall * sizeof(int));
-      T.sq_head = T.sq_tail = 0;
-      T.norder = 0;
-      T.ntiles = 0;
-      continue;
+      P->nbtiles = grow_all(&T, any_send && o.boundary_first ? is_send : NULL, &o, grow_fronts);
     }
-  }
-  break;
   }
   CFDP_ASSERT(T.norder == nown);
   T.tile_first[T.ntiles] = nown;
