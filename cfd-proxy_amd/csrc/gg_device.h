@@ -1271,6 +1271,7 @@ void gg_fused_split_kernel(
     if (!(dbg & 0x200)) push_tile_rows(pa, t, tid, nthr, td, gnew);
     if (!(dbg & 0x400)) push_tile_done(pa, t, tid, iter0, dbg);
   }
+  if constexpr (STAMP) gg_stamp_wave(dbg, (int)gridDim.x, t, 3);  // this wave is through the tile (rows pushed, tile counted)
 }
 
 

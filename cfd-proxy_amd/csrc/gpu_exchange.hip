@@ -956,6 +956,33 @@ int cfdp_gpu_run_steps_ipc(cfdp_gpu *g, int steps, int with_exchange, int overla
   return 0;
 }
 
+// diagnostics: cfdp_gpu_debug_phase_stamps for steps of the write + notify schedule (launched from the streams, with or
+// without the exchange riding in the pass): the stamps of the LAST of `passes` steps
+int cfdp_gpu_debug_phase_stamps_ipc(cfdp_gpu *g, int passes, int with_exchange, unsigned long long *stamps) {
+  NEED_UPLOAD(g);
+  if (!g->ipc.on) return fail("cfdp_gpu_ipc_ready() has not been called");
+  if (!g->fusion || !g->d_grad_alt || passes < 1 || !stamps) return fail("fusion must be on");
+  if (const char *why = gg_diag_available()) return fail("%s", why);
+  for (int i = 0; i < 2; i++)  // (the first step of a run has no flux to fuse with)
+    if (one_step_ipc(g, with_exchange, 1, 1, CFDP_FLUX_CONSISTENT)) return 1;
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long *d = nullptr;
+  const size_t n = (size_t)g->ntiles * 24;
+  HIP_TRY(hipMalloc(&d, n * sizeof(unsigned long long)));
+  HIP_TRY(cfdp_memset_sync(d, 0, n * sizeof(unsigned long long)));
+  HIP_TRY(gg_set_stamp_buffer(d));
+  const int saved = gg_debug_flags;
+  gg_debug_flags |= 0x20000;
+  int rc = 0;
+  for (int i = 0; i < passes && !rc; i++) rc = one_step_ipc(g, with_exchange, 1, 1, CFDP_FLUX_CONSISTENT);
+  gg_debug_flags = saved;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(gg_set_stamp_buffer(nullptr));
+  if (!rc) HIP_TRY(hipMemcpy(stamps, d, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return rc ? 1 : 0;
+}
+
 // how the steps of cfdp_gpu_run_steps_ipc have run on this context so far: replayed from hipGraphs, launched from the
 // streams (lead-in steps, odd remainders, runs of fewer than 4 steps, use_graph = 0 -- or every step when a capture
 // failed), and how many captures were abandoned (0 in every schedule the library selects by itself)

@@ -619,6 +619,10 @@ static int grow_all(tiler *T, const unsigned char *is_send, const cfdp_plan_opts
   int nbtiles = 0;
   if (is_send) {
     int btp = o->tile_points / 2 < 8 ? 8 : o->tile_points / 2; /* sheets have big halos */
+    {
+      const char *e = getenv("CFDP_BOUNDARY_POINTS"); /* experiments: the point cap of the sheet's tiles */
+      if (e && atoi(e) >= 8 && atoi(e) <= o->tile_points) btp = atoi(e);
+    }
     tiler_pass(T, is_send, 1, btp);
     nbtiles = T->ntiles;
     /* the interior grows from ONE seed, layer by layer, like an un-partitioned mesh: seeding it

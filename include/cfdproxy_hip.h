@@ -301,6 +301,8 @@ int  cfdp_gpu_time_fused(cfdp_gpu *g, int iters, int flux_mode, float *ms_fused)
 /* diagnostics: per tile 8 shader-clock stamps of the phase boundaries of the last of `passes` fused passes
  * (start, indices here, loads landed, flux done, var rows in place, gradients done, stores acknowledged, -)  */
 int  cfdp_gpu_debug_phase_stamps(cfdp_gpu *g, int passes, unsigned long long *stamps);
+/* the same for steps of the write + notify schedule (after cfdp_gpu_ipc_ready), with or without the exchange in the pass */
+int  cfdp_gpu_debug_phase_stamps_ipc(cfdp_gpu *g, int passes, int with_exchange, unsigned long long *stamps);
 /* the schedule of an exchange step without the exchange itself (the two brackets only), from one
  * hipGraph or from the streams: average milliseconds per step                             */
 int  cfdp_gpu_time_schedule(cfdp_gpu *g, int steps, int with_exchange, int overlap, int use_graph, float *ms_step);
