@@ -950,6 +950,63 @@ def test_movement_only_instantiation_is_a_floor_and_leaves_real_values(gpu):
     dom.free()
 
 
+def test_phase_stamps_of_the_pass_and_of_the_pushing_pass(gpu):
+    """the stamp diagnostics (lib/libcfdproxy_diag.so, tools/phase_stamps.py and tools/loopback_stamps.py): every tile of a
+    pass leaves seven stamps in order and its place (XCD, CU); with the exchange riding in the pass (loopback) the boundary
+    tiles leave theirs too, their last wave's "pushed and counted" stamp behind everything else; the fields hold real
+    values again afterwards (a stamped pass computes what a pass computes)"""
+    import ctypes as C
+    pkg = gpu
+    from cfd_proxy_amd import multigpu as mg
+    cfg = mg.bench_config("dualgrid.48", 4)
+    gp = pkg.gen_params(*cfg["dims"], ndomains=cfg["ndomains"])
+    parts = [mg.build_rank_partition(gp, cfg["ndomains"], 4, r, via_files=False)[0] for r in range(4)]
+    reqs = [{int(k): (v[0], v[1]) for k, v in pkg.merge_requests(p).items()} for p in parts]
+    mg.exchange_requests(parts[0], 0, 4, None, all_requests=reqs)
+    g = pkg.GpuPartition(parts[0])
+    g.set_fusion(True)
+    nt, nb = g.stats["ntiles"], g.stats["nbtiles"]
+    assert nb > 0
+    g.run_iterations(3, True, 0, use_graph=False)
+    g.pull_fields()
+    g0, f0 = parts[0].grad[: parts[0].nown].copy(), parts[0].psd_flux[: parts[0].nown].copy()
+
+    def check(raw):
+        st = raw[: nt * 8].reshape(nt, 8).astype(np.int64)
+        wv = raw[nt * 8:].reshape(nt, 4, 4).astype(np.int64)
+        assert (st[:, :7] > 0).all(), "a tile left no stamps"
+        assert (np.diff(st[:, :7], axis=1) >= 0).all(), "stamps out of order"
+        assert ((st[:, 7] >> 32) & 0xF).max() < 8 and len(np.unique((st[:, 7] >> 32) & 0xF)) > 1, "XCC_ID"
+        return st, wv
+    raw = np.zeros(nt * 24, np.uint64)
+    g.lib.cfdp_gpu_debug_phase_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    g._ck(g.lib.cfdp_gpu_debug_phase_stamps(g.h, 2, raw.ctypes.data))
+    check(raw)
+    g.pull_fields()
+    assert np.array_equal(parts[0].grad[: parts[0].nown], g0) and np.array_equal(parts[0].psd_flux[: parts[0].nown], f0)
+    # the same with the write + notify schedule, every partner slot looped back
+    g.ipc_export()
+    for s in range(len(g.partners())):
+        g._ck(g.lib.cfdp_gpu_ipc_connect_loopback(g.h, s))
+    g.ipc_ready()
+    g.lib.cfdp_gpu_debug_phase_stamps_ipc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    for ex in (0, 1):
+        raw[:] = 0
+        pkg.kernel_forms()
+        g._ck(g.lib.cfdp_gpu_debug_phase_stamps_ipc(g.h, 3, ex, raw.ctypes.data))
+        forms = pkg.kernel_forms()
+        assert "stamp" in forms, forms
+        st, wv = check(raw)
+        end = wv[:, :, 3].max(axis=1)
+        assert (wv[:, 0, 3] > 0).all() and (end >= st[:, 6]).all(), "the end-of-tile stamp"
+    pkg.kernel_forms_off()
+    assert g.ipc_error() == 0
+    g.ipc_disconnect()
+    g.close()
+    for p in parts:
+        p.free()
+
+
 # ------------------------------------------------------------------ BASELINE.json configs 3-5
 @pytest.mark.parametrize("label,n,nd,G", [
     ("dualgrid.48 lvl 2 on 4 ranks", 64, 48, 4),
