@@ -88,7 +88,7 @@ def cpu_model() -> str:
 def kernel_source_tag() -> str:
     """identifies the kernel build a committed PMC measurement belongs to"""
     h = hashlib.sha256()
-    for f in ("cfd-proxy_amd/csrc/gg_kernels.hip", "cfd-proxy_amd/host/tiling.c"):
+    for f in ("cfd-proxy_amd/csrc/gg_device.h", "cfd-proxy_amd/csrc/gg_kernels.hip", "cfd-proxy_amd/host/tiling.c"):
         h.update(open(os.path.join(ROOT, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -57,7 +57,7 @@ for n, label in ((64, "dualgrid.12 lvl 2 stand-in (64^3)"), (128, "dualgrid.384 
     result[label] = entry
 import hashlib
 h = hashlib.sha256()
-for f in ("cfd-proxy_amd/csrc/gg_kernels.hip", "cfd-proxy_amd/host/tiling.c"):  # = bench.py kernel_source_tag()
+for f in ("cfd-proxy_amd/csrc/gg_device.h", "cfd-proxy_amd/csrc/gg_kernels.hip", "cfd-proxy_amd/host/tiling.c"):  # = bench.py kernel_source_tag()
     h.update(open(os.path.join(ROOT, f), "rb").read())
 result["kernel_source_tag"] = h.hexdigest()[:16]
 json.dump(result, open(os.path.join(out_dir, f"{tag}_traffic.json"), "w"), indent=1)
