@@ -298,8 +298,10 @@ int  cfdp_gpu_scaled_check_end(cfdp_gpu *g, cfdp_scaled_check *out);
 int  cfdp_gpu_time_kernels(cfdp_gpu *g, int iters, int flux_mode, float *ms_grad, float *ms_flux);
 /* average milliseconds of the fused pass (flux(i) + gradients(i+1), all tiles); fusion on  */
 int  cfdp_gpu_time_fused(cfdp_gpu *g, int iters, int flux_mode, float *ms_fused);
-/* diagnostics: per tile 8 shader-clock stamps of the phase boundaries of the last of `passes` fused passes
- * (start, indices here, loads landed, flux done, var rows in place, gradients done, stores acknowledged, -)  */
+/* diagnostics (needs lib/libcfdproxy_diag.so): shader-clock stamps (s_memtime: one clock per XCD) of the last of `passes` fused
+ * passes.  `stamps` takes 24 words per tile: [ntiles][8] -- start, indices here, loads landed, flux done, var rows in place,
+ * gradients done, stores acknowledged, and the tile's place (XCC_ID register << 32 | HW_ID register) -- then [ntiles][4 waves][4]
+ * -- the wave's own pieces landed, through its flux phase, through its gradient phase, through the tile (rows pushed, tile counted) */
 int  cfdp_gpu_debug_phase_stamps(cfdp_gpu *g, int passes, unsigned long long *stamps);
 /* the same for steps of the write + notify schedule (after cfdp_gpu_ipc_ready), with or without the exchange in the pass */
 int  cfdp_gpu_debug_phase_stamps_ipc(cfdp_gpu *g, int passes, int with_exchange, unsigned long long *stamps);
