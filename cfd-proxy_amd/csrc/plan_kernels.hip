@@ -337,7 +337,7 @@ __global__ __launch_bounds__(BLOB_T) void k_tile_blobs(blob_args a, int np_max) 
         if (face < 0) {  // internal face met at its p1 end: numbered at q's incidence of the same face (sign 0)
           int lo = a.xadj[q], hi = a.xadj[q + 1] - 1;
           while (lo < hi) {  // q's list is sorted by (face, sign)
-            const int mid = (lo + hi) >> 1;
+            const int mid = lo + ((hi - lo) >> 1);  // (lo + hi overflows an int once the mesh has more than 2^29 faces)
             if (adj_key(a.adj_face[mid]) < ((unsigned long long)(unsigned)f << 1)) lo = mid + 1; else hi = mid;
           }
           face = lf[ioff[lq] + (lo - a.xadj[q])];

@@ -463,7 +463,11 @@ static int host_blobs(const solver_data *sd, const cfdp_tiling *tl, cfdp_plan *P
       }
       P->blob_bytes = boff[P->ntiles];
       P->nhalo_total = hoff[P->ntiles];
-      CFDP_ASSERT(P->blob_bytes % 16 == 0 && P->blob_bytes / 16 < 0x7FFFFFFF);
+      if (P->blob_bytes / 16 >= 0x7FFFFFFF || P->nhalo_total >= 0x7FFFFFFF) /* (measured up to 32.1 GB: 110.6 M points, 771 M faces) */
+        fprintf(stderr, "cfdp_plan: %.1f GB of tile blobs / %ld halo row numbers in ONE partition: a tile's offsets are 32-bit (16-byte units), "
+                        "a partition holds at most 34 GB of blobs -- about 118 M points of a mesh like the F6 dual grid; cut the mesh "
+                        "into more domains and give each GPU several ranks\n", (double)P->blob_bytes / 1e9, (long)P->nhalo_total);
+      CFDP_ASSERT(P->blob_bytes % 16 == 0 && P->blob_bytes / 16 < 0x7FFFFFFF && P->nhalo_total < 0x7FFFFFFF);
       P->blob = cfdp_malloc((size_t)(P->blob_bytes ? P->blob_bytes : 16));
       P->halo_idx = cfdp_malloc((size_t)(P->nhalo_total ? P->nhalo_total : 1) * sizeof(int));
     }
@@ -658,6 +662,7 @@ cfdp_plan *cfdp_plan_build_with(const solver_data *sd, const comm_data *cd, cons
   list_thresholds_from_env();
   const int nown = sd->nownpoints, nall = sd->nallpoints;
   CFDP_ASSERT(nown > 0 && nall >= nown);
+  CFDP_ASSERT((long)sd->nfaces * 2 < 0x7FFFFFFF); /* the point->face lists are indexed by ints: 2 entries per face */
   const int has_comm = cd && cd->ndomains > 1 && cd->ncommdomains > 0;
 
   const int trace = getenv("CFDP_PLAN_TRACE") != NULL;
