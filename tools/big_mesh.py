@@ -1,7 +1,8 @@
 """the hot path at a size that needs the card: an N^3 lattice stand-in in ONE domain on one GPU (N = 256: 16.8 M points, 116 M
 faces; N = 320: 32.8 M points, 228 M faces, a 9.5-GB tile blob) -- plan (device stages), upload, fused iterations from a
 hipGraph, EVERY row against the C oracle with the tolerance of SURVEY 8c (cancellation scale computed in chunks), kernel
-times.  Refuses when the host's available memory is below what the check needs.  python tools/big_mesh.py [N] [tile_points]"""
+times.  Refuses when the host's available memory is below what the check needs.  python tools/big_mesh.py [N] [tile_points]; IRREGULAR=1: the
+generator's irregular option (capacity classes in launches of their own, long lists in chunks) at that size"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +30,11 @@ def stage(name, t):
     print(f"[{time.time() - T0:7.1f} s] {name}: {time.time() - t:.1f} s", flush=True)
 
 
-t = time.time(); dom = m.gen_domain(m.gen_params(n, ndomains=1), 0); m.fill_var(dom, None, m.VAR_HASH); stage("generate", t)
+irr = os.environ.get("IRREGULAR", "0") != "0"  # the generator's irregular option (random tetrahedralisation + hubs, scrambled numbering)
+out["connectivity"] = "irregular" if irr else "lattice stand-in"
+t = time.time()
+dom = m.gen_domain(m.gen_params(n, ndomains=1, connectivity=m.CONN_IRREGULAR if irr else 7, numbering=1 if irr else 0), 0)
+m.fill_var(dom, None, m.VAR_HASH); stage("generate", t)
 out["faces"] = int(dom.nfaces)
 t = time.time(); g = m.GpuPartition(dom, tile_points=tp); stage("plan + upload", t)
 st = g.stats
@@ -82,5 +87,5 @@ out["parity"] = {"gradient_rows_compared": P, "worst_component_error_over_scale"
                  "flux_inf_norm_ratio": fe, "tolerance": 1e-10, "ok": bool(worst <= 1e-10 and dmax / gmax <= 1e-10 and fe <= 1e-10)}
 print(json.dumps(out), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"big_mesh_{n}.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"big_mesh_{n}{'_irregular' if irr else ''}.json"), "w"), indent=1)
 sys.exit(0 if out["parity"]["ok"] else 1)
