@@ -14,12 +14,14 @@ def timed(g, steps, reps, **kw):
     return best * 1e6
 
 variants = os.environ.get("VARIANTS", "A=1;CFDP_DEGREE_SORT=0;CFDP_TILE_BUDGET=1;A=2").split(";")
-for name in os.environ.get("CONFIGS8", "dualgrid.384,dualgrid.192").split(","):
-    cfg = mg.bench_config(name, 8)
+for name in os.environ.get("CONFIGS8", "dualgrid.384,dualgrid.192").split(","):  # NAME or NAME:RANKS (8 ranks unless said)
+    name, _, w = name.partition(":")
+    world = int(w or 8)
+    cfg = mg.bench_config(name, world)
     gp = pkg.gen_params(*cfg["dims"], ndomains=cfg["ndomains"])
-    parts = [mg.build_rank_partition(gp, cfg["ndomains"], 8, r, via_files=False)[0] for r in range(8)]
+    parts = [mg.build_rank_partition(gp, cfg["ndomains"], world, r, via_files=False)[0] for r in range(world)]
     reqs = [{int(k): (v[0], v[1]) for k, v in pkg.merge_requests(p).items()} for p in parts]
-    mg.exchange_requests(parts[0], 0, 8, None, all_requests=reqs)
+    mg.exchange_requests(parts[0], 0, world, None, all_requests=reqs)
     for var in variants:
         sets = [kv.split("=", 1) for kv in var.split() if "=" in kv]
         for k, v in sets:
