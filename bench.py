@@ -385,14 +385,14 @@ def main() -> None:
                 # twice: median 36.9-37.0 -> 36.2 us/step, quartiles 36.6-37.5 -> 36.1-36.3; EXPERIMENTS E.12)
                 if PRIMER:
                     if world == 1:
-                        solver.gpu.run_iterations(steps, with_flux=True, use_graph=True)
+                        solver.gpu.run_iterations(steps, with_flux=True, use_graph=True, device_time=False)
                     else:
                         solver.run_steps(steps, **kw)
                     cond["primer"] = steps
             barrier()
             t = time.perf_counter()
-            if world == 1:
-                solver.gpu.run_iterations(steps, with_flux=True, use_graph=True)
+            if world == 1:  # (device_time=False: no HIP event pair around a run the host clock times -- 0.2 us/step, E.12)
+                solver.gpu.run_iterations(steps, with_flux=True, use_graph=True, device_time=False)
             else:
                 solver.run_steps(steps, **kw)
             solver.synchronize()   # device sync (+ torch.cuda.synchronize): every rank's K steps are done ...

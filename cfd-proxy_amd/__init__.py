@@ -948,7 +948,12 @@ class GpuPartition:
         return g.value, f.value
 
     def run_iterations(self, iters: int, with_flux: bool = True, flux_mode: int = FLUX_CONSISTENT,
-                       use_graph: bool = True) -> float:
+                       use_graph: bool = True, device_time: bool = True) -> float:
+        """returns the device time of the run in ms (HIP events around it); device_time = False: no event pair -- for a
+        caller that times the run itself -- and 0.0 comes back"""
+        if not device_time:
+            self._ck(self.lib.cfdp_gpu_run_iterations(self.h, iters, int(with_flux), flux_mode, int(use_graph), None))
+            return 0.0
         ms = C.c_float()
         self._ck(self.lib.cfdp_gpu_run_iterations(self.h, iters, int(with_flux), flux_mode, int(use_graph),
                                                   C.byref(ms)))

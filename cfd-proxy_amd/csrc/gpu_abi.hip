@@ -1122,7 +1122,8 @@ static int run_or_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int 
   if (chunk && capture(g->graph, g->graph_iters, chunk)) return 1;
   if (rem && capture(g->graph_rem, g->graph_rem_iters, rem)) return 1;
   if (!run) return 0;
-  HIP_TRY(hipEventRecord(g->ev_a, st));
+  // (ms_total == NULL: the caller times the run itself -- no event pair around it, the call returns when the stream is through)
+  if (ms_total) HIP_TRY(hipEventRecord(g->ev_a, st));
   if (whole) {
     g->main_marked = false;
     HIP_TRY(hipGraphLaunch(g->graph_rem, st));
@@ -1147,11 +1148,15 @@ static int run_or_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int 
     if (eager && body(eager)) return 1;
     if (fuse && flush_flux(g, false, st)) return 1;  // flux of the last iteration
   }
+  if (!ms_total) {
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+  }
   HIP_TRY(hipEventRecord(g->ev_b, st));
   HIP_TRY(hipEventSynchronize(g->ev_b));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, g->ev_a, g->ev_b));
-  if (ms_total) *ms_total = ms;
+  *ms_total = ms;
   return 0;
 }
 

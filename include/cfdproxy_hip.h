@@ -310,7 +310,8 @@ int  cfdp_gpu_debug_phase_stamps_ipc(cfdp_gpu *g, int passes, int with_exchange,
 int  cfdp_gpu_time_schedule(cfdp_gpu *g, int steps, int with_exchange, int overlap, int use_graph, float *ms_step);
 /* K full iterations (gradients [+flux]) replayed from hipGraphs -- whole chunks (50 fused passes
  * / 25 iterations, the reference's NITER, src/hybrid.f6.c:72) plus one graph for the remainder, so
- * any K runs without per-kernel stream launches; ms_total: device time of the K iterations      */
+ * any K runs without per-kernel stream launches; ms_total: device time of the K iterations
+ * (HIP events around them), or NULL: no event pair, the call returns when the stream is through  */
 int  cfdp_gpu_run_iterations(cfdp_gpu *g, int iters, int with_flux, int flux_mode,
                              int use_graph, float *ms_total);
 /* the data-movement floor of the fused pass: the same kernel without its two face loops (every load and every store of

@@ -1,7 +1,8 @@
 """The distribution of bench.py's 20-step timed region (one partition): the same sequence -- 0.25 s of conditioning, graphs
 instantiated again, sync, K steps, sync -- repeated REPS times in one process, for several ways of preparing the region
 (MODES): refresh = bench.py's; primer = refresh, then the timed graph launched once (untimed) and a sync; none = no refresh;
-upload = refresh with CFDP_GRAPH_UPLOAD=1 in the environment (hipGraphUpload behind every instantiation)."""
+noevents = primer, and the timed run without the HIP event pair around it (cfdp_gpu_run_iterations with ms_total = NULL).
+(A build with hipGraphUpload behind every instantiation was measured with the refresh mode too: worse, not kept.)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -19,11 +20,11 @@ def region(mode):
     g.run_iterations(COND + 1, True, 0, use_graph=True)
     if mode != "none":
         g.refresh_graphs()
-    if mode == "primer":
+    if mode in ("primer", "noevents"):
         g.run_iterations(K, True, 0, use_graph=True)
     g.sync(); torch.cuda.synchronize()
     t = time.perf_counter()
-    g.run_iterations(K, True, 0, use_graph=True)
+    g.run_iterations(K, True, 0, use_graph=True, device_time=mode != "noevents")
     g.sync(); torch.cuda.synchronize()
     return (time.perf_counter() - t) / K * 1e6
 for mode in os.environ.get("MODES", "refresh,primer,none,refresh,primer").split(","):
