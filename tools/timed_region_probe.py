@@ -27,6 +27,26 @@ def region(mode):
     g.run_iterations(K, True, 0, use_graph=True, device_time=mode != "noevents")
     g.sync(); torch.cuda.synchronize()
     return (time.perf_counter() - t) / K * 1e6
+if os.environ.get("BREAKDOWN"):  # where the region's wall time goes: the call (launch + stream sync), the context's sync, torch's
+    rows = []
+    for _ in range(REPS):
+        g.prepare_iterations(K, True, 0)
+        g.run_iterations(COND + 1, True, 0, use_graph=True)
+        g.refresh_graphs()
+        g.run_iterations(K, True, 0, use_graph=True, device_time=False)
+        g.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g.run_iterations(K, True, 0, use_graph=True, device_time=False)
+        t1 = time.perf_counter()
+        g.sync()
+        t2 = time.perf_counter()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        rows.append(((t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6))
+    a = np.median(np.array(rows), axis=0)
+    print(f"median us per region of {K} steps: run_iterations (launch + stream sync) {a[0]:.1f}, context sync {a[1]:.1f}, torch.cuda.synchronize {a[2]:.1f}", flush=True)
+    g.close()
+    sys.exit(0)
 for mode in os.environ.get("MODES", "refresh,primer,none,refresh,primer").split(","):
     w = np.array([region(mode) for _ in range(REPS)])
     print(f"{mode:8s}: us/step min {w.min():.2f} p25 {np.percentile(w,25):.2f} median {np.median(w):.2f} p75 {np.percentile(w,75):.2f} max {w.max():.2f}; "
