@@ -330,7 +330,9 @@ int  cfdp_gpu_prepare_iterations(cfdp_gpu *g, int iters, int with_flux, int flux
 /* instantiate every cached graph (those of cfdp_gpu_run_iterations and of cfdp_gpu_run_steps_ipc) again from the graph
  * it was captured as; syncs the device first.  For a caller that times a SHORT run on an idle device: an executable
  * graph instantiated before other work went through the device starts 60-100 us later than one instantiated just before
- * its launch (measured); replays queued behind running work do not see that.  ~50 us per graph.  */
+ * its launch (measured); replays queued behind running work do not see that.  ~50 us per graph.
+ * The FIRST replay of a freshly instantiated graph pays the runtime's set-up for it (~15 us, and a variable amount): a
+ * caller that times a short run replays it once, untimed, between this call and its timed replay (EXPERIMENTS.md E.12). */
 int  cfdp_gpu_refresh_graphs(cfdp_gpu *g);
 
 /* multigrid "3V cycle" (documentation/CFD-Proxy.pdf p.3; levels = the -lvl files of
