@@ -1,5 +1,5 @@
 for rep in 1 2 3; do
-for S in 0.25 1.0 0.5 2.0; do
+for S in ${SWEEP:-0.25 1.0 0.5 2.0}; do
   echo -n "CONDITION_S=$S: "
   CFDP_BENCH_CONDITION_S=$S python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-finest --no-loopback --no-irregular --no-power 2>/dev/null | python -c "
 import sys,json
